@@ -1,0 +1,90 @@
+"""ctypes binding of libcrossscore_hip.so (include/crossscore_hip.h).  Fails loudly when the library is
+missing: there is no CPU or eager fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcrossscore_hip.so")
+
+CS_OK, CS_ERR_BAD_ARG, CS_ERR_UNSUPPORTED, CS_ERR_STATE, CS_ERR_HIP = range(5)
+
+# CsEpilogue (csrc/cs_common.h)
+EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_LEAKY_BF16, EPI_RESID_F32, EPI_PATCH_F32, EPI_HEAD_SCORE = range(7)
+
+
+class CsConfig(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int), ("enc_layers", C.c_int), ("enc_heads", C.c_int), ("mlp_ratio", C.c_int),
+        ("patch", C.c_int), ("pos_grid", C.c_int), ("pe_h", C.c_int), ("pe_w", C.c_int),
+        ("dec_layers", C.c_int), ("dec_heads", C.c_int), ("do_self_attn", C.c_int), ("do_short_cut", C.c_int),
+        ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int),
+    ]
+
+
+# every symbol include/crossscore_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+SYMBOLS = {
+    "cs_create": (_vp, [C.POINTER(CsConfig)]),
+    "cs_destroy": (None, [_vp]),
+    "cs_last_error": (C.c_char_p, []),
+    "cs_set_weight": (_i, [_vp, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64)]),
+    "cs_num_weights": (_i, [_vp]),
+    "cs_weight_name": (C.c_char_p, [_vp, _i]),
+    "cs_finalize": (_i, [_vp]),
+    "cs_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "cs_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "cs_profile_enable": (_i, [_vp, _i]),
+    "cs_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "cs_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "cs_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cs_op_attention_weights": (_i, [_vp, _vp, _i, _i, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "cs_op_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "cs_op_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cs_op_pos_bicubic": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "cs_op_pe_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cs_op_pack_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+}
+
+_lib = None
+
+
+class CrossScoreHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and bind every declared symbol.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CrossScoreHipError(
+            f"{LIB_PATH} is missing: build it with `python -m crossscore_amd.build` (hipcc --offload-arch=gfx950). "
+            "The CrossScore hot path has no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().cs_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Maps library status codes to the exceptions the reference raises for the same conditions:
+    ValueError for bad shapes / configs (regression_layer.py:37, check_config.py:23-28, image.py:15 assert),
+    RuntimeError for state and HIP errors (load_state_dict / CUDA errors)."""
+    if rc == CS_OK:
+        return
+    msg = last_error()
+    if rc in (CS_ERR_BAD_ARG,):
+        raise ValueError(msg)
+    if rc == CS_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise CrossScoreHipError(msg)

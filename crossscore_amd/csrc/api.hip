@@ -1,0 +1,640 @@
+// C ABI + forward orchestration of the CrossScore gfx950 path (see include/crossscore_hip.h).
+// Host-side only: owns packed weights + workspace, validates shapes, enqueues the HIP kernels of gemm.hip,
+// attention.hip and elementwise.hip on the caller's stream.  Restates the control flow of
+// CrossScoreNet.forward / get_featmaps (task/core.py:58-161), CrossReferenceNet.forward
+// (model/cross_reference.py:52-94) and the post-norm decoder layer (transformer.py:157-173).
+#include "../../include/crossscore_hip.h"
+#include "cs_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+extern "C" {
+const char* cs_gemm_check(const CsGemmParams* p, int epi);
+hipError_t cs_gemm_launch(const CsGemmParams* p, int epi, hipStream_t stream);
+const char* cs_attn_check(const CsAttnParams* p, int dh, int batch);
+hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, hipStream_t stream);
+hipError_t cs_im2col_launch(const float* q, const float* refs, int N, int img0, bf16_t* out, int I, int H, int W, int P, int Kp,
+                            hipStream_t st);
+hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32, bf16_t* obf,
+                               hipStream_t st);
+hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
+                                    const float* pe, float* q_f32, bf16_t* q_bf, bf16_t* mem_bf, hipStream_t st);
+hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, hipStream_t st);
+hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float* out, hipStream_t st);
+hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st);
+hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, hipStream_t st);
+hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
+hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
+}
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(CS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct Tensor {
+  std::vector<int64_t> shape;
+  float* d = nullptr;
+  size_t numel = 0;
+};
+
+struct EncLayer {
+  float *ln1g, *ln1b, *ln2g, *ln2b, *bqkv, *bo, *b1, *b2, *ls1, *ls2;
+  bf16_t *Wqkv, *Wo, *W1, *W2;
+};
+struct DecLayer {
+  float *sa_bin, *sa_bo, *ca_bq, *ca_bo, *l1b, *l2b, *n1g, *n1b, *n2g, *n2b, *n3g, *n3b;
+  bf16_t *sa_Win, *sa_Wo, *ca_Wq, *ca_Wo, *l1W, *l2W;
+};
+
+struct ProfRec { hipEvent_t a, b; int family; double flops; };
+
+}  // namespace
+
+struct cs_model {
+  cs_config cfg{};
+  std::vector<std::string> names;
+  std::map<std::string, Tensor> w;
+  bool finalized = false;
+  int Kp = 0;  // padded patch K
+  std::vector<void*> owned;  // device allocations of packed weights
+  // packed
+  bf16_t* Wpatch = nullptr; float* bpatch = nullptr;
+  std::vector<EncLayer> enc;
+  std::vector<DecLayer> dec;
+  bf16_t* Wkv_all = nullptr; float* bkv_all = nullptr;
+  bf16_t *Wh0 = nullptr, *Wh2 = nullptr; float *bh0 = nullptr, *bh2 = nullptr;
+  float *lnfg = nullptr, *lnfb = nullptr, *cls = nullptr, *pos = nullptr, *pe = nullptr;
+  // per-(gh,gw,square) tables
+  int tab_gh = -1, tab_gw = -1, tab_sq = -1;
+  float *pos_tab = nullptr, *pe_tab = nullptr; bool pos_tab_owned = false;
+  // workspace
+  char* ws = nullptr; size_t ws_bytes = 0;
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+};
+
+namespace {
+
+std::vector<std::string> expected_names(const cs_config& c) {
+  std::vector<std::string> n;
+  n.push_back("img_mean_std");
+  const std::string e = "backbone.embeddings.";
+  n.push_back(e + "cls_token"); n.push_back(e + "mask_token"); n.push_back(e + "position_embeddings");
+  n.push_back(e + "patch_embeddings.projection.weight"); n.push_back(e + "patch_embeddings.projection.bias");
+  for (int l = 0; l < c.enc_layers; ++l) {
+    const std::string p = "backbone.encoder.layer." + std::to_string(l) + ".";
+    for (const char* s : {"norm1.weight", "norm1.bias", "attention.attention.query.weight", "attention.attention.query.bias",
+                          "attention.attention.key.weight", "attention.attention.key.bias", "attention.attention.value.weight",
+                          "attention.attention.value.bias", "attention.output.dense.weight", "attention.output.dense.bias",
+                          "layer_scale1.lambda1", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
+                          "mlp.fc2.bias", "layer_scale2.lambda1"})
+      n.push_back(p + s);
+  }
+  n.push_back("backbone.layernorm.weight"); n.push_back("backbone.layernorm.bias");
+  n.push_back("pos_enc_fn.PE");
+  for (int l = 0; l < c.dec_layers; ++l) {
+    const std::string p = "ref_cross.attn.layers." + std::to_string(l) + ".";
+    std::vector<std::string> blocks;
+    if (c.do_self_attn) blocks.push_back("self_attn");
+    blocks.push_back("multihead_attn");
+    for (auto& b : blocks)
+      for (const char* s : {".in_proj_weight", ".in_proj_bias", ".out_proj.weight", ".out_proj.bias"}) n.push_back(p + b + s);
+    for (const char* s : {"linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "norm1.weight", "norm1.bias",
+                          "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias"})
+      n.push_back(p + s);
+  }
+  for (const char* s : {"ref_cross.head.0.weight", "ref_cross.head.0.bias", "ref_cross.head.2.weight", "ref_cross.head.2.bias"})
+    n.push_back(s);
+  return n;
+}
+
+bool supported_dh(int dh) { return dh == 16 || dh == 48 || dh == 64 || dh == 96; }
+
+struct Arena {  // carve 256-byte aligned pieces out of the workspace
+  char* base; size_t off = 0;
+  template <typename T> T* take(size_t n) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off += (n * sizeof(T) + 255) & ~size_t(255);
+    return p;
+  }
+};
+
+struct Plan {
+  int B, N, H, W, gh, gw, Np, T, I, Ic, C;
+  size_t total;
+  // encoder chunk
+  float* x; bf16_t* u; bf16_t* r1;
+  // decoder
+  float *xq, *y, *lse; bf16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
+};
+
+Plan make_plan(const cs_model* m, int B, int N, int H, int W, char* base) {
+  Plan p{};
+  const cs_config& c = m->cfg;
+  p.B = B; p.N = N; p.H = H; p.W = W; p.C = c.hidden;
+  p.gh = H / c.patch; p.gw = W / c.patch; p.Np = p.gh * p.gw; p.T = p.Np + 1; p.I = B * (1 + N);
+  int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 16 : 8);
+  // keep chunks balanced: same number of passes, near-equal sizes
+  const int passes = (p.I + ic - 1) / ic;
+  p.Ic = (p.I + passes - 1) / passes;
+  const size_t C = c.hidden, Mc = (size_t)p.Ic * p.T, M = (size_t)B * p.Np, Mk = (size_t)B * N * p.Np;
+  Arena a{base};
+  p.x = a.take<float>(Mc * C);
+  p.u = a.take<bf16_t>(Mc * C);
+  p.r1 = a.take<bf16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * 3 * C, (size_t)p.Ic * p.Np * m->Kp)));
+  p.xq = a.take<float>(M * C);
+  p.y = a.take<float>(M * C);
+  p.q_bf = a.take<bf16_t>(M * C);
+  p.mem_bf = a.take<bf16_t>(Mk * C);
+  p.kv = a.take<bf16_t>(Mk * 2 * C * c.dec_layers);
+  p.dqkv = a.take<bf16_t>(M * 3 * C);
+  p.dq = a.take<bf16_t>(M * C);
+  p.dob = a.take<bf16_t>(M * C);
+  p.dhid = a.take<bf16_t>(M * C);
+  p.lse = a.take<float>((size_t)B * c.dec_heads * p.Np);
+  p.total = a.off;
+  return p;
+}
+
+// launch helpers that record profiling events when enabled
+struct Launcher {
+  cs_model* m; hipStream_t st; int rc = 0;
+  void begin(int family, double flops) {
+    if (!m->prof) return;
+    ProfRec r{}; r.family = family; r.flops = flops;
+    hipEventCreate(&r.a); hipEventCreate(&r.b);
+    hipEventRecord(r.a, st);
+    m->recs.push_back(r);
+  }
+  void end() { if (m->prof) hipEventRecord(m->recs.back().b, st); }
+  bool gemm(CsGemmParams g, int epi, double k_real = 0) {
+    if (rc) return false;
+    if (const char* e = cs_gemm_check(&g, epi)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
+    begin(0, 2.0 * g.M * g.N * (k_real > 0 ? k_real : g.K));
+    hipError_t e = cs_gemm_launch(&g, epi, st);
+    end();
+    if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "gemm launch: %s", hipGetErrorString(e)); return false; }
+    return true;
+  }
+  bool attn(CsAttnParams a, int dh, int batch) {
+    if (rc) return false;
+    if (const char* e = cs_attn_check(&a, dh, batch)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
+    begin(1, 4.0 * batch * a.heads * (double)a.Lq * a.Lk * dh);
+    hipError_t e = cs_attn_launch(&a, dh, batch, st);
+    end();
+    if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "attention launch: %s", hipGetErrorString(e)); return false; }
+    return true;
+  }
+  bool misc(hipError_t e, const char* what) {
+    if (rc) return false;
+    if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e)); return false; }
+    return true;
+  }
+};
+
+CsGemmParams gp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const float* bias, void* out, int ldc) {
+  CsGemmParams g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldc = ldc;
+  g.powp = 1.f;
+  return g;
+}
+
+int ensure_tables(cs_model* m, int gh, int gw, bool square, hipStream_t st) {
+  const cs_config& c = m->cfg;
+  const int sq = square ? 1 : 0;
+  if (m->tab_gh == gh && m->tab_gw == gw && m->tab_sq == sq) return 0;
+  // tables may still be read by work queued on st from a previous shape
+  HIPCHK(hipStreamSynchronize(st));
+  if (m->pos_tab && m->pos_tab_owned) hipFree(m->pos_tab);
+  if (m->pe_tab && m->pe_tab != m->pe) hipFree(m->pe_tab);
+  m->pos_tab = nullptr; m->pe_tab = nullptr; m->pos_tab_owned = false;
+  const int Np = gh * gw, C = c.hidden;
+  if (Np == c.pos_grid * c.pos_grid && square) {  // HF:71 -- parameter used as is
+    m->pos_tab = m->pos;
+  } else {
+    HIPCHK(hipMalloc(&m->pos_tab, (size_t)(1 + Np) * C * sizeof(float)));
+    m->pos_tab_owned = true;
+    HIPCHK(cs_pos_bicubic_launch(m->pos, c.pos_grid, C, gh, gw, m->pos_tab, st));
+  }
+  if (gh == c.pe_h && gw == c.pe_w) {  // positional_encoding.py:51-56
+    m->pe_tab = m->pe;
+  } else {
+    HIPCHK(hipMalloc(&m->pe_tab, (size_t)Np * C * sizeof(float)));
+    HIPCHK(cs_pe_bilinear_launch(m->pe, c.pe_h, c.pe_w, C, gh, gw, m->pe_tab, st));
+  }
+  m->tab_gh = gh; m->tab_gw = gw; m->tab_sq = sq;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cs_last_error(void) { return g_err.c_str(); }
+
+cs_handle cs_create(const cs_config* cfg) {
+  if (!cfg) { fail(CS_ERR_BAD_ARG, "cs_create: null config"); return nullptr; }
+  const cs_config& c = *cfg;
+  if (c.hidden <= 0 || c.hidden % 64 || c.hidden > 1024) { fail(CS_ERR_UNSUPPORTED, "hidden=%d must be a multiple of 64 and <= 1024", c.hidden); return nullptr; }
+  if (c.enc_layers <= 0 || c.enc_heads <= 0 || c.hidden % c.enc_heads) { fail(CS_ERR_BAD_ARG, "bad encoder layers/heads"); return nullptr; }
+  if (!supported_dh(c.hidden / c.enc_heads)) { fail(CS_ERR_UNSUPPORTED, "encoder head dim %d not in {16,48,64,96}", c.hidden / c.enc_heads); return nullptr; }
+  if (c.dec_heads <= 0 || c.hidden % c.dec_heads || !supported_dh(c.hidden / c.dec_heads)) { fail(CS_ERR_UNSUPPORTED, "decoder head dim %d not in {16,48,64,96}", c.dec_heads > 0 ? c.hidden / c.dec_heads : 0); return nullptr; }
+  if (c.dec_layers <= 0 || c.patch <= 0 || (c.patch * c.patch) % 4 || c.pos_grid <= 0 || c.pe_h <= 0 || c.pe_w <= 0 || c.mlp_ratio <= 0) { fail(CS_ERR_BAD_ARG, "bad config"); return nullptr; }
+  if (c.act != 0 && c.act != 1) { fail(CS_ERR_BAD_ARG, "act must be 0 (sigmoid) or 1 (tanh)"); return nullptr; }
+  if (c.act == 1 && c.pow_p != 1.0f) { fail(CS_ERR_BAD_ARG, "power factor applies only to the sigmoid range"); return nullptr; }
+  cs_model* m = new cs_model();
+  m->cfg = c;
+  m->names = expected_names(c);
+  m->Kp = ((3 * c.patch * c.patch + 63) / 64) * 64;
+  return m;
+}
+
+void cs_destroy(cs_handle h) {
+  if (!h) return;
+  hipDeviceSynchronize();
+  for (auto& kv : h->w) if (kv.second.d) hipFree(kv.second.d);
+  for (void* p : h->owned) hipFree(p);
+  if (h->pos_tab && h->pos_tab_owned) hipFree(h->pos_tab);
+  if (h->pe_tab && h->pe_tab != h->pe) hipFree(h->pe_tab);
+  if (h->ws) hipFree(h->ws);
+  for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  delete h;
+}
+
+int cs_num_weights(cs_handle h) { return h ? (int)h->names.size() : 0; }
+const char* cs_weight_name(cs_handle h, int i) { return (h && i >= 0 && i < (int)h->names.size()) ? h->names[i].c_str() : nullptr; }
+
+int cs_set_weight(cs_handle h, const char* name, const float* data, int is_device, int ndim, const int64_t* shape) {
+  if (!h || !name || !data || ndim < 1 || !shape) return fail(CS_ERR_BAD_ARG, "cs_set_weight: null argument");
+  if (h->finalized) return fail(CS_ERR_STATE, "cs_set_weight after cs_finalize");
+  if (std::find(h->names.begin(), h->names.end(), name) == h->names.end()) return fail(CS_ERR_BAD_ARG, "unexpected key %s", name);
+  Tensor t;
+  t.numel = 1;
+  for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return fail(CS_ERR_BAD_ARG, "%s: bad shape", name); t.shape.push_back(shape[i]); t.numel *= (size_t)shape[i]; }
+  auto it = h->w.find(name);
+  if (it != h->w.end() && it->second.d) { hipFree(it->second.d); }
+  HIPCHK(hipMalloc(&t.d, t.numel * sizeof(float)));
+  HIPCHK(hipMemcpy(t.d, data, t.numel * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  h->w[name] = t;
+  return 0;
+}
+
+int cs_finalize(cs_handle h) {
+  if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
+  if (h->finalized) return 0;
+  const cs_config& c = h->cfg;
+  const int64_t C = c.hidden, P = c.patch, F = (int64_t)c.mlp_ratio * C;
+  auto need = [&](const std::string& n, std::vector<int64_t> shp) -> Tensor* {
+    auto it = h->w.find(n);
+    if (it == h->w.end()) { fail(CS_ERR_STATE, "missing key %s", n.c_str()); return nullptr; }
+    if (it->second.shape != shp) {
+      std::string got, want;
+      for (auto v : it->second.shape) got += std::to_string(v) + ",";
+      for (auto v : shp) want += std::to_string(v) + ",";
+      fail(CS_ERR_BAD_ARG, "size mismatch for %s: got (%s) expected (%s)", n.c_str(), got.c_str(), want.c_str());
+      return nullptr;
+    }
+    return &it->second;
+  };
+  hipStream_t st = nullptr;
+  auto pack = [&](const float* src, int rows, int K, int ldo, bf16_t* dst) -> int {
+    HIPCHK(cs_pack_bf16_launch(src, rows, K, dst, ldo, st));
+    return 0;
+  };
+  auto alloc_bf = [&](size_t n) -> bf16_t* { void* p = nullptr; if (hipMalloc(&p, n * sizeof(bf16_t)) != hipSuccess) return nullptr; h->owned.push_back(p); return (bf16_t*)p; };
+  auto alloc_f = [&](size_t n) -> float* { void* p = nullptr; if (hipMalloc(&p, n * sizeof(float)) != hipSuccess) return nullptr; h->owned.push_back(p); return (float*)p; };
+#define NEED(var, name, ...) Tensor* var = need(name, {__VA_ARGS__}); if (!var) return CS_ERR_STATE;
+#define ALLOC_BF(var, n) bf16_t* var = alloc_bf(n); if (!var) return fail(CS_ERR_HIP, "hipMalloc failed");
+#define ALLOC_F(var, n) float* var = alloc_f(n); if (!var) return fail(CS_ERR_HIP, "hipMalloc failed");
+#define D2D(dst, src, n) HIPCHK(hipMemcpy(dst, src, (n) * sizeof(float), hipMemcpyDeviceToDevice))
+
+  const std::string e = "backbone.embeddings.";
+  NEED(t_ms, "img_mean_std", 6) (void)t_ms;
+  NEED(t_cls, e + "cls_token", 1, 1, C)
+  NEED(t_mask, e + "mask_token", 1, C) (void)t_mask;
+  NEED(t_pos, e + "position_embeddings", 1, (int64_t)c.pos_grid * c.pos_grid + 1, C)
+  NEED(t_pw, e + "patch_embeddings.projection.weight", C, 3, P, P)
+  NEED(t_pb, e + "patch_embeddings.projection.bias", C)
+  h->cls = t_cls->d; h->pos = t_pos->d; h->bpatch = t_pb->d;
+  { ALLOC_BF(wp, (size_t)C * h->Kp) if (int r = pack(t_pw->d, (int)C, (int)(3 * P * P), h->Kp, wp)) return r; h->Wpatch = wp; }
+  h->enc.resize(c.enc_layers);
+  for (int l = 0; l < c.enc_layers; ++l) {
+    const std::string p = "backbone.encoder.layer." + std::to_string(l) + ".";
+    EncLayer& L = h->enc[l];
+    NEED(n1w, p + "norm1.weight", C) NEED(n1b, p + "norm1.bias", C) NEED(n2w, p + "norm2.weight", C) NEED(n2b, p + "norm2.bias", C)
+    NEED(qw, p + "attention.attention.query.weight", C, C) NEED(qb, p + "attention.attention.query.bias", C)
+    NEED(kw, p + "attention.attention.key.weight", C, C) NEED(kb, p + "attention.attention.key.bias", C)
+    NEED(vw, p + "attention.attention.value.weight", C, C) NEED(vb, p + "attention.attention.value.bias", C)
+    NEED(ow, p + "attention.output.dense.weight", C, C) NEED(ob, p + "attention.output.dense.bias", C)
+    NEED(l1, p + "layer_scale1.lambda1", C) NEED(l2, p + "layer_scale2.lambda1", C)
+    NEED(f1w, p + "mlp.fc1.weight", F, C) NEED(f1b, p + "mlp.fc1.bias", F)
+    NEED(f2w, p + "mlp.fc2.weight", C, F) NEED(f2b, p + "mlp.fc2.bias", C)
+    L.ln1g = n1w->d; L.ln1b = n1b->d; L.ln2g = n2w->d; L.ln2b = n2b->d; L.bo = ob->d; L.b1 = f1b->d; L.b2 = f2b->d; L.ls1 = l1->d; L.ls2 = l2->d;
+    ALLOC_BF(wqkv, (size_t)3 * C * C) ALLOC_F(bqkv, (size_t)3 * C)
+    if (int r = pack(qw->d, (int)C, (int)C, (int)C, wqkv)) return r;
+    if (int r = pack(kw->d, (int)C, (int)C, (int)C, wqkv + C * C)) return r;
+    if (int r = pack(vw->d, (int)C, (int)C, (int)C, wqkv + 2 * C * C)) return r;
+    D2D(bqkv, qb->d, C); D2D(bqkv + C, kb->d, C); D2D(bqkv + 2 * C, vb->d, C);
+    ALLOC_BF(wo, (size_t)C * C) ALLOC_BF(w1, (size_t)F * C) ALLOC_BF(w2, (size_t)C * F)
+    if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
+    if (int r = pack(f1w->d, (int)F, (int)C, (int)C, w1)) return r;
+    if (int r = pack(f2w->d, (int)C, (int)F, (int)F, w2)) return r;
+    L.Wqkv = wqkv; L.bqkv = bqkv; L.Wo = wo; L.W1 = w1; L.W2 = w2;
+  }
+  { NEED(g, "backbone.layernorm.weight", C) NEED(b, "backbone.layernorm.bias", C) h->lnfg = g->d; h->lnfb = b->d; }
+  { NEED(pe, "pos_enc_fn.PE", 1, c.pe_h, c.pe_w, C) h->pe = pe->d; }
+  h->dec.resize(c.dec_layers);
+  { ALLOC_BF(wkv, (size_t)c.dec_layers * 2 * C * C) ALLOC_F(bkv, (size_t)c.dec_layers * 2 * C) h->Wkv_all = wkv; h->bkv_all = bkv; }
+  for (int l = 0; l < c.dec_layers; ++l) {
+    const std::string p = "ref_cross.attn.layers." + std::to_string(l) + ".";
+    DecLayer& L = h->dec[l];
+    std::memset(&L, 0, sizeof L);
+    if (c.do_self_attn) {
+      NEED(iw, p + "self_attn.in_proj_weight", 3 * C, C) NEED(ib, p + "self_attn.in_proj_bias", 3 * C)
+      NEED(ow, p + "self_attn.out_proj.weight", C, C) NEED(ob, p + "self_attn.out_proj.bias", C)
+      ALLOC_BF(w, (size_t)3 * C * C) if (int r = pack(iw->d, (int)(3 * C), (int)C, (int)C, w)) return r;
+      ALLOC_BF(wo, (size_t)C * C) if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
+      L.sa_Win = w; L.sa_bin = ib->d; L.sa_Wo = wo; L.sa_bo = ob->d;
+    }
+    NEED(iw, p + "multihead_attn.in_proj_weight", 3 * C, C) NEED(ib, p + "multihead_attn.in_proj_bias", 3 * C)
+    NEED(ow, p + "multihead_attn.out_proj.weight", C, C) NEED(ob, p + "multihead_attn.out_proj.bias", C)
+    ALLOC_BF(wq, (size_t)C * C) if (int r = pack(iw->d, (int)C, (int)C, (int)C, wq)) return r;
+    // rows [C:3C) = [Wk;Wv] of this layer -> rows [l*2C, (l+1)*2C) of the fused KV projection (same memory for both layers)
+    if (int r = pack(iw->d + C * C, (int)(2 * C), (int)C, (int)C, h->Wkv_all + (size_t)l * 2 * C * C)) return r;
+    D2D(h->bkv_all + (size_t)l * 2 * C, ib->d + C, 2 * C);
+    ALLOC_BF(wo, (size_t)C * C) if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
+    L.ca_Wq = wq; L.ca_bq = ib->d; L.ca_Wo = wo; L.ca_bo = ob->d;
+    NEED(l1w, p + "linear1.weight", C, C) NEED(l1b, p + "linear1.bias", C) NEED(l2w, p + "linear2.weight", C, C) NEED(l2b, p + "linear2.bias", C)
+    ALLOC_BF(w1, (size_t)C * C) if (int r = pack(l1w->d, (int)C, (int)C, (int)C, w1)) return r;
+    ALLOC_BF(w2, (size_t)C * C) if (int r = pack(l2w->d, (int)C, (int)C, (int)C, w2)) return r;
+    L.l1W = w1; L.l1b = l1b->d; L.l2W = w2; L.l2b = l2b->d;
+    NEED(n1g, p + "norm1.weight", C) NEED(n1b, p + "norm1.bias", C) NEED(n2g, p + "norm2.weight", C) NEED(n2b, p + "norm2.bias", C)
+    NEED(n3g, p + "norm3.weight", C) NEED(n3b, p + "norm3.bias", C)
+    L.n1g = n1g->d; L.n1b = n1b->d; L.n2g = n2g->d; L.n2b = n2b->d; L.n3g = n3g->d; L.n3b = n3b->d;
+  }
+  {
+    const int64_t PP = P * P;
+    NEED(h0w, "ref_cross.head.0.weight", C, C) NEED(h0b, "ref_cross.head.0.bias", C)
+    NEED(h2w, "ref_cross.head.2.weight", PP, C) NEED(h2b, "ref_cross.head.2.bias", PP)
+    ALLOC_BF(w0, (size_t)C * C) if (int r = pack(h0w->d, (int)C, (int)C, (int)C, w0)) return r;
+    ALLOC_BF(w2, (size_t)PP * C) if (int r = pack(h2w->d, (int)PP, (int)C, (int)C, w2)) return r;
+    h->Wh0 = w0; h->bh0 = h0b->d; h->Wh2 = w2; h->bh2 = h2b->d;
+  }
+  HIPCHK(hipDeviceSynchronize());
+  // fp32 copies of the big matrices are no longer needed
+  for (auto& kv : h->w) {
+    const std::string& n = kv.first;
+    const bool big = kv.second.shape.size() >= 2 && n.find("weight") != std::string::npos && n.find("norm") == std::string::npos;
+    if (big && kv.second.d) { hipFree(kv.second.d); kv.second.d = nullptr; }
+  }
+  h->finalized = true;
+  return 0;
+}
+
+size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W) {
+  if (!h || B <= 0 || N <= 0 || H < h->cfg.patch || W < h->cfg.patch) return 0;
+  return make_plan(h, B, N, H, W, nullptr).total;
+}
+
+int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N, int H, int W, float* score_out, float* attn_out,
+               int head_id, float* mean_out, cs_stream stream) {
+  if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
+  if (!h->finalized) return fail(CS_ERR_STATE, "cs_forward before cs_finalize");
+  const cs_config& c = h->cfg;
+  if (!query || !refs || !score_out) return fail(CS_ERR_BAD_ARG, "null tensor (ref_cross_imgs is required when do_reference_cross)");
+  if (B <= 0 || N <= 0) return fail(CS_ERR_BAD_ARG, "empty batch or no reference views");
+  if (H < c.patch || W < c.patch) return fail(CS_ERR_BAD_ARG, "image smaller than one patch");
+  if (attn_out && (head_id < 0 || head_id >= c.dec_heads)) return fail(CS_ERR_BAD_ARG, "need_attn_weights_head_id %d out of range", head_id);
+  hipStream_t st = (hipStream_t)stream;
+  const int C = c.hidden, P = c.patch;
+  const size_t need = cs_workspace_bytes(h, B, N, H, W);
+  if (need > h->ws_bytes) {
+    HIPCHK(hipStreamSynchronize(st));
+    if (h->ws) hipFree(h->ws);
+    h->ws = nullptr; h->ws_bytes = 0;
+    HIPCHK(hipMalloc(&h->ws, need));
+    h->ws_bytes = need;
+  }
+  Plan p = make_plan(h, B, N, H, W, h->ws);
+  if ((long long)B * N * p.Np * 2 * C * c.dec_layers >= (1ll << 31)) return fail(CS_ERR_UNSUPPORTED, "batch too large for 32-bit offsets; split the batch");
+  if (int r = ensure_tables(h, p.gh, p.gw, H == W, st)) return r;
+  Launcher L{h, st};
+  const int enc_dh = C / c.enc_heads, dec_dh = C / c.dec_heads;
+  const int F = c.mlp_ratio * C;
+  const float LOG2E = 1.4426950408889634f;
+
+  // ================= encoder (Dinov2Model.forward, HF:451-477), Ic images per pass =================
+  for (int i0 = 0; i0 < p.I; i0 += p.Ic) {
+    const int ic = std::min(p.Ic, p.I - i0);
+    const int Mc = ic * p.T;
+    L.begin(2, 0); L.misc(cs_im2col_launch(query, refs, N, i0, p.r1, ic, H, W, P, h->Kp, st), "im2col"); L.end();
+    L.begin(2, 0); L.misc(cs_cls_rows_launch(p.x, ic, p.T, C, h->cls, h->pos_tab, st), "cls"); L.end();
+    {
+      CsGemmParams g = gp(p.r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, p.x, C);
+      g.pos = h->pos_tab; g.Np = p.Np;
+      L.gemm(g, CS_EPI_PATCH_F32, 3.0 * P * P);
+    }
+    for (int l = 0; l < c.enc_layers; ++l) {
+      const EncLayer& E = h->enc[l];
+      L.begin(2, 0); L.misc(cs_layernorm_launch(p.x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, p.u, st), "ln1"); L.end();
+      L.gemm(gp(p.u, C, E.Wqkv, C, Mc, 3 * C, C, E.bqkv, p.r1, 3 * C), CS_EPI_BIAS_BF16);
+      {
+        CsAttnParams a{};
+        a.Q = p.r1; a.K = p.r1 + C; a.V = p.r1 + 2 * C; a.O = p.u;
+        a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+        a.q_bs = a.k_bs = a.v_bs = (long long)p.T * 3 * C; a.o_bs = (long long)p.T * C;
+        a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = LOG2E / std::sqrt((float)enc_dh); a.lse = nullptr;
+        L.attn(a, enc_dh, ic);
+      }
+      {
+        CsGemmParams g = gp(p.u, C, E.Wo, C, Mc, C, C, E.bo, p.x, C);
+        g.scale = E.ls1; g.resid = p.x; g.ldr = C;
+        L.gemm(g, CS_EPI_RESID_F32);
+      }
+      L.begin(2, 0); L.misc(cs_layernorm_launch(p.x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, p.u, st), "ln2"); L.end();
+      L.gemm(gp(p.u, C, E.W1, C, Mc, F, C, E.b1, p.r1, F), CS_EPI_BIAS_GELU_BF16);
+      {
+        CsGemmParams g = gp(p.r1, F, E.W2, F, Mc, C, F, E.b2, p.x, C);
+        g.scale = E.ls2; g.resid = p.x; g.ldr = C;
+        L.gemm(g, CS_EPI_RESID_F32);
+      }
+    }
+    L.begin(2, 0);
+    L.misc(cs_final_ln_split_launch(p.x, ic, i0, p.Np, C, N, h->lnfg, h->lnfb, 1e-6f, h->pe_tab, p.xq, p.q_bf, p.mem_bf, st), "final_ln");
+    L.end();
+    if (L.rc) return L.rc;
+  }
+
+  // ================= decoder (transformer.py:213-268, post-norm layers :157-173) =================
+  const int M = B * p.Np, Mk = B * N * p.Np, KV = 2 * C * c.dec_layers;
+  L.gemm(gp(p.mem_bf, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, p.kv, KV), CS_EPI_BIAS_BF16);
+  for (int l = 0; l < c.dec_layers; ++l) {
+    const DecLayer& D = h->dec[l];
+    if (c.do_self_attn) {
+      L.gemm(gp(p.q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, p.dqkv, 3 * C), CS_EPI_BIAS_BF16);
+      CsAttnParams a{};
+      a.Q = p.dqkv; a.K = p.dqkv + C; a.V = p.dqkv + 2 * C; a.O = p.dob;
+      a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+      a.q_bs = a.k_bs = a.v_bs = (long long)p.Np * 3 * C; a.o_bs = (long long)p.Np * C;
+      a.Lq = a.Lk = p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
+      L.attn(a, dec_dh, B);
+      CsGemmParams g = gp(p.dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, p.y, C);
+      g.resid = c.do_short_cut ? p.xq : nullptr; g.ldr = C;
+      L.gemm(g, CS_EPI_RESID_F32);
+      L.begin(2, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n1g, D.n1b, 1e-5f, p.xq, p.q_bf, st), "norm1"); L.end();
+    }
+    L.gemm(gp(p.q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, p.dq, C), CS_EPI_BIAS_BF16);
+    CsAttnParams a{};
+    a.Q = p.dq; a.K = p.kv + (size_t)l * 2 * C; a.V = p.kv + (size_t)l * 2 * C + C; a.O = p.dob;
+    a.ldq = C; a.ldk = a.ldv = KV; a.ldo = C;
+    a.q_bs = (long long)p.Np * C; a.k_bs = a.v_bs = (long long)N * p.Np * KV; a.o_bs = (long long)p.Np * C;
+    a.Lq = p.Np; a.Lk = N * p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
+    const bool want_w = attn_out && l == c.dec_layers - 1;  // only the last layer's weights are returned (transformer.py:266-268)
+    a.lse = want_w ? p.lse : nullptr;
+    L.attn(a, dec_dh, B);
+    if (want_w && !L.rc) {
+      L.begin(2, 0); L.misc(cs_attn_weights_launch(&a, dec_dh, B, head_id, attn_out, st), "attn_weights"); L.end();
+    }
+    {
+      CsGemmParams g = gp(p.dob, C, D.ca_Wo, C, M, C, C, D.ca_bo, p.y, C);
+      g.resid = c.do_short_cut ? p.xq : nullptr; g.ldr = C;
+      L.gemm(g, CS_EPI_RESID_F32);
+    }
+    L.begin(2, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n2g, D.n2b, 1e-5f, p.xq, p.q_bf, st), "norm2"); L.end();
+    L.gemm(gp(p.q_bf, C, D.l1W, C, M, C, C, D.l1b, p.dhid, C), CS_EPI_BIAS_RELU_BF16);
+    {
+      CsGemmParams g = gp(p.dhid, C, D.l2W, C, M, C, C, D.l2b, p.y, C);
+      g.resid = p.xq; g.ldr = C;
+      L.gemm(g, CS_EPI_RESID_F32);
+    }
+    L.begin(2, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n3g, D.n3b, 1e-5f, p.xq, p.q_bf, st), "norm3"); L.end();
+  }
+  // ================= head + RegressionLayer + jigsaw (cross_reference.py:45-50,82-87) =================
+  L.gemm(gp(p.q_bf, C, h->Wh0, C, M, C, C, h->bh0, p.dhid, C), CS_EPI_BIAS_LEAKY_BF16);
+  {
+    CsGemmParams g = gp(p.dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out, 4);
+    g.Np = p.Np; g.gw = p.gw; g.P = P; g.act = c.act; g.powp = c.pow_p;
+    L.gemm(g, CS_EPI_HEAD_SCORE);
+  }
+  if (mean_out && !L.rc) {
+    L.begin(2, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();
+  }
+  return L.rc;
+}
+
+int cs_profile_enable(cs_handle h, int on) {
+  if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
+  hipDeviceSynchronize();
+  for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  h->recs.clear();
+  h->prof = on != 0;
+  return 0;
+}
+
+int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, double* flops) {
+  if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
+  HIPCHK(hipDeviceSynchronize());
+  double ms = 0, fl = 0; int n = 0;
+  for (auto& r : h->recs) {
+    if (r.family != family) continue;
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t; fl += r.flops; ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (flops) *flops = fl;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// single-op entry points
+// ---------------------------------------------------------------------------------------------------------
+int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias, const float* scale,
+               const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np, int gw, int P, int act,
+               float powp, cs_stream stream) {
+  CsGemmParams g = gp(A, lda, W, ldw, M, N, K, bias, out, ldc);
+  g.scale = scale; g.resid = resid; g.ldr = ldr; g.pos = pos; g.Np = Np; g.gw = gw; g.P = P; g.act = act; g.powp = powp;
+  if (epi < 0 || epi > CS_EPI_HEAD_SCORE) return fail(CS_ERR_BAD_ARG, "gemm: unknown epilogue %d", epi);
+  if (const char* e = cs_gemm_check(&g, epi)) return fail(CS_ERR_BAD_ARG, "%s", e);
+  HIPCHK(cs_gemm_launch(&g, epi, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* V, uint16_t* O, int ldq, int ldk, int ldv, int ldo,
+                    long long q_bs, long long k_bs, long long v_bs, long long o_bs, int batch, int heads, int Lq, int Lk, int dh,
+                    float* lse, cs_stream stream) {
+  CsAttnParams a{};
+  a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs; a.Lq = Lq; a.Lk = Lk; a.heads = heads;
+  a.scale_log2e = 1.4426950408889634f / std::sqrt((float)dh); a.lse = lse;
+  if (const char* e = cs_attn_check(&a, dh, batch)) return fail(CS_ERR_BAD_ARG, "%s", e);
+  HIPCHK(cs_attn_launch(&a, dh, batch, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int ldk, long long q_bs, long long k_bs, int batch,
+                            int heads, int Lq, int Lk, int dh, const float* lse, int head, float* out, cs_stream stream) {
+  if (!Q || !K || !lse || !out || !supported_dh(dh) || head < 0 || head >= heads || Lq <= 0 || Lk <= 0 || Lq > 65535 || batch <= 0 || batch > 65535)
+    return fail(CS_ERR_BAD_ARG, "attention_weights: bad arguments");
+  CsAttnParams a{};
+  a.Q = Q; a.K = K; a.ldq = ldq; a.ldk = ldk; a.q_bs = q_bs; a.k_bs = k_bs; a.Lq = Lq; a.Lk = Lk; a.heads = heads;
+  a.scale_log2e = 1.4426950408889634f / std::sqrt((float)dh); a.lse = const_cast<float*>(lse);
+  HIPCHK(cs_attn_weights_launch(&a, dh, batch, head, out, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
+                    uint16_t* out_bf16, cs_stream stream) {
+  if (!x || !gamma || !beta || M <= 0 || C <= 0 || C % 4 || C > 1024) return fail(CS_ERR_BAD_ARG, "layernorm: C must be a multiple of 4 and <= 1024");
+  HIPCHK(cs_layernorm_launch(x, M, C, gamma, beta, eps, out_f32, out_bf16, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream) {
+  if (!x || !out || I <= 0 || P <= 0 || H < P || W < P || Kp % 8 || Kp < 3 * P * P) return fail(CS_ERR_BAD_ARG, "im2col: bad arguments");
+  HIPCHK(cs_im2col_launch(x, nullptr, 0, 0, out, I, H, W, P, Kp, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream) {
+  if (!pos || !out || G <= 0 || C <= 0 || gh <= 0 || gw <= 0) return fail(CS_ERR_BAD_ARG, "pos_bicubic: bad arguments");
+  HIPCHK(cs_pos_bicubic_launch(pos, G, C, gh, gw, out, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream) {
+  if (!pe || !out || ph <= 0 || pw <= 0 || C <= 0 || gh <= 0 || gw <= 0) return fail(CS_ERR_BAD_ARG, "pe_bilinear: bad arguments");
+  HIPCHK(cs_pe_bilinear_launch(pe, ph, pw, C, gh, gw, out, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, cs_stream stream) {
+  if (!w || !out || rows <= 0 || K <= 0 || ldo < K) return fail(CS_ERR_BAD_ARG, "pack_bf16: bad arguments");
+  HIPCHK(cs_pack_bf16_launch(w, rows, K, out, ldo, (hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

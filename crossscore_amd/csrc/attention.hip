@@ -1,0 +1,240 @@
+// Flash-style fused attention for gfx950: O = softmax(Q K^T / sqrt(dh)) V, no mask, bf16 in/out, fp32 softmax.
+//
+// One kernel serves the three attention sites of the CrossScore forward:
+//   * DINOv2 encoder self-attention, dh = 64, per image over T = 1 + h*w tokens   (HF modeling_dinov2.py:153-234)
+//   * decoder self-attention, 8 heads, dh = C/8 in {48, 96}                        (transformer.py:182-192)
+//   * query <-> multi-reference cross-attention, Lk = N*h*w keys                   (transformer.py:195-205)
+// Q/K/V are addressed through (row stride, batch stride, head*dh column offset) so the packed projections the
+// GEMMs emit ([tokens][3C], [tokens][4C]) are consumed in place -- no head-split copies.
+//
+// Structure (wave64, MFMA 32x32x16 bf16): a workgroup = 4 waves = 128 query rows, each wave 32 rows; keys are
+// streamed in 64-key tiles, K and V staged HBM -> VGPR -> LDS (issue early / write late), double buffered, one
+// barrier per tile.  QK^T is computed "swapped" (S^T = K Q^T) so each lane owns one query column: row max and
+// row sum are lane-local plus one cross-half exchange, and the S^T accumulator IS the B operand of the PV MFMA
+// (O^T = V^T P^T) after an in-register bf16 pack -- P never touches LDS.  V^T fragments come from a row-major V
+// image through ds_read_b64_tr_b16 (hardware transposed read); LDS row strides are chosen bank-conflict free
+// (K: odd number of 16-B slots; V: 192 B so the four rows of a transposed block hit disjoint bank windows).
+#include "cs_common.h"
+#include <math.h>
+
+namespace {
+
+template <int DH>
+struct AttnCfg {
+  static constexpr int KS = DH / 16;                 // QK^T k-steps (MFMA K = 16)
+  static constexpr int DT = (DH + 31) / 32;          // 32-wide d tiles of O^T
+  static constexpr int CH = DH / 8;                  // 16-byte chunks per K/V row
+  static constexpr int KROW = DH * 2 + 16;           // bytes; odd multiple of 16 -> ds_read_b128 conflict free
+  static constexpr int VROW = (DH <= 16) ? 64 : 192; // bytes; >= DT*64 and == 16 or 48 dwords (mod 64)
+  static constexpr int KTILE = 64 * KROW;
+  static constexpr int VTILE = 64 * VROW;
+  static constexpr int STAGE = KTILE + VTILE;
+  static constexpr int NIT = (64 * CH + 255) / 256;  // 16-byte chunks per thread per tile (K and V each)
+};
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
+  using Cfg = AttnCfg<DH>;
+  constexpr int KS = Cfg::KS, DT = Cfg::DT, CH = Cfg::CH, NIT = Cfg::NIT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;   // MFMA row/col index inside a 32-tile
+  const int hh = lane >> 5;  // lane half
+  const int head = blockIdx.y;
+  const int bat = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wv * 32;
+
+  const bf16_t* Qb = p.Q + (size_t)bat * p.q_bs + head * DH;
+  const bf16_t* Kb = p.K + (size_t)bat * p.k_bs + head * DH;
+  const bf16_t* Vb = p.V + (size_t)bat * p.v_bs + head * DH;
+
+  // ---- Q^T fragments (B operand of S^T = K Q^T): lane (r,hh) holds Q[q0+r][16s + 8hh .. +7] ----
+  bf16x8_t qf[KS];
+  {
+    int qr = q0 + r;
+    qr = qr < p.Lq ? qr : p.Lq - 1;
+    const bf16_t* qp = Qb + (size_t)qr * p.ldq + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
+  }
+
+  // ---- staging maps: chunk c = tid + it*256 -> (key = c / CH, ch = c % CH); the last pass may be partial
+  //      (whole waves idle: the guard is wave-uniform) ----
+  constexpr bool kFullLast = (64 * CH) % 256 == 0;
+  int skey[NIT], sch[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = tid + it * 256;
+    skey[it] = c / CH;
+    sch[it] = c - skey[it] * CH;
+  }
+  uint4 kreg[NIT], vreg[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) { kreg[it] = make_uint4(0, 0, 0, 0); vreg[it] = make_uint4(0, 0, 0, 0); }
+#define CS_ATTN_LOAD_TILE(T)                                                                       \
+  _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                             \
+    if (kFullLast || it + 1 < NIT || tid + it * 256 < 64 * CH) {                                   \
+      int key_ = (T) * 64 + skey[it];                                                              \
+      key_ = key_ < p.Lk ? key_ : p.Lk - 1;                                                        \
+      kreg[it] = *reinterpret_cast<const uint4*>(Kb + (size_t)key_ * p.ldk + sch[it] * 8);         \
+      vreg[it] = *reinterpret_cast<const uint4*>(Vb + (size_t)key_ * p.ldv + sch[it] * 8);         \
+    }                                                                                              \
+  }
+#define CS_ATTN_WRITE_TILE(BUF)                                                                    \
+  _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                             \
+    if (kFullLast || it + 1 < NIT || tid + it * 256 < 64 * CH) {                                   \
+      char* kb_ = smem + (BUF) * Cfg::STAGE;                                                       \
+      *reinterpret_cast<uint4*>(kb_ + skey[it] * Cfg::KROW + sch[it] * 16) = kreg[it];             \
+      *reinterpret_cast<uint4*>(kb_ + Cfg::KTILE + skey[it] * Cfg::VROW + sch[it] * 16) = vreg[it]; \
+    }                                                                                              \
+  }
+
+  f32x16_t ot[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ot[d][e] = 0.f;
+  float m_run = -INFINITY;  // running max of s*scale*log2e
+  float l_run = 0.f;        // running sum over this lane's keys (other half lives in lane^32)
+  const float sc = p.scale_log2e;
+
+  // per-lane LDS byte offsets
+  const int koff = r * Cfg::KROW + hh * 16;                                  // + kt2*32*KROW + s*32
+  const int li = lane & 15, lg = (lane >> 4) & 1;
+  const int voff = (4 * hh + (li >> 2)) * Cfg::VROW + (16 * lg + 4 * (li & 3)) * 2;  // + (kt2*32+16*s2 [+8])*VROW + dt*64
+
+  const int nt = (p.Lk + 63) / 64;
+  CS_ATTN_LOAD_TILE(0)
+  CS_ATTN_WRITE_TILE(0)
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) { CS_ATTN_LOAD_TILE(t + 1) }
+    const char* kb = smem + (t & 1) * Cfg::STAGE;
+    const char* vb = kb + Cfg::KTILE;
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles ----
+    f32x16_t st[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[k2][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + koff + k2 * 32 * Cfg::KROW + s * 32);
+        st[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[k2], 0, 0, 0);
+      }
+    }
+    // ---- mask the ragged tail (keys >= Lk) : wave-uniform branch ----
+    if (t == nt - 1 && (p.Lk & 63)) {
+      const int kbase = t * 64 + 4 * hh;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kbase + k2 * 32 + (e & 3) + 8 * (e >> 2);
+          if (key >= p.Lk) st[k2][e] = -INFINITY;
+        }
+    }
+    // ---- online softmax (base-2 domain) ----
+    float tmax = st[0][0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax * sc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j] * sc - m_new);
+          psum += pv;
+          pf[k2][s2][j] = (__bf16)pv;
+        }
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ot[d][e] *= alpha;
+
+    // ---- O^T += V^T P^T : V^T fragments via transposed LDS reads ----
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const char* vrow = vb + voff + (k2 * 32 + 16 * s2) * Cfg::VROW;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) short4_t*)(vrow + d * 64));
+          short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) short4_t*)(vrow + 8 * Cfg::VROW + d * 64));
+          short8_t vf8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf8), pf[k2][s2], ot[d], 0, 0, 0);
+        }
+      }
+
+    if (t + 1 < nt) { CS_ATTN_WRITE_TILE((t + 1) & 1) }
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][head*DH + d] = O^T[d][q] / l ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + r;
+  if (q < p.Lq) {
+    bf16_t* op = p.O + (size_t)bat * p.o_bs + (size_t)q * p.ldo + head * DH;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int dd = d * 32 + 8 * g4 + 4 * hh;
+        if (dd < DH) {
+          uint2 o;
+          o.x = pack_bf16x2(ot[d][4 * g4 + 0] * inv, ot[d][4 * g4 + 1] * inv);
+          o.y = pack_bf16x2(ot[d][4 * g4 + 2] * inv, ot[d][4 * g4 + 3] * inv);
+          *reinterpret_cast<uint2*>(op + dd) = o;
+        }
+      }
+    if (p.lse && hh == 0) p.lse[((size_t)bat * p.heads + head) * p.Lq + q] = m_run + log2f(l_tot);
+  }
+}
+
+template <int DH>
+hipError_t launch(const CsAttnParams& p, int batch, hipStream_t stream) {
+  dim3 grid((p.Lq + 127) / 128, p.heads, batch);
+  const int lds = 2 * AttnCfg<DH>::STAGE + 64;  // +64: the last rows' transposed reads of a padded d tile may run past the image
+  hipLaunchKernelGGL(cs_attn_kernel<DH>, grid, dim3(256), lds, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" const char* cs_attn_check(const CsAttnParams* p, int dh, int batch) {
+  if (dh != 16 && dh != 48 && dh != 64 && dh != 96) return "attention: head dim must be 16, 48, 64 or 96";
+  if (p->Lq <= 0 || p->Lk <= 0 || p->heads <= 0 || batch <= 0) return "attention: empty shape";
+  if (batch > 65535 || p->heads > 65535) return "attention: grid too large";
+  if (p->ldq % 8 || p->ldk % 8 || p->ldv % 8 || p->ldo % 4) return "attention: row strides must keep 16-byte rows";
+  if (p->q_bs % 8 || p->k_bs % 8 || p->v_bs % 8 || p->o_bs % 4) return "attention: batch strides must keep 16-byte rows";
+  if (!p->Q || !p->K || !p->V || !p->O) return "attention: null operand";
+  return nullptr;
+}
+
+extern "C" hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, hipStream_t stream) {
+  switch (dh) {
+    case 16: return launch<16>(*p, batch, stream);
+    case 48: return launch<48>(*p, batch, stream);
+    case 64: return launch<64>(*p, batch, stream);
+    case 96: return launch<96>(*p, batch, stream);
+  }
+  return hipErrorInvalidValue;
+}

@@ -1,0 +1,351 @@
+// Memory-bound stages of the CrossScore forward (gfx950): im2col for the patchify GEMM, LayerNorm, the fused
+// "final LayerNorm + drop CLS + split query/refs + add multi-view PE" stage, CLS row init, the two frozen
+// position-table resizes (done once per (h,w)), the optional attention-weight materialisation and per-image
+// score means.  All are HBM-bound: 16-byte accesses, one wave per token row, no LDS round trips.
+#include "cs_common.h"
+#include <math.h>
+
+namespace {
+
+// -------------------------------------------------------------------------------------------------------
+// im2col: x fp32 (I,3,H,W) -> A bf16 [I*Np][Kp], k = ch*P*P + dy*P + dx (conv weight.reshape(C,588) order,
+// HF modeling_dinov2.py:139-149); columns 588..Kp-1 are zero so the GEMM K is a multiple of 64.
+// One thread per 8-element output chunk.
+// -------------------------------------------------------------------------------------------------------
+// Image g = img0 + img of the (B*(1+N)) image batch is the query of item b = g/(1+N) when g%(1+N) == 0, else
+// reference view g%(1+N)-1 of item b: the torch.cat of core.py:134-138 is folded into the addressing.
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ xq, const float* __restrict__ xr, int N, int img0,
+                                                      bf16_t* __restrict__ out, int I, int H, int W, int gh, int gw, int P, int Kp) {
+  const int chunks = Kp / 8;
+  const long long total = (long long)I * gh * gw * chunks;
+  const int KK = 3 * P * P;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(g % chunks);
+    const long long m = g / chunks;
+    const int pj = (int)(m % gw);
+    const int pi = (int)((m / gw) % gh);
+    const int img = (int)(m / ((long long)gw * gh));
+    const int g_img = img0 + img;
+    const int bb = g_img / (1 + N), vv = g_img - bb * (1 + N);
+    const float* x = vv == 0 ? xq + (size_t)bb * 3 * H * W : xr + ((size_t)bb * N + (vv - 1)) * 3 * H * W;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = c * 8 + e;
+      float val = 0.f;
+      if (k < KK) {
+        const int ch = k / (P * P);
+        const int rem = k - ch * P * P;
+        const int dy = rem / P, dx = rem - dy * P;
+        val = x[((size_t)ch * H + (pi * P + dy)) * W + pj * P + dx];
+      }
+      v[e] = val;
+    }
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(out + (size_t)m * Kp + c * 8) = o;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// LayerNorm over C (biased variance, two-pass in registers): one wave per row, float4 per lane.
+// -------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
+
+struct LnRow {
+  float4 v[LN_MAXV];
+};
+
+__device__ __forceinline__ void ln_load(const float* row, int C4, int lane, LnRow& r) {
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    r.v[i] = c < C4 ? reinterpret_cast<const float4*>(row)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void ln_normalise(LnRow& r, int C, int C4, int lane, const float* g, const float* b, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    if (lane + i * 64 < C4) {
+      const float a = r.v[i].x - mu, bb = r.v[i].y - mu, c = r.v[i].z - mu, d = r.v[i].w - mu;
+      q += (a * a + bb * bb) + (c * c + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < C4) {
+      const float4 g4 = reinterpret_cast<const float4*>(g)[c];
+      const float4 b4 = reinterpret_cast<const float4*>(b)[c];
+      r.v[i].x = (r.v[i].x - mu) * rstd * g4.x + b4.x;
+      r.v[i].y = (r.v[i].y - mu) * rstd * g4.y + b4.y;
+      r.v[i].z = (r.v[i].z - mu) * rstd * g4.z + b4.z;
+      r.v[i].w = (r.v[i].w - mu) * rstd * g4.w + b4.w;
+    }
+  }
+}
+__device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float* of32, bf16_t* obf) {
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < C4) {
+      if (of32) reinterpret_cast<float4*>(of32)[c] = r.v[i];
+      if (obf) {
+        uint2 o;
+        o.x = pack_bf16x2(r.v[i].x, r.v[i].y);
+        o.y = pack_bf16x2(r.v[i].z, r.v[i].w);
+        reinterpret_cast<uint2*>(obf)[c] = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int M, int C, const float* __restrict__ g,
+                                                         const float* __restrict__ b, float eps, float* of32, bf16_t* obf) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int C4 = C / 4;
+  LnRow r;
+  ln_load(x + (size_t)row * C, C4, lane, r);
+  ln_normalise(r, C, C4, lane, g, b, eps);
+  ln_store(r, C4, lane, of32 ? of32 + (size_t)row * C : nullptr, obf ? obf + (size_t)row * C : nullptr);
+}
+
+// -------------------------------------------------------------------------------------------------------
+// Final encoder LayerNorm (HF:465-470) fused with CLS drop + query/ref split (core.py:142-153) + multi-view PE
+// add (positional_encoding.py:42-75).  x: [I*T][C] fp32, image = b*(1+N)+v.  Row (b,v,p):
+//   v == 0 : q_f32[b*Np+p], q_bf16[b*Np+p]      (decoder residual stream + GEMM operand)
+//   v >= 1 : mem_bf16[b*N*Np + (v-1)*Np + p]    (cross-attention memory, GEMM operand only)
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __restrict__ x, int I, int img0, int Np, int C, int N,
+                                                              const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                              const float* __restrict__ pe, float* q_f32, bf16_t* q_bf,
+                                                              bf16_t* mem_bf) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)I * Np) return;
+  const int img = (int)(row / Np);
+  const int pp = (int)(row - (long long)img * Np);
+  const int bb = (img0 + img) / (1 + N), v = (img0 + img) - bb * (1 + N);
+  const int C4 = C / 4;
+  LnRow r;
+  ln_load(x + ((size_t)img * (Np + 1) + 1 + pp) * C, C4, lane, r);
+  ln_normalise(r, C, C4, lane, g, b, eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < C4) {
+      const float4 e = reinterpret_cast<const float4*>(pe + (size_t)pp * C)[c];
+      r.v[i].x += e.x; r.v[i].y += e.y; r.v[i].z += e.z; r.v[i].w += e.w;
+    }
+  }
+  if (v == 0) {
+    const size_t o = ((size_t)bb * Np + pp) * C;
+    ln_store(r, C4, lane, q_f32 + o, q_bf + o);
+  } else {
+    const size_t o = (((size_t)bb * N + (v - 1)) * Np + pp) * C;
+    ln_store(r, C4, lane, nullptr, mem_bf + o);
+  }
+}
+
+// CLS rows of the residual stream: x[img*T][c] = cls[c] + pos[0][c]  (HF:108-112)
+__global__ void cls_rows_kernel(float* x, int I, int T, int C, const float* cls, const float* pos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I * C) return;
+  const int img = i / C, c = i - img * C;
+  x[(size_t)img * T * C + c] = cls[c] + pos[c];
+}
+
+// -------------------------------------------------------------------------------------------------------
+// Frozen position tables, computed once per (h,w).
+// Encoder: bicubic (A=-0.75), align_corners=False, src=(dst+0.5)*in/out-0.5 un-clamped, border-clamped taps
+// (HF:57-95 -> aten upsample_bicubic2d).  pos: [(1+G*G)][C] -> out [(1+gh*gw)][C], row 0 copied.
+// -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ void pos_bicubic_kernel(const float* __restrict__ pos, int G, int C, int gh, int gw, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)(1 + gh * gw) * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int t = (int)(i / C);
+  if (t == 0) { out[i] = pos[c]; return; }
+  const int oy = (t - 1) / gw, ox = (t - 1) - oy * gw;
+  const float A = -0.75f;
+  const float sy = (oy + 0.5f) * ((float)G / (float)gh) - 0.5f;
+  const float sx = (ox + 0.5f) * ((float)G / (float)gw) - 0.5f;
+  const float fy = floorf(sy), fx = floorf(sx);
+  const float ty = sy - fy, tx = sx - fx;
+  const int iy = (int)fy, ix = (int)fx;
+  const float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+  const float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int yy = min(max(iy - 1 + a, 0), G - 1);
+    float rowacc = 0.f;
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) {
+      const int xx = min(max(ix - 1 + bq, 0), G - 1);
+      rowacc += pos[(size_t)(1 + yy * G + xx) * C + c] * wx[bq];
+    }
+    acc += rowacc * wy[a];
+  }
+  out[i] = acc;
+}
+
+// Multi-view PE: bilinear, align_corners=True: src = dst*(in-1)/(out-1) (positional_encoding.py:61-69).
+// PE: [pe_h][pe_w][C] -> out [gh*gw][C]
+__global__ void pe_bilinear_kernel(const float* __restrict__ pe, int ph, int pw, int C, int gh, int gw, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)gh * gw * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int t = (int)(i / C);
+  const int oy = t / gw, ox = t - oy * gw;
+  const float scy = gh > 1 ? (float)(ph - 1) / (float)(gh - 1) : 0.f;
+  const float scx = gw > 1 ? (float)(pw - 1) / (float)(gw - 1) : 0.f;
+  const float sy = oy * scy, sx = ox * scx;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = min(y0 + 1, ph - 1), x1 = min(x0 + 1, pw - 1);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const float v00 = pe[((size_t)y0 * pw + x0) * C + c], v01 = pe[((size_t)y0 * pw + x1) * C + c];
+  const float v10 = pe[((size_t)y1 * pw + x0) * C + c], v11 = pe[((size_t)y1 * pw + x1) * C + c];
+  const float top = v00 * (1.f - lx) + v01 * lx;
+  const float bot = v10 * (1.f - lx) + v11 * lx;
+  out[i] = top * (1.f - ly) + bot * ly;
+}
+
+// fp32 -> bf16 weight packing (K-contiguous rows; optional zero padding of K to ldo)
+__global__ void pack_bf16_kernel(const float* __restrict__ w, int rows, int K, bf16_t* __restrict__ out, int ldo) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * ldo) return;
+  const int k = (int)(i % ldo);
+  const long long rr = i / ldo;
+  out[i] = k < K ? f2bf(w[rr * K + k]) : (bf16_t)0;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// Optional attention-weight map (cross_reference.py:91-93 / torch functional.py:6576-6612): probabilities of
+// ONE head of the last decoder layer's cross-attention, P[b][q][k] = exp2(s*scale*log2e - lse2[b][head][q]).
+// lse2 comes from the fused attention kernel, so this pass only recomputes q.k for one head (fp32 dot on the
+// bf16 operands the fused kernel used) and streams the fp32 matrix out: HBM-write bound (B*Lq*Lk*4 bytes).
+// One wave per (q, 64 keys): lane = key; q row broadcast from registers.
+// -------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_weights_kernel(CsAttnParams p, int head, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int bat = blockIdx.z;
+  const int q = blockIdx.y;
+  const int kbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (kbase >= p.Lk) return;
+  const int key = kbase + lane;
+  const bf16_t* qp = p.Q + (size_t)bat * p.q_bs + (size_t)q * p.ldq + head * DH;
+  const float lse = p.lse[((size_t)bat * p.heads + head) * p.Lq + q];
+  if (key < p.Lk) {
+    const bf16_t* kp = p.K + (size_t)bat * p.k_bs + (size_t)key * p.ldk + head * DH;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH / 8; ++c) {
+      const uint4 kv = *reinterpret_cast<const uint4*>(kp + c * 8);
+      const uint4 qv = *reinterpret_cast<const uint4*>(qp + c * 8);
+      const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s += __uint_as_float(kw[e] << 16) * __uint_as_float(qw[e] << 16);
+        s += __uint_as_float(kw[e] & 0xffff0000u) * __uint_as_float(qw[e] & 0xffff0000u);
+      }
+    }
+    out[((size_t)bat * p.Lq + q) * p.Lk + key] = __builtin_amdgcn_exp2f(s * p.scale_log2e - lse);
+  }
+}
+
+// per-image mean of the score map (feeds the CSV writer, score_summariser.py:180-192): one block per image
+__global__ __launch_bounds__(256) void score_mean_kernel(const float* __restrict__ score, int n, float* __restrict__ out) {
+  __shared__ float part[4];
+  const float* s = score + (size_t)blockIdx.x * n;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += s[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1] + part[2] + part[3]) / (float)n;
+}
+
+}  // namespace
+
+extern "C" {
+
+hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, bf16_t* out, int I, int H, int W, int P, int Kp,
+                            hipStream_t st) {
+  const int gh = H / P, gw = W / P;
+  const long long total = (long long)I * gh * gw * (Kp / 8);
+  const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, st, xq, xr, N, img0, out, I, H, W, gh, gw, P, Kp);
+  return hipGetLastError();
+}
+
+hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32,
+                               bf16_t* obf, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, g, b, eps, of32, obf);
+  return hipGetLastError();
+}
+
+hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
+                                    const float* pe, float* q_f32, bf16_t* q_bf, bf16_t* mem_bf, hipStream_t st) {
+  const long long rows = (long long)I * Np;
+  hipLaunchKernelGGL(final_ln_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, I, img0, Np, C, N, g, b, eps, pe,
+                     q_f32, q_bf, mem_bf);
+  return hipGetLastError();
+}
+
+hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, hipStream_t st) {
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((I * C + 255) / 256), dim3(256), 0, st, x, I, T, C, cls, pos);
+  return hipGetLastError();
+}
+
+hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float* out, hipStream_t st) {
+  const long long total = (long long)(1 + gh * gw) * C;
+  hipLaunchKernelGGL(pos_bicubic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pos, G, C, gh, gw, out);
+  return hipGetLastError();
+}
+
+hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st) {
+  const long long total = (long long)gh * gw * C;
+  hipLaunchKernelGGL(pe_bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pe, ph, pw, C, gh, gw, out);
+  return hipGetLastError();
+}
+
+hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, hipStream_t st) {
+  const long long total = (long long)rows * ldo;
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, rows, K, out, ldo);
+  return hipGetLastError();
+}
+
+hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st) {
+  dim3 grid((p->Lk + 255) / 256, p->Lq, batch);
+  switch (dh) {
+    case 16: hipLaunchKernelGGL(attn_weights_kernel<16>, grid, dim3(256), 0, st, *p, head, out); break;
+    case 48: hipLaunchKernelGGL(attn_weights_kernel<48>, grid, dim3(256), 0, st, *p, head, out); break;
+    case 64: hipLaunchKernelGGL(attn_weights_kernel<64>, grid, dim3(256), 0, st, *p, head, out); break;
+    case 96: hipLaunchKernelGGL(attn_weights_kernel<96>, grid, dim3(256), 0, st, *p, head, out); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(score_mean_kernel, dim3(B), dim3(256), 0, st, score, n, out);
+  return hipGetLastError();
+}
+
+}  // extern "C"

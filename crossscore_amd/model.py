@@ -1,0 +1,211 @@
+"""Drop-in `CrossScoreNet` whose forward runs on the hand-written gfx950 kernels of libcrossscore_hip.so.
+
+Mirrors the reference model boundary (task/core.py:26-161):
+  * `CrossScoreNet(cfg)` reads the same config keys (config/model/model.yaml),
+  * `state_dict()` has exactly the reference's keys and shapes, so a Lightning checkpoint's
+    `ckpt["state_dict"]` (keys prefixed "model.") loads with `strict=True`,
+  * `forward(query_img, ref_cross_imgs, need_attn_weights, need_attn_weights_head_id, norm_img)` returns
+    `{"score_map_ref_cross": (B,14h,14w) fp32, "attn_weights_map_ref_cross": None | (B,h,w,N,h,w) fp32}`.
+PyTorch is used here only for device buffers, the current stream and (de)serialisation: every arithmetic
+stage of the forward is a HIP kernel launched through the C ABI.  There is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+from .synth import ArchSpec, BACKBONES
+
+
+# ----- config helpers restating utils/check_config.py:1-28 and model/regression_layer.py:31-62 ---------------
+def check_metric_prediction_config(metric_type, metric_min, metric_max) -> None:
+    if metric_type not in ("ssim", "mse", "mae"):
+        raise ValueError(f"Invalid metric type {metric_type}")
+    valid_max = metric_max == 1
+    valid_min = (metric_min in (-1, 0)) if metric_type == "ssim" else (metric_min == 0)
+    if not (valid_min and valid_max):
+        raise ValueError(f"Invalid metric range {metric_min} to {metric_max} for {metric_type}")
+
+
+def regression_activation(metric_type, metric_min, metric_max, power_factor):
+    """-> (act, p): act 0 = sigmoid, 1 = tanh; p = exponent applied after the activation."""
+    check_metric_prediction_config(metric_type, metric_min, metric_max)
+    if metric_min == -1:
+        act = 1
+    elif metric_min == 0:
+        act = 0
+    else:
+        raise ValueError(f"metric_min={metric_min} not supported")
+    if metric_min == 0:
+        p = {"ssim": 1, "mae": 2, "mse": 4}[metric_type] if power_factor == "default" else power_factor
+    else:
+        p = 1
+    return act, float(p)
+
+
+def arch_from_cfg(cfg) -> ArchSpec:
+    """Architecture constants from cfg.model (the reference gets hidden size / layers / heads from
+    Dinov2Config.from_pretrained(cfg.model.backbone.from_pretrained), task/core.py:39; the hub is unreachable
+    offline, so the two published backbones are tabulated; cfg.model.backbone may also carry explicit
+    hidden_size / num_hidden_layers / num_attention_heads / image_size)."""
+    m = cfg.model
+    bb = m.backbone
+    name = bb.from_pretrained
+    if name in BACKBONES:
+        a = BACKBONES[name]
+    elif all(k in bb for k in ("hidden_size", "num_hidden_layers", "num_attention_heads")):
+        a = ArchSpec(hidden=int(bb.hidden_size), enc_layers=int(bb.num_hidden_layers), enc_heads=int(bb.num_attention_heads),
+                     pos_grid=int(bb.get("image_size", 518)) // int(m.patch_size), name=str(name))
+    else:
+        raise ValueError(f"unknown backbone '{name}': known {sorted(BACKBONES)} (or give explicit sizes in cfg.model.backbone)")
+    return dataclasses.replace(a, patch=int(m.patch_size), pe_h=int(m.pos_enc.multi_view.h), pe_w=int(m.pos_enc.multi_view.w),
+                               do_self_attn=bool(m.decoder_do_self_attn))
+
+
+class _Node(torch.nn.Module):
+    """Parameter container; the tree of _Nodes reproduces the reference module paths."""
+
+
+class CrossScoreNet(torch.nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        m = cfg.model
+        if not m.do_reference_cross:
+            raise NotImplementedError("model.do_reference_cross=False produces no score map in the reference (task/core.py:89); not built")
+        if m.pos_enc.multi_view.interpolate_mode != "bilinear":
+            raise NotImplementedError("only model.pos_enc.multi_view.interpolate_mode=bilinear (the reference default) is built")
+        self.arch = arch_from_cfg(cfg)
+        metric = m.predict.metric
+        self._act, self._pow = regression_activation(metric.type, metric.min, metric.max, metric.power_factor)
+        # parameter tree with the checkpoint's key names (all frozen for inference)
+        for name, shape, kind, _ in synth.state_dict_spec(self.arch):
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, _Node())
+                node = getattr(node, p)
+            if name == "img_mean_std":
+                node.register_buffer(parts[-1], torch.tensor(synth.IMAGENET_MEAN_STD, dtype=torch.float32))
+            else:
+                node.register_parameter(parts[-1], torch.nn.Parameter(torch.zeros(shape, dtype=torch.float32), requires_grad=False))
+        self._handle = None
+        self._handle_device = None
+        self._dirty = True
+        self.enc_chunk_images = 0  # 0 = library default
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
+
+    # -- weights ----------------------------------------------------------------------------------------------
+    def _mark_dirty(self):
+        self._dirty = True
+
+    def load_numpy_state_dict(self, sd: Dict[str, np.ndarray]) -> None:
+        self.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.load().cs_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _ensure_handle(self, device: torch.device):
+        if self._handle is not None and not self._dirty and self._handle_device == device:
+            return self._handle
+        lib = _lib.load()
+        self._release()
+        a = self.arch
+        m = self.cfg.model
+        cc = _lib.CsConfig(hidden=a.hidden, enc_layers=a.enc_layers, enc_heads=a.enc_heads, mlp_ratio=a.mlp_ratio, patch=a.patch,
+                           pos_grid=a.pos_grid, pe_h=a.pe_h, pe_w=a.pe_w, dec_layers=a.dec_layers, dec_heads=a.dec_heads,
+                           do_self_attn=int(bool(m.decoder_do_self_attn)), do_short_cut=int(bool(m.decoder_do_short_cut)),
+                           act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images))
+        with torch.cuda.device(device):
+            h = lib.cs_create(C.byref(cc))
+            if not h:
+                msg = _lib.last_error()
+                raise NotImplementedError(msg) if "not in" in msg else ValueError(msg)
+            try:
+                for name, t in self.state_dict().items():
+                    t = t.detach().to(torch.float32).contiguous()
+                    shape = (C.c_int64 * t.dim())(*t.shape)
+                    _lib.check(lib.cs_set_weight(h, name.encode(), C.c_void_p(t.data_ptr()), int(t.is_cuda), t.dim(), shape))
+                _lib.check(lib.cs_finalize(h))
+            except Exception:
+                lib.cs_destroy(h)
+                raise
+        self._handle, self._handle_device, self._dirty = h, device, False
+        return h
+
+    # -- forward ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, query_img, ref_cross_imgs, need_attn_weights=False, need_attn_weights_head_id=0, norm_img=False,
+                return_mean=False):
+        """
+        :param query_img:       (B, 3, H, W) fp32, ImageNet-normalised
+        :param ref_cross_imgs:  (B, N_ref_cross, 3, H, W)
+        :param norm_img:        reference flag (task/core.py:76-81), bug-for-bug: the std used is the mean.
+        """
+        if ref_cross_imgs is None:
+            raise ValueError("ref_cross_imgs is required when model.do_reference_cross=True (task/core.py:90)")
+        if query_img.dim() != 4 or query_img.shape[1] != 3 or ref_cross_imgs.dim() != 5 or ref_cross_imgs.shape[2] != 3:
+            raise ValueError("expected query_img (B,3,H,W) and ref_cross_imgs (B,N,3,H,W)")
+        if ref_cross_imgs.shape[0] != query_img.shape[0] or ref_cross_imgs.shape[-2:] != query_img.shape[-2:]:
+            raise ValueError("query and reference batch / image sizes differ")
+        if not query_img.is_cuda:
+            raise _lib.CrossScoreHipError("CrossScoreNet.forward needs CUDA(HIP) tensors: the hot path has no CPU fallback")
+        dev = query_img.device
+        if norm_img:
+            mean = self.img_mean_std.to(dev)[None, :3, None, None]
+            query_img = (query_img - mean) / mean  # sic: task/core.py:77-79 divides by the mean
+            ref_cross_imgs = (ref_cross_imgs - mean[:, None]) / mean[:, None]
+        q = query_img.to(torch.float32).contiguous()
+        r = ref_cross_imgs.to(device=dev, dtype=torch.float32).contiguous()
+        B, _, H, W = q.shape
+        N = r.shape[1]
+        P = self.arch.patch
+        h, w = H // P, W // P
+        lib = _lib.load()
+        handle = self._ensure_handle(dev)
+        with torch.cuda.device(dev):
+            score = torch.empty((B, h * P, w * P), dtype=torch.float32, device=dev)
+            attn = torch.empty((B, h, w, N, h, w), dtype=torch.float32, device=dev) if need_attn_weights else None
+            mean_out = torch.empty((B,), dtype=torch.float32, device=dev) if return_mean else None
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.cs_forward(handle, C.c_void_p(q.data_ptr()), C.c_void_p(r.data_ptr()), B, N, H, W,
+                                C.c_void_p(score.data_ptr()), C.c_void_p(attn.data_ptr()) if attn is not None else None,
+                                int(need_attn_weights_head_id), C.c_void_p(mean_out.data_ptr()) if mean_out is not None else None,
+                                C.c_void_p(stream))
+            _lib.check(rc)
+        results = {"score_map_ref_cross": score, "attn_weights_map_ref_cross": attn}
+        if return_mean:
+            results["score_mean_ref_cross"] = mean_out  # key does not start with "score_map": writers ignore it
+        return results
+
+    # -- profiling hooks used by bench.py --------------------------------------------------------------------
+    def profile_enable(self, on: bool) -> None:
+        _lib.check(_lib.load().cs_profile_enable(self._handle, int(on)))
+
+    def profile_read(self, family: int):
+        ms, n, fl = C.c_double(), C.c_int(), C.c_double()
+        _lib.check(_lib.load().cs_profile_read(self._handle, family, C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
+
+def load_lightning_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    """`state_dict` of a CrossScore Lightning checkpoint with the "model." prefix removed
+    (CrossScoreLightningModule.model = CrossScoreNet, task/core.py:173).  Optimizer / scheduler / callback
+    state is ignored."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    return {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")} or dict(sd)

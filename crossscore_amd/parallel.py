@@ -1,0 +1,68 @@
+"""Batch sharding of the CrossScore forward over the GPUs of one node.
+
+Every batch item (query, N refs) is independent -- no op mixes the batch dimension (task/core.py:134-161,
+per-sample attention, no BatchNorm) -- and the reference scales the same way (Lightning DDP + distributed
+sampler, zero collectives in the forward: task/predict.py:119-135).  So the multi-GPU design is "replicas +
+contiguous batch shard": one process per GPU, a full weight replica each, rank r owns items
+[r*B/G, (r+1)*B/G).  RCCL (torch.distributed backend "nccl") carries only the per-image mean scores
+(B floats, all_gather) and timing scalars -- latency-bound messages; there is no data-path collective.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(global_batch: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous split; the first (global_batch % world_size) ranks take one extra item."""
+    if global_batch < 0 or world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad shard arguments")
+    base, rem = divmod(global_batch, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment; initialises the process group when
+    WORLD_SIZE > 1.  backend defaults to nccl (= RCCL on ROCm) when a GPU is present, else gloo."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def gather_means(local_means: torch.Tensor, global_batch: int) -> torch.Tensor:
+    """All ranks receive the (global_batch,) per-image mean scores in item order.  Shards may be ragged, so each
+    rank pads to the largest shard before the all_gather."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_means
+    world = dist.get_world_size()
+    sizes = [shard_bounds(global_batch, world, r) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros(mx, dtype=local_means.dtype, device=local_means.device)
+    pad[: local_means.numel()] = local_means
+    bufs: List[torch.Tensor] = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)])
+
+
+def max_over_ranks(value: float, device: torch.device | str = "cpu") -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,107 @@
+/* C ABI of libcrossscore_hip.so -- the MI355X (gfx950) CrossScore inference hot path.
+ *
+ * The reference (ActiveVisionLab/CrossScore) is pure Python and has no native interface; the boundary this
+ * library sits behind is the model call
+ *     CrossScoreNet.forward(query_img, ref_cross_imgs, need_attn_weights, need_attn_weights_head_id, norm_img)
+ *         -> {"score_map_ref_cross", "attn_weights_map_ref_cross"}            (task/core.py:58-117)
+ * made from CrossScoreLightningModule._core_step (task/core.py:265-272).  Each entry point below names the
+ * reference code it replaces.  Plain pointers and sizes only: no torch / Python types cross this line.
+ *
+ * Ownership: the caller (PyTorch) owns every input / output / weight-source buffer; the library owns only its
+ * packed bf16 weights and its workspace.  Threading: a handle is not thread-safe; one handle per process per
+ * GPU.  All work is enqueued on the caller's hipStream_t; no entry point synchronises the device except
+ * cs_finalize, cs_profile_* and cs_destroy.  Every function returning int returns 0 on success; on failure
+ * cs_last_error() describes it (CS_ERR_* below) and nothing was launched on the bad-argument paths.
+ */
+#ifndef CROSSSCORE_HIP_H
+#define CROSSSCORE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cs_model* cs_handle;
+typedef void* cs_stream; /* hipStream_t */
+
+enum {
+  CS_OK = 0,
+  CS_ERR_BAD_ARG = 1,     /* shape / config the reference would also reject (ValueError / assert) */
+  CS_ERR_UNSUPPORTED = 2, /* legal for the reference, not built here (e.g. head dim outside {16,48,64,96}) */
+  CS_ERR_STATE = 3,       /* wrong call order (forward before finalize, missing weight) */
+  CS_ERR_HIP = 4          /* HIP runtime error; message carries hipGetErrorString */
+};
+
+/* Architecture + the model.* config keys the forward consumes (config/model/model.yaml:1-32). */
+typedef struct cs_config {
+  int hidden;        /* C: Dinov2Config.hidden_size (384 small / 768 base), task/core.py:39 */
+  int enc_layers;    /* Dinov2Config.num_hidden_layers */
+  int enc_heads;     /* Dinov2Config.num_attention_heads (head dim must be 64 or 16) */
+  int mlp_ratio;     /* 4 */
+  int patch;         /* model.patch_size = 14 */
+  int pos_grid;      /* sqrt(#position_embeddings - 1) = 37 */
+  int pe_h, pe_w;    /* model.pos_enc.multi_view.{h,w} = 40,40 (bilinear, align_corners=True) */
+  int dec_layers;    /* 2, model/cross_reference.py:38 */
+  int dec_heads;     /* 8, model/cross_reference.py:31 */
+  int do_self_attn;  /* model.decoder_do_self_attn */
+  int do_short_cut;  /* model.decoder_do_short_cut */
+  int act;           /* 0 sigmoid (metric.min == 0), 1 tanh (metric.min == -1), model/regression_layer.py:31-38 */
+  float pow_p;       /* exponent after the activation; 1 = identity, model/regression_layer.py:40-62 */
+  int enc_chunk_images; /* images per encoder pass (0 = library default); keeps activations cache resident */
+} cs_config;
+
+/* Replaces CrossScoreNet.__init__ (task/core.py:27-56). NULL on failure. */
+cs_handle cs_create(const cs_config* cfg);
+void cs_destroy(cs_handle h);
+const char* cs_last_error(void);
+
+/* Replaces load_state_dict for one tensor: `name` is the checkpoint key without the "model." prefix (ckpt layout:
+ * SURVEY.md 8b), `data` fp32, row-major, host or device memory (is_device), `shape[ndim]` as in the state dict. */
+int cs_set_weight(cs_handle h, const char* name, const float* data, int is_device, int ndim, const int64_t* shape);
+/* Number of tensors cs_finalize expects and the i-th expected name (for loaders / strict checking). */
+int cs_num_weights(cs_handle h);
+const char* cs_weight_name(cs_handle h, int i);
+/* Packs weights to bf16 / fused layouts (QKV, both decoder layers' KV). Fails if a tensor is missing. */
+int cs_finalize(cs_handle h);
+
+/* Replaces CrossScoreNet.forward (task/core.py:58-117) with norm_img=False.
+ *   query:  (B,3,H,W) fp32 device, contiguous;   refs: (B,N,3,H,W) fp32 device, contiguous
+ *   score_out: (B, P*(H/P), P*(W/P)) fp32 device
+ *   attn_out:  NULL, or (B, h, w, N, h, w) fp32 device = probabilities of head `head_id` of the LAST decoder
+ *              layer's cross-attention (model/cross_reference.py:91-93)
+ *   mean_out:  NULL, or (B) fp32 device = per-image mean of the score map (utils/io/score_summariser.py:180-192) */
+int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N, int H, int W, float* score_out,
+               float* attn_out, int head_id, float* mean_out, cs_stream stream);
+/* Bytes of library-owned workspace a forward of this shape needs (grown lazily, never shrunk). */
+size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
+
+/* Per-kernel-family timing with HIP events on the launch stream (for bench.py's roofline object).
+ * Families: 0 gemm, 1 attention, 2 layernorm/elementwise.  Enabling inserts two events per launch. */
+int cs_profile_enable(cs_handle h, int on);
+int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, double* flops);
+
+/* ---- single-op entry points (used by the parity tests; same kernels the forward launches) ------------- */
+/* out = epilogue(A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. bf16 = raw uint16. */
+int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
+               const float* scale, const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np,
+               int gw, int P, int act, float powp, cs_stream stream);
+/* softmax(QK^T/sqrt(dh))V for `batch` x `heads`; strides in elements; lse may be NULL. */
+int cs_op_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* V, uint16_t* O, int ldq, int ldk, int ldv,
+                    int ldo, long long q_bs, long long k_bs, long long v_bs, long long o_bs, int batch, int heads,
+                    int Lq, int Lk, int dh, float* lse, cs_stream stream);
+int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int ldk, long long q_bs, long long k_bs,
+                            int batch, int heads, int Lq, int Lk, int dh, const float* lse, int head, float* out,
+                            cs_stream stream);
+int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
+                    uint16_t* out_bf16, cs_stream stream);
+int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream);
+int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream);
+int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
+int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, cs_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""torch-tensor wrappers over the single-op C-ABI entry points (tests only)."""
+import ctypes as C
+
+import torch
+
+from crossscore_amd import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_BF16, scale=None, resid=None, out=None, pos=None, Np=0, gw=0, P=0, act=0, powp=1.0,
+         K=None, ldc=None):
+    """A:(M,lda) bf16, W:(N,ldw) bf16 -> out (allocated here unless given)."""
+    lib = _lib.load()
+    M, lda = A.shape
+    N, ldw = W.shape
+    K = K or lda
+    if out is None:
+        dt = torch.bfloat16 if epi <= _lib.EPI_BIAS_LEAKY_BF16 else torch.float32
+        out = torch.zeros((M, N), dtype=dt, device=A.device)
+    ldc = ldc or out.shape[-1]
+    rc = lib.cs_op_gemm(_p(A), lda, _p(W), ldw, M, N, K, _p(bias), _p(scale), _p(resid), resid.shape[-1] if resid is not None else 0,
+                        _p(out), ldc, epi, _p(pos), Np, gw, P, act, powp, _stream())
+    _lib.check(rc)
+    return out
+
+
+def attention(Q, K, V, heads, dh, lse=False):
+    """Q:(B,Lq,heads*dh) K,V:(B,Lk,heads*dh) bf16 contiguous -> O (B,Lq,heads*dh) bf16 [, lse (B,heads,Lq)]."""
+    lib = _lib.load()
+    B, Lq, Cq = Q.shape
+    Lk = K.shape[1]
+    O = torch.zeros((B, Lq, heads * dh), dtype=torch.bfloat16, device=Q.device)
+    L = torch.zeros((B, heads, Lq), dtype=torch.float32, device=Q.device) if lse else None
+    rc = lib.cs_op_attention(_p(Q), _p(K), _p(V), _p(O), Q.stride(1), K.stride(1), V.stride(1), O.stride(1), Q.stride(0), K.stride(0),
+                             V.stride(0), O.stride(0), B, heads, Lq, Lk, dh, _p(L), _stream())
+    _lib.check(rc)
+    return (O, L) if lse else O
+
+
+def attention_weights(Q, K, heads, dh, lse, head):
+    lib = _lib.load()
+    B, Lq, _ = Q.shape
+    Lk = K.shape[1]
+    out = torch.zeros((B, Lq, Lk), dtype=torch.float32, device=Q.device)
+    rc = lib.cs_op_attention_weights(_p(Q), _p(K), Q.stride(1), K.stride(1), Q.stride(0), K.stride(0), B, heads, Lq, Lk, dh, _p(lse),
+                                     head, _p(out), _stream())
+    _lib.check(rc)
+    return out
+
+
+def layernorm(x, g, b, eps, want_f32=True, want_bf16=True):
+    lib = _lib.load()
+    M, Cc = x.shape
+    of = torch.zeros_like(x) if want_f32 else None
+    ob = torch.zeros((M, Cc), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    _lib.check(lib.cs_op_layernorm(_p(x), M, Cc, _p(g), _p(b), eps, _p(of), _p(ob), _stream()))
+    return of, ob
+
+
+def im2col(x, P, Kp):
+    lib = _lib.load()
+    I, _, H, W = x.shape
+    out = torch.zeros((I * (H // P) * (W // P), Kp), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.cs_op_im2col(_p(x), _p(out), I, H, W, P, Kp, _stream()))
+    return out
+
+
+def pos_bicubic(pos, G, gh, gw):
+    lib = _lib.load()
+    Cc = pos.shape[-1]
+    out = torch.zeros((1 + gh * gw, Cc), dtype=torch.float32, device=pos.device)
+    _lib.check(lib.cs_op_pos_bicubic(_p(pos), G, Cc, gh, gw, _p(out), _stream()))
+    return out
+
+
+def pe_bilinear(pe, gh, gw):
+    lib = _lib.load()
+    ph, pw, Cc = pe.shape
+    out = torch.zeros((gh * gw, Cc), dtype=torch.float32, device=pe.device)
+    _lib.check(lib.cs_op_pe_bilinear(_p(pe), ph, pw, Cc, gh, gw, _p(out), _stream()))
+    return out
+
+
+def pack_bf16(w, ldo=None):
+    lib = _lib.load()
+    rows, K = w.shape
+    ldo = ldo or K
+    out = torch.zeros((rows, ldo), dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.cs_op_pack_bf16(_p(w), rows, K, _p(out), ldo, _stream()))
+    return out

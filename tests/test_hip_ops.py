@@ -1,0 +1,281 @@
+"""Parity of each HIP kernel (through the C ABI) against the fp32 oracle / a plain fp32 torch restatement on the
+same seeded inputs.  Floating point: tolerances are stated per test (bf16 operands, fp32 accumulation)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from crossscore_amd import _lib  # noqa: E402
+from oracle import crossscore_oracle as orc  # noqa: E402
+import hip_helpers as hh  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 384), (1370, 1152, 384), (257, 196 + 60, 128), (65, 1536, 384),
+                                   (1000, 384, 1536), (2740, 2304, 768)])
+def test_gemm_bias_bf16(M, N, K):
+    g = _rng(M + N + K)
+    A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))
+    W = _bf(_t(g.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)))
+    b = _t(g.standard_normal((N,), dtype=np.float32))
+    out = hh.gemm(A, W, b, _lib.EPI_BIAS_BF16)
+    ref = A.float() @ W.float().t() + b
+    torch.cuda.synchronize()
+    # out is bf16-rounded: rel 2^-9 of |ref| plus accumulation-order noise
+    err = (out.float() - ref).abs()
+    assert (err <= 4e-3 * ref.abs() + 1e-3).all(), float(err.max())
+
+
+def test_gemm_exact_integer_layout():
+    """A = I-like / asymmetric integer operands: any row<->col swap or fragment mis-mapping is an exact mismatch."""
+    M, N, K = 256, 256, 128
+    A = torch.zeros((M, K), device=DEV)
+    A[torch.arange(M), torch.arange(M) % K] = 1.0  # row m selects k = m % K
+    W = (torch.arange(N, device=DEV)[:, None] * 3 + torch.arange(K, device=DEV)[None, :] * 7) % 61 - 30.0  # asymmetric ints
+    out = hh.gemm(_bf(A), _bf(W.float()), None, _lib.EPI_RESID_F32)
+    ref = A @ W.float().t()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_BIAS_GELU_BF16, _lib.EPI_BIAS_RELU_BF16, _lib.EPI_BIAS_LEAKY_BF16])
+def test_gemm_activations(epi):
+    M, N, K = 513, 384, 384
+    g = _rng(epi)
+    A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))
+    W = _bf(_t(g.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)))
+    b = _t(g.standard_normal((N,), dtype=np.float32))
+    out = hh.gemm(A, W, b, epi)
+    y = A.float() @ W.float().t() + b
+    ref = {_lib.EPI_BIAS_GELU_BF16: orc.gelu_erf(y.cpu()).to(DEV), _lib.EPI_BIAS_RELU_BF16: torch.relu(y),
+           _lib.EPI_BIAS_LEAKY_BF16: torch.where(y >= 0, y, 0.01 * y)}[epi]
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs()
+    assert (err <= 4e-3 * ref.abs() + 1e-3).all(), float(err.max())
+
+
+@pytest.mark.parametrize("with_scale,with_resid", [(True, True), (False, True), (False, False)])
+def test_gemm_resid_f32(with_scale, with_resid):
+    M, N, K = 700, 384, 1536
+    g = _rng(11)
+    A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))
+    W = _bf(_t(g.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)))
+    b = _t(g.standard_normal((N,), dtype=np.float32))
+    s = _t(g.standard_normal((N,), dtype=np.float32)) if with_scale else None
+    r = _t(g.standard_normal((M, N), dtype=np.float32)) if with_resid else None
+    out = r.clone() if with_resid else None  # in-place residual update, as the encoder uses it
+    out = hh.gemm(A, W, b, _lib.EPI_RESID_F32, scale=s, resid=out, out=out)
+    ref = A.float() @ W.float().t() + b
+    if with_scale:
+        ref = ref * s
+    if with_resid:
+        ref = ref + r
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max() < 2e-4  # fp32 out; only accumulation order differs
+
+
+def test_gemm_patch_epilogue_and_im2col():
+    """im2col + patch GEMM == conv patchify + cls/pos placement (HF:97-149), rows m -> img*T + 1 + p."""
+    I, H, W, P, Cc = 3, 75, 90, 14, 128
+    gh, gw = H // P, W // P
+    Np, T = gh * gw, gh * gw + 1
+    g = _rng(5)
+    x = _t(g.standard_normal((I, 3, H, W), dtype=np.float32))
+    wconv = _t(g.standard_normal((Cc, 3, P, P), dtype=np.float32) / math.sqrt(588))
+    b = _t(g.standard_normal((Cc,), dtype=np.float32))
+    pos = _t(g.standard_normal((T, Cc), dtype=np.float32))
+    Kp = 640
+    A = hh.im2col(x, P, Kp)
+    # im2col vs unfold restatement
+    xr = x[:, :, : gh * P, : gw * P].reshape(I, 3, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(I * Np, 588)
+    assert torch.equal(A[:, :588], _bf(xr)) and (A[:, 588:] == 0).all()
+    Wp = hh.pack_bf16(wconv.reshape(Cc, 588), Kp)
+    assert torch.equal(Wp[:, :588], _bf(wconv.reshape(Cc, 588))) and (Wp[:, 588:] == 0).all()
+    out = torch.full((I * T, Cc), 7.0, device=DEV)
+    hh.gemm(A, Wp, b, _lib.EPI_PATCH_F32, out=out, pos=pos, Np=Np, K=Kp)
+    ref = (A[:, :588].float() @ Wp[:, :588].float().t() + b).reshape(I, Np, Cc) + pos[None, 1:]
+    torch.cuda.synchronize()
+    o3 = out.reshape(I, T, Cc)
+    assert (o3[:, 1:] - ref).abs().max() < 2e-4
+    assert (o3[:, 0] == 7.0).all()  # CLS rows untouched by the GEMM
+
+
+@pytest.mark.parametrize("act,powp", [(0, 1.0), (0, 2.0), (0, 0.5), (1, 1.0)])
+def test_gemm_head_score_jigsaw(act, powp):
+    """sigmoid/tanh (+pow) + jigsaw store (regression_layer.py:26-62, utils/misc/image.py:8-21)."""
+    B, gh, gw, P, Cc = 2, 5, 6, 14, 128
+    Np = gh * gw
+    g = _rng(9)
+    A = _bf(_t(g.standard_normal((B * Np, Cc), dtype=np.float32)))
+    W = _bf(_t(g.standard_normal((P * P, Cc), dtype=np.float32) / math.sqrt(Cc)))
+    b = _t(g.standard_normal((P * P,), dtype=np.float32))
+    out = torch.zeros((B, gh * P, gw * P), device=DEV)
+    hh.gemm(A, W, b, _lib.EPI_HEAD_SCORE, out=out, Np=Np, gw=gw, P=P, act=act, powp=powp, ldc=4)
+    y = A.float() @ W.float().t() + b
+    y = torch.sigmoid(y) if act == 0 else torch.tanh(y)
+    if powp != 1.0:
+        y = y ** powp
+    ref = orc.jigsaw_to_image(y.cpu().view(B, Np, P, P), gh, gw).to(DEV)
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max() < 1e-5
+
+
+def test_gemm_rejects_bad_shapes():
+    A = torch.zeros((64, 96), dtype=torch.bfloat16, device=DEV)
+    W = torch.zeros((64, 96), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError):
+        hh.gemm(A, W)  # K=96 not a multiple of 64
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_ref(Q, K, V, heads, dh):
+    B, Lq, _ = Q.shape
+    Lk = K.shape[1]
+    q = Q.float().view(B, Lq, heads, dh).transpose(1, 2)
+    k = K.float().view(B, Lk, heads, dh).transpose(1, 2)
+    v = V.float().view(B, Lk, heads, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(B, Lq, heads * dh)
+    return o, p, torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("dh,heads,Lq,Lk,B", [
+    (64, 2, 128, 64, 1), (64, 6, 1370, 1370, 2), (64, 2, 31, 31, 3), (64, 1, 129, 65, 1),
+    (48, 8, 1369, 1369, 1), (48, 8, 300, 1500, 2), (96, 8, 257, 513, 1), (16, 8, 30, 60, 2), (16, 8, 200, 333, 1),
+])
+def test_attention_matches_fp32(dh, heads, Lq, Lk, B):
+    g = _rng(dh * 1000 + Lq + Lk)
+    Cc = heads * dh
+    Q = _bf(_t(1.5 * g.standard_normal((B, Lq, Cc), dtype=np.float32)))
+    K = _bf(_t(1.5 * g.standard_normal((B, Lk, Cc), dtype=np.float32)))
+    V = _bf(_t(g.standard_normal((B, Lk, Cc), dtype=np.float32)))
+    O, lse = hh.attention(Q, K, V, heads, dh, lse=True)
+    ref, _, lse_ref = _attn_ref(Q, K, V, heads, dh)
+    torch.cuda.synchronize()
+    # P is rounded to bf16 before PV and O to bf16 on store: abs tol 1.5e-2 on |O|<~4, typical 2e-3
+    err = (O.float() - ref).abs()
+    assert err.max() < 2e-2 and err.mean() < 2e-3, (float(err.max()), float(err.mean()))
+    assert (lse * math.log(2.0) - lse_ref).abs().max() < 2e-3
+
+
+def test_attention_exact_layout():
+    """One-hot softmax (huge logit on a chosen key per query) makes O[q] == V[key(q)] exactly: catches any key /
+    d permutation error in the transposed-read / accumulator-as-operand path."""
+    dh, heads, Lq, Lk = 64, 1, 160, 200
+    Q = torch.zeros((1, Lq, dh), device=DEV)
+    K = torch.zeros((1, Lk, dh), device=DEV)
+    sel = (torch.arange(Lq, device=DEV) * 37 + 11) % Lk
+    # 8-bit codes in +-16 on dims 0..7 : q.k is maximal (8*256) only for the matching key
+    def code(i):
+        bits = ((i[:, None] >> torch.arange(8, device=DEV)[None]) & 1).float() * 2 - 1
+        return bits * 16
+    K[0, :, :8] = code(torch.arange(Lk, device=DEV))
+    Q[0, :, :8] = code(sel)
+    V = torch.arange(Lk * dh, device=DEV).float().view(1, Lk, dh) % 251 - 125  # exact in bf16
+    O = hh.attention(_bf(Q), _bf(K), _bf(V), heads, dh)
+    torch.cuda.synchronize()
+    assert torch.equal(O.float()[0], V[0][sel])
+
+
+def test_attention_forces_rescale_branch():
+    """Spike in a LATE key tile: the running max jumps there, so the online-softmax rescale of O and l is exercised
+    against a full fp32 reference (cdna guide rule 26)."""
+    dh, heads, Lq, Lk = 64, 2, 96, 640
+    g = _rng(77)
+    Q = _t(g.standard_normal((1, Lq, heads * dh), dtype=np.float32))
+    K = _t(g.standard_normal((1, Lk, heads * dh), dtype=np.float32))
+    V = _t(g.standard_normal((1, Lk, heads * dh), dtype=np.float32))
+    K[0, 600] = 6.0 * Q[0, 5]  # key 600 (tile 9) dominates query 5
+    K[0, 3] = 3.0 * Q[0, 40]   # early spike for query 40
+    Qb, Kb, Vb = _bf(Q), _bf(K), _bf(V)
+    O = hh.attention(Qb, Kb, Vb, heads, dh)
+    ref, _, _ = _attn_ref(Qb, Kb, Vb, heads, dh)
+    torch.cuda.synchronize()
+    assert (O.float() - ref).abs().max() < 2e-2
+
+
+def test_attention_strided_packed_qkv():
+    """Reads Q/K/V in place from a packed [tokens][3C] projection, as the encoder does."""
+    dh, heads, T, B = 64, 2, 150, 2
+    Cc = heads * dh
+    g = _rng(3)
+    qkv = _bf(_t(g.standard_normal((B, T, 3 * Cc), dtype=np.float32)))
+    O = hh.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads, dh)
+    ref, _, _ = _attn_ref(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads, dh)
+    torch.cuda.synchronize()
+    assert (O.float() - ref).abs().max() < 2e-2
+
+
+def test_attention_weights_one_head():
+    dh, heads, Lq, Lk, B = 48, 8, 70, 210, 2
+    g = _rng(8)
+    Cc = heads * dh
+    Q = _bf(_t(1.5 * g.standard_normal((B, Lq, Cc), dtype=np.float32)))
+    K = _bf(_t(1.5 * g.standard_normal((B, Lk, Cc), dtype=np.float32)))
+    V = _bf(_t(g.standard_normal((B, Lk, Cc), dtype=np.float32)))
+    _, lse = hh.attention(Q, K, V, heads, dh, lse=True)
+    Pw = hh.attention_weights(Q, K, heads, dh, lse, head=3)
+    _, p_ref, _ = _attn_ref(Q, K, V, heads, dh)
+    torch.cuda.synchronize()
+    assert (Pw - p_ref[:, 3]).abs().max() < 1e-4
+    assert (Pw.sum(-1) - 1).abs().max() < 1e-4
+
+
+def test_attention_rejects_unsupported_head_dim():
+    Q = torch.zeros((1, 8, 32), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError):
+        hh.attention(Q, Q, Q, 1, 32)
+
+
+# ------------------------------------------------------------------------------- LayerNorm & position tables
+@pytest.mark.parametrize("M,Cc,eps", [(1370, 384, 1e-6), (77, 768, 1e-5), (5, 128, 1e-6)])
+def test_layernorm(M, Cc, eps):
+    g = _rng(M)
+    x = _t(3.0 * g.standard_normal((M, Cc), dtype=np.float32) + 1.0)
+    gam = _t(1 + 0.2 * g.standard_normal((Cc,), dtype=np.float32))
+    bet = _t(0.1 * g.standard_normal((Cc,), dtype=np.float32))
+    of, ob = hh.layernorm(x, gam, bet, eps)
+    ref = orc.layer_norm(x.cpu(), gam.cpu(), bet.cpu(), eps).to(DEV)
+    torch.cuda.synchronize()
+    assert (of - ref).abs().max() < 2e-5
+    assert torch.equal(ob, _bf(of))
+
+
+@pytest.mark.parametrize("G,gh,gw", [(5, 5, 6), (37, 74, 74), (37, 37, 49), (37, 20, 11)])
+def test_pos_bicubic(G, gh, gw):
+    Cc = 64
+    g = _rng(G + gh)
+    pos = _t(g.standard_normal((1 + G * G, Cc), dtype=np.float32))
+    out = hh.pos_bicubic(pos, G, gh, gw)
+    ref = torch.cat([pos[:1].cpu(), orc.bicubic_resize_grid(pos[1:].cpu().reshape(G, G, Cc), gh, gw).reshape(gh * gw, Cc)])
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("gh,gw", [(37, 37), (5, 6), (74, 74), (37, 49)])
+def test_pe_bilinear(gh, gw):
+    Cc = 64
+    g = _rng(gh * gw)
+    pe = _t(g.standard_normal((40, 40, Cc), dtype=np.float32))
+    out = hh.pe_bilinear(pe, gh, gw)
+    ref = orc.bilinear_resize_grid_align_corners(pe.cpu(), gh, gw).reshape(gh * gw, Cc)
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 1e-5

@@ -1,0 +1,181 @@
+"""CPU-side checks: config tree, drop-in module surface / state-dict layout, C-ABI exports, batch sharding."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from crossscore_amd import _lib, synth
+from crossscore_amd.config import load_config, model_config
+from crossscore_amd.model import CrossScoreNet, regression_activation
+from crossscore_amd.parallel import shard_bounds
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_defaults_match_reference_keys():
+    cfg = load_config()
+    assert cfg.model.patch_size == 14 and cfg.model.do_reference_cross is True
+    assert cfg.model.backbone.from_pretrained == "facebook/dinov2-small"
+    assert (cfg.model.pos_enc.multi_view.h, cfg.model.pos_enc.multi_view.w) == (40, 40)
+    assert cfg.model.pos_enc.multi_view.interpolate_mode == "bilinear"
+    assert cfg.model.predict.metric.type == "ssim" and cfg.model.predict.metric.min == 0 and cfg.model.predict.metric.max == 1
+    assert cfg.model.predict.metric.power_factor == "default"
+    assert cfg.model.need_attn_weights is False and cfg.model.need_attn_weights_head_id == 0
+    assert cfg.data.loader.validation.batch_size == 8 and cfg.data.neighbour_config.cross == 5
+    assert cfg.this_main.resize_short_side == 518 and cfg.trainer.precision == "16-mixed"
+    assert cfg.lightning.seed == 1
+
+
+def test_config_overrides():
+    cfg = load_config(overrides=["model.backbone.from_pretrained=facebook/dinov2-base", "trainer.devices=[0,1]",
+                                 "model.predict.metric.power_factor=1.5", "alias=run1"])
+    assert cfg.model.backbone.from_pretrained == "facebook/dinov2-base"
+    assert cfg.trainer.devices == [0, 1] and cfg.model.predict.metric.power_factor == 1.5 and cfg.alias == "run1"
+    with pytest.raises(ValueError):
+        load_config(overrides=["novalue"])
+
+
+def test_regression_activation_table():
+    assert regression_activation("ssim", 0, 1, "default") == (0, 1.0)
+    assert regression_activation("mae", 0, 1, "default") == (0, 2.0)
+    assert regression_activation("mse", 0, 1, "default") == (0, 4.0)
+    assert regression_activation("ssim", -1, 1, 5) == (1, 1.0)
+    assert regression_activation("ssim", 0, 1, 1.5) == (0, 1.5)
+    for bad in [("psnr", 0, 1), ("mae", -1, 1), ("ssim", 0, 2), ("ssim", 0.5, 1)]:
+        with pytest.raises(ValueError):
+            regression_activation(*bad, "default")
+
+
+def test_state_dict_layout_small():
+    net = CrossScoreNet(model_config())
+    sd = net.state_dict()
+    spec = {n: s for n, s, _, _ in synth.state_dict_spec(synth.BACKBONES["facebook/dinov2-small"])}
+    assert set(sd) == set(spec)
+    assert all(tuple(sd[k].shape) == spec[k] for k in spec)
+    # spot checks against the checkpoint layout listed in SURVEY.md 8b
+    assert tuple(sd["backbone.embeddings.position_embeddings"].shape) == (1, 1370, 384)
+    assert tuple(sd["backbone.encoder.layer.11.mlp.fc1.weight"].shape) == (1536, 384)
+    assert tuple(sd["ref_cross.attn.layers.1.multihead_attn.in_proj_weight"].shape) == (1152, 384)
+    assert tuple(sd["ref_cross.head.2.weight"].shape) == (196, 384)
+    assert tuple(sd["pos_enc_fn.PE"].shape) == (1, 40, 40, 384)
+    assert sum(v.numel() for k, v in sd.items() if k != "img_mean_std") == 25_855_684 - 0  # SURVEY.md section 5 param count
+    assert torch.allclose(net.img_mean_std, torch.tensor(synth.IMAGENET_MEAN_STD))
+    assert not any(p.requires_grad for p in net.parameters())
+
+
+def test_state_dict_strict_load_and_lightning_prefix(tmp_path):
+    arch = synth.BACKBONES["synthetic/dinov2-tiny"]
+    net = CrossScoreNet(model_config(**{"backbone.from_pretrained": "synthetic/dinov2-tiny"}))
+    sd = synth.make_state_dict(arch, 3)
+    net.load_numpy_state_dict(sd)
+    assert np.array_equal(net.state_dict()["ref_cross.head.2.bias"].numpy(), sd["ref_cross.head.2.bias"])
+    bad = dict(sd)
+    bad.pop("pos_enc_fn.PE")
+    with pytest.raises(RuntimeError):
+        net.load_numpy_state_dict(bad)
+    # Lightning checkpoint layout: state_dict keys prefixed "model."
+    from crossscore_amd.model import load_lightning_checkpoint
+    path = str(tmp_path / "fake.ckpt")
+    torch.save({"state_dict": {"model." + k: torch.from_numpy(v) for k, v in sd.items()}, "hyper_parameters": {}, "epoch": 3}, path)
+    net2 = CrossScoreNet(model_config(**{"backbone.from_pretrained": "synthetic/dinov2-tiny"}))
+    net2.load_state_dict(load_lightning_checkpoint(path), strict=True)
+    assert torch.equal(net2.state_dict()["pos_enc_fn.PE"], net.state_dict()["pos_enc_fn.PE"])
+
+
+def test_no_self_attn_variant_has_no_self_attn_keys():
+    net = CrossScoreNet(model_config(**{"backbone.from_pretrained": "synthetic/dinov2-tiny", "decoder_do_self_attn": False}))
+    assert not any("self_attn" in k for k in net.state_dict())
+
+
+def test_forward_refuses_cpu_tensors():
+    net = CrossScoreNet(model_config(**{"backbone.from_pretrained": "synthetic/dinov2-tiny"}))
+    q = torch.zeros(1, 3, 70, 70)
+    with pytest.raises(RuntimeError):
+        net(q, torch.zeros(1, 2, 3, 70, 70), False, 0, False)
+    with pytest.raises(ValueError):
+        net(q, None, False, 0, False)
+
+
+def test_invalid_metric_config_raises_like_reference():
+    with pytest.raises(ValueError):
+        CrossScoreNet(model_config(**{"predict.metric.type": "psnr"}))
+    with pytest.raises(ValueError):
+        CrossScoreNet(model_config(**{"predict.metric.type": "mae", "predict.metric.min": -1}))
+
+
+def test_library_exports_every_declared_symbol():
+    """The .so loads and exports exactly what include/crossscore_hip.h declares (no compute without a GPU)."""
+    lib = _lib.load()
+    hdr = open(os.path.join(REPO, "include", "crossscore_hip.h")).read()
+    declared = set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    # cs_create validates on the host before touching the device
+    cc = _lib.CsConfig(hidden=100, enc_layers=1, enc_heads=1, mlp_ratio=4, patch=14, pos_grid=5, pe_h=40, pe_w=40, dec_layers=2,
+                       dec_heads=8, do_self_attn=1, do_short_cut=1, act=0, pow_p=1.0, enc_chunk_images=0)
+    assert not lib.cs_create(ctypes.byref(cc))
+    assert b"hidden" in lib.cs_last_error()
+
+
+def test_product_package_never_imports_oracle():
+    src_dir = os.path.join(REPO, "crossscore_amd")
+    for root, _, files in os.walk(src_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_shard_bounds_cover_batch():
+    for B in (1, 7, 8, 128, 130):
+        for G in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(B, G, r) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    assert shard_bounds(128, 8, 3) == (48, 64)
+
+
+def test_synth_shard_inputs_bitwise_equal_full_batch():
+    q, r = synth.make_inputs(4, 2, 28, 42, 9)
+    q1, r1 = synth.make_inputs_shard(2, 4, 2, 28, 42, 9)
+    assert np.array_equal(q[2:], q1) and np.array_equal(r[2:], r1)
+
+
+def _run_workers(world, script):
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", script]
+    return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+
+
+def test_gloo_world2_shard_gather(tmp_path):
+    """world_size-2 gloo run of the N>1 control path: shard bounds, ragged all_gather of per-image means,
+    max-over-ranks timing.  Each rank 'scores' its shard with a stand-in (the seeded input mean) so the gathered
+    vector must equal the single-process result bit for bit."""
+    script = tmp_path / "worker.py"
+    script.write_text(
+        "import torch, numpy as np\n"
+        "from crossscore_amd import synth\n"
+        "from crossscore_amd.parallel import init_from_env, shard_bounds, gather_means, max_over_ranks, barrier\n"
+        "rank, local, world = init_from_env('gloo')\n"
+        "B = 5\n"
+        "lo, hi = shard_bounds(B, world, rank)\n"
+        "q, r = synth.make_inputs_shard(lo, hi, 2, 28, 28, 4)\n"
+        "local_means = torch.from_numpy(q.reshape(hi - lo, -1).mean(1))\n"
+        "barrier()\n"
+        "allm = gather_means(local_means, B)\n"
+        "t = max_over_ranks(float(rank + 1))\n"
+        "qf, _ = synth.make_inputs(B, 2, 28, 28, 4)\n"
+        "ref = torch.from_numpy(qf.reshape(B, -1).mean(1))\n"
+        "assert torch.equal(allm, ref), (allm, ref)\n"
+        "assert t == float(world)\n"
+        "if rank == 0: print('GLOO_OK', world)\n")
+    res = _run_workers(2, str(script))
+    assert res.returncode == 0 and "GLOO_OK 2" in res.stdout, res.stdout[-2000:]
