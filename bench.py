@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Benchmark of the CrossScore hot path on MI355X: query-images/sec of CrossScoreNet.forward on synthetic input.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one rank per GPU).
+A step = one forward over one per-GPU batch of (query, 5 refs) items already resident in HBM.  Workload =
+BASELINE.json configs[1]: ViT-S/14 encoder, 518x518, 5 refs, batch 8 per GPU (weak scaling: every rank runs its own
+independent batch; no data-path collective -- items never interact).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+from crossscore_amd import synth  # noqa: E402
+from crossscore_amd.config import model_config  # noqa: E402
+from crossscore_amd.model import CrossScoreNet  # noqa: E402
+from crossscore_amd import parallel  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+GEMM_EPI = ["BIAS_BF16", "BIAS_GELU_BF16", "BIAS_RELU_BF16", "BIAS_LEAKY_BF16", "RESID_F32", "PATCH_F32", "HEAD_SCORE"]
+WORKLOADS = {
+    # name: (backbone, H, W, N refs, per-GPU batch)
+    "cfg2": ("facebook/dinov2-small", 518, 518, 5, 8),
+    "cfg3": ("facebook/dinov2-base", 518, 518, 10, 8),
+    "cfg4": ("facebook/dinov2-base", 518, 518, 5, 16),
+    "cfg5": ("facebook/dinov2-small", 1036, 1036, 5, 2),
+}
+
+
+def algorithmic_flops_per_query(C, L, H, W, N, P=14, dec_layers=2):
+    """2 FLOPs per MAC."""
+    Np = (H // P) * (W // P)
+    T, Lq, Lk = Np + 1, Np, N * Np
+    enc = 2 * Np * 3 * P * P * C + L * (24 * T * C * C + 4 * T * T * C)
+    dec = dec_layers * (16 * Lq * C * C + 4 * Lk * C * C + 4 * Lq * Lq * C + 4 * Lq * Lk * C)
+    head = 2 * Lq * C * C + 2 * Lq * C * P * P
+    return (1 + N) * enc + dec + head
+
+
+def kernel_table(net):
+    rows = []
+    for fam in list(range(7)) + [16 + d // 16 for d in (16, 48, 64, 96)] + [32]:
+        ms, n, fl = net.profile_read(fam)
+        if n == 0:
+            continue
+        name = (f"cs_gemm_kernel<{GEMM_EPI[fam]}>" if fam < 7 else f"cs_attn_kernel<{(fam - 16) * 16}>" if fam < 32 else "layernorm/im2col/other")
+        rows.append(dict(kernel=name, launches=n, total_ms=ms, avg_us=1e3 * ms / n, tflops=(fl / ms / 1e9) if fl else None, flops=fl))
+    return rows
+
+
+def cpu_baseline(arch, sd, H, W, N, hip_score_item0, seed, max_seconds=40.0):
+    """Oracle (CPU fp32 restatement = 'port') timed on the host cores on a bounded sample of the same workload:
+    B=1 items of the benchmark batch, 1 untimed warm-up + timed repeats while under ~max_seconds."""
+    from oracle import crossscore_oracle as orc
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))  # pure-torch oracle: more threads than ~32 only adds contention
+    Wt = orc.to_torch(sd)
+    q, r = synth.make_inputs_shard(0, 1, N, H, W, seed)
+    tq, tr = torch.from_numpy(q), torch.from_numpy(r)
+    cfg = dict(enc_heads=arch.enc_heads)
+    t0 = time.time()
+    ref = orc.forward(Wt, cfg, tq, tr)["score_map_ref_cross"]  # warm-up (also the parity reference)
+    warm = time.time() - t0
+    n, t_sum = 0, 0.0
+    while n < 1 or (t_sum + warm * (n + 1) / max(n, 1) < max_seconds and n < 3):
+        t0 = time.time()
+        orc.forward(Wt, cfg, tq, tr)
+        t_sum += time.time() - t0
+        n += 1
+    mae = float((hip_score_item0.cpu() - ref[0]).abs().mean())
+    return dict(value=n / t_sum, unit="query-images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} timed + 1 warm-up forward(s) of batch item 0 (B=1, {N} refs, {H}x{W}), fp32 oracle"), mae
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    rank, local_rank, world = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    backbone, H, W, N, B = WORKLOADS[args.workload]
+    seed = 1
+    net = CrossScoreNet(model_config(**{"backbone.from_pretrained": backbone}))
+    arch = net.arch
+    sd = synth.make_state_dict(arch, seed)  # every rank builds the same replica from the seed (no broadcast needed)
+    net.load_numpy_state_dict(sd)
+    net = net.to(dev)
+    lo = rank * B  # weak scaling: rank r scores global items [r*B, (r+1)*B)
+    q, r = synth.make_inputs_shard(lo, lo + B, N, H, W, seed)
+    tq, tr = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)  # inputs resident in HBM before timing
+
+    for _ in range(max(args.warmup, 1)):
+        out = net(tq, tr, False, 0, False)
+    torch.cuda.synchronize(dev)
+    parallel.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net(tq, tr, False, 0, False)
+    torch.cuda.synchronize(dev)
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(elapsed, dev)
+    score = out["score_map_ref_cross"]
+
+    # ---- per-kernel HIP-event timing (separate pass so the events do not perturb the timed region) ----
+    result = None
+    if rank == 0:
+        net.profile_enable(True)
+        prof_steps = 3
+        for _ in range(prof_steps):
+            net(tq, tr, False, 0, False)
+        rows = kernel_table(net)
+        net.profile_enable(False)
+        for rrow in rows:
+            rrow["launches_per_step"] = rrow["launches"] // prof_steps
+        dom = max((x for x in rows if x["tflops"]), key=lambda x: x["total_ms"])
+        flops_q = algorithmic_flops_per_query(arch.hidden, arch.enc_layers, H, W, N)
+        value = world * B * args.steps / elapsed
+        result = {
+            "metric": "query-images/sec at 518x518, 5 ref views, bs=8; score-map MAE vs ref",
+            "value": value, "unit": "query-images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {backbone} encoder, {H}x{W}, {N} refs, batch {B} per GPU "
+                                   f"(global batch {B * world}), seeded synthetic weights + N(0,1) inputs",
+                       "gflop_per_query": flops_q / 1e9, "parallelism": f"batch-shard x{world} (replicas, no data-path collective)"},
+            "whole_path": {"achieved_tflops": value * flops_q / 1e12 / world, "peak_tflops": PEAK_BF16_TFLOPS,
+                           "frac": value * flops_q / 1e12 / world / PEAK_BF16_TFLOPS},
+            "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                         "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
+                         "flop_per_launch": dom["flops"] / dom["launches"]},
+            "kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in x.items() if k != "flops"} for x in rows],
+        }
+        if args.kernels:
+            for x in rows:
+                print(x, file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            cb, mae = cpu_baseline(arch, sd, H, W, N, score[0], seed)
+            result["cpu_baseline"] = cb
+            result["score_map_mae"] = mae
+            result["speedup_vs_cpu_baseline"] = value / cb["value"]
+    parallel.barrier()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

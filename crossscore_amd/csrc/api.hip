@@ -155,7 +155,7 @@ Plan make_plan(const cs_model* m, int B, int N, int H, int W, char* base) {
   const cs_config& c = m->cfg;
   p.B = B; p.N = N; p.H = H; p.W = W; p.C = c.hidden;
   p.gh = H / c.patch; p.gw = W / c.patch; p.Np = p.gh * p.gw; p.T = p.Np + 1; p.I = B * (1 + N);
-  int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 16 : 8);
+  int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 64 : 32);
   // keep chunks balanced: same number of passes, near-equal sizes
   const int passes = (p.I + ic - 1) / ic;
   p.Ic = (p.I + passes - 1) / passes;
@@ -192,7 +192,7 @@ struct Launcher {
   bool gemm(CsGemmParams g, int epi, double k_real = 0) {
     if (rc) return false;
     if (const char* e = cs_gemm_check(&g, epi)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
-    begin(0, 2.0 * g.M * g.N * (k_real > 0 ? k_real : g.K));
+    begin(epi, 2.0 * g.M * g.N * (k_real > 0 ? k_real : g.K));
     hipError_t e = cs_gemm_launch(&g, epi, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "gemm launch: %s", hipGetErrorString(e)); return false; }
@@ -201,7 +201,7 @@ struct Launcher {
   bool attn(CsAttnParams a, int dh, int batch) {
     if (rc) return false;
     if (const char* e = cs_attn_check(&a, dh, batch)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
-    begin(1, 4.0 * batch * a.heads * (double)a.Lq * a.Lk * dh);
+    begin(16 + dh / 16, 4.0 * batch * a.heads * (double)a.Lq * a.Lk * dh);
     hipError_t e = cs_attn_launch(&a, dh, batch, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "attention launch: %s", hipGetErrorString(e)); return false; }
@@ -449,8 +449,8 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
   for (int i0 = 0; i0 < p.I; i0 += p.Ic) {
     const int ic = std::min(p.Ic, p.I - i0);
     const int Mc = ic * p.T;
-    L.begin(2, 0); L.misc(cs_im2col_launch(query, refs, N, i0, p.r1, ic, H, W, P, h->Kp, st), "im2col"); L.end();
-    L.begin(2, 0); L.misc(cs_cls_rows_launch(p.x, ic, p.T, C, h->cls, h->pos_tab, st), "cls"); L.end();
+    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N, i0, p.r1, ic, H, W, P, h->Kp, st), "im2col"); L.end();
+    L.begin(32, 0); L.misc(cs_cls_rows_launch(p.x, ic, p.T, C, h->cls, h->pos_tab, st), "cls"); L.end();
     {
       CsGemmParams g = gp(p.r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, p.x, C);
       g.pos = h->pos_tab; g.Np = p.Np;
@@ -458,7 +458,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
     }
     for (int l = 0; l < c.enc_layers; ++l) {
       const EncLayer& E = h->enc[l];
-      L.begin(2, 0); L.misc(cs_layernorm_launch(p.x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, p.u, st), "ln1"); L.end();
+      L.begin(32, 0); L.misc(cs_layernorm_launch(p.x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, p.u, st), "ln1"); L.end();
       L.gemm(gp(p.u, C, E.Wqkv, C, Mc, 3 * C, C, E.bqkv, p.r1, 3 * C), CS_EPI_BIAS_BF16);
       {
         CsAttnParams a{};
@@ -473,7 +473,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
         g.scale = E.ls1; g.resid = p.x; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
-      L.begin(2, 0); L.misc(cs_layernorm_launch(p.x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, p.u, st), "ln2"); L.end();
+      L.begin(32, 0); L.misc(cs_layernorm_launch(p.x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, p.u, st), "ln2"); L.end();
       L.gemm(gp(p.u, C, E.W1, C, Mc, F, C, E.b1, p.r1, F), CS_EPI_BIAS_GELU_BF16);
       {
         CsGemmParams g = gp(p.r1, F, E.W2, F, Mc, C, F, E.b2, p.x, C);
@@ -481,7 +481,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
         L.gemm(g, CS_EPI_RESID_F32);
       }
     }
-    L.begin(2, 0);
+    L.begin(32, 0);
     L.misc(cs_final_ln_split_launch(p.x, ic, i0, p.Np, C, N, h->lnfg, h->lnfb, 1e-6f, h->pe_tab, p.xq, p.q_bf, p.mem_bf, st), "final_ln");
     L.end();
     if (L.rc) return L.rc;
@@ -503,7 +503,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
       CsGemmParams g = gp(p.dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, p.y, C);
       g.resid = c.do_short_cut ? p.xq : nullptr; g.ldr = C;
       L.gemm(g, CS_EPI_RESID_F32);
-      L.begin(2, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n1g, D.n1b, 1e-5f, p.xq, p.q_bf, st), "norm1"); L.end();
+      L.begin(32, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n1g, D.n1b, 1e-5f, p.xq, p.q_bf, st), "norm1"); L.end();
     }
     L.gemm(gp(p.q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, p.dq, C), CS_EPI_BIAS_BF16);
     CsAttnParams a{};
@@ -515,21 +515,21 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
     a.lse = want_w ? p.lse : nullptr;
     L.attn(a, dec_dh, B);
     if (want_w && !L.rc) {
-      L.begin(2, 0); L.misc(cs_attn_weights_launch(&a, dec_dh, B, head_id, attn_out, st), "attn_weights"); L.end();
+      L.begin(32, 0); L.misc(cs_attn_weights_launch(&a, dec_dh, B, head_id, attn_out, st), "attn_weights"); L.end();
     }
     {
       CsGemmParams g = gp(p.dob, C, D.ca_Wo, C, M, C, C, D.ca_bo, p.y, C);
       g.resid = c.do_short_cut ? p.xq : nullptr; g.ldr = C;
       L.gemm(g, CS_EPI_RESID_F32);
     }
-    L.begin(2, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n2g, D.n2b, 1e-5f, p.xq, p.q_bf, st), "norm2"); L.end();
+    L.begin(32, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n2g, D.n2b, 1e-5f, p.xq, p.q_bf, st), "norm2"); L.end();
     L.gemm(gp(p.q_bf, C, D.l1W, C, M, C, C, D.l1b, p.dhid, C), CS_EPI_BIAS_RELU_BF16);
     {
       CsGemmParams g = gp(p.dhid, C, D.l2W, C, M, C, C, D.l2b, p.y, C);
       g.resid = p.xq; g.ldr = C;
       L.gemm(g, CS_EPI_RESID_F32);
     }
-    L.begin(2, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n3g, D.n3b, 1e-5f, p.xq, p.q_bf, st), "norm3"); L.end();
+    L.begin(32, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n3g, D.n3b, 1e-5f, p.xq, p.q_bf, st), "norm3"); L.end();
   }
   // ================= head + RegressionLayer + jigsaw (cross_reference.py:45-50,82-87) =================
   L.gemm(gp(p.q_bf, C, h->Wh0, C, M, C, C, h->bh0, p.dhid, C), CS_EPI_BIAS_LEAKY_BF16);
@@ -539,7 +539,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
     L.gemm(g, CS_EPI_HEAD_SCORE);
   }
   if (mean_out && !L.rc) {
-    L.begin(2, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();
+    L.begin(32, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();
   }
   return L.rc;
 }

@@ -78,7 +78,8 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
 size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
 
 /* Per-kernel-family timing with HIP events on the launch stream (for bench.py's roofline object).
- * Families: 0 gemm, 1 attention, 2 layernorm/elementwise.  Enabling inserts two events per launch. */
+ * Families = kernel symbols: 0..6 cs_gemm_kernel<epilogue>, 16 + dh/16 cs_attn_kernel<dh>, 32 everything else
+ * (LayerNorm, im2col, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */
 int cs_profile_enable(cs_handle h, int on);
 int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, double* flops);
 

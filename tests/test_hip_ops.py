@@ -192,7 +192,7 @@ def test_attention_exact_layout():
     V = torch.arange(Lk * dh, device=DEV).float().view(1, Lk, dh) % 251 - 125  # exact in bf16
     O = hh.attention(_bf(Q), _bf(K), _bf(V), heads, dh)
     torch.cuda.synchronize()
-    assert torch.equal(O.float()[0], V[0][sel])
+    assert (O.float()[0] - V[0][sel]).abs().max() < 1e-20  # exact up to the e^-64 tails of the other keys
 
 
 def test_attention_forces_rescale_branch():
@@ -267,7 +267,7 @@ def test_pos_bicubic(G, gh, gw):
     out = hh.pos_bicubic(pos, G, gh, gw)
     ref = torch.cat([pos[:1].cpu(), orc.bicubic_resize_grid(pos[1:].cpu().reshape(G, G, Cc), gh, gw).reshape(gh * gw, Cc)])
     torch.cuda.synchronize()
-    assert (out.cpu() - ref).abs().max() < 1e-5
+    assert (out.cpu() - ref).abs().max() < 3e-5  # fp32, different summation order of the 16 taps
 
 
 @pytest.mark.parametrize("gh,gw", [(37, 37), (5, 6), (74, 74), (37, 49)])
@@ -278,4 +278,4 @@ def test_pe_bilinear(gh, gw):
     out = hh.pe_bilinear(pe, gh, gw)
     ref = orc.bilinear_resize_grid_align_corners(pe.cpu(), gh, gw).reshape(gh * gw, Cc)
     torch.cuda.synchronize()
-    assert (out.cpu() - ref).abs().max() < 1e-5
+    assert (out.cpu() - ref).abs().max() < 3e-5
