@@ -90,6 +90,10 @@ struct cs_model {
   float *pos_tab = nullptr, *pe_tab = nullptr; bool pos_tab_owned = false;
   // workspace
   char* ws = nullptr; size_t ws_bytes = 0;
+  // lanes: internal streams that run independent image chunks / batch groups concurrently (forked from and joined to
+  // the caller's stream with events), so one kernel's tail and the memory-bound stages overlap another's MFMA work
+  hipStream_t lane_st[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -142,10 +146,10 @@ struct Arena {  // carve 256-byte aligned pieces out of the workspace
 };
 
 struct Plan {
-  int B, N, H, W, gh, gw, Np, T, I, Ic, C;
+  int B, N, H, W, gh, gw, Np, T, I, Ic, C, lanes;
   size_t total;
-  // encoder chunk
-  float* x; bf16_t* u; bf16_t* r1;
+  // encoder chunk buffers, one set per lane
+  float* x[2]; bf16_t* u[2]; bf16_t* r1[2];
   // decoder
   float *xq, *y, *lse; bf16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
 };
@@ -155,15 +159,19 @@ Plan make_plan(const cs_model* m, int B, int N, int H, int W, char* base) {
   const cs_config& c = m->cfg;
   p.B = B; p.N = N; p.H = H; p.W = W; p.C = c.hidden;
   p.gh = H / c.patch; p.gw = W / c.patch; p.Np = p.gh * p.gw; p.T = p.Np + 1; p.I = B * (1 + N);
-  int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 64 : 32);
-  // keep chunks balanced: same number of passes, near-equal sizes
-  const int passes = (p.I + ic - 1) / ic;
+  p.lanes = (c.lanes == 1 || m->prof) ? 1 : 2;  // per-kernel profiling times kernels in isolation: one lane
+  int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 32 : 16);
+  // balanced chunks: a multiple of the lane count, near-equal sizes
+  int passes = (p.I + ic - 1) / ic;
+  if (p.I >= p.lanes) passes = ((passes + p.lanes - 1) / p.lanes) * p.lanes;
   p.Ic = (p.I + passes - 1) / passes;
   const size_t C = c.hidden, Mc = (size_t)p.Ic * p.T, M = (size_t)B * p.Np, Mk = (size_t)B * N * p.Np;
   Arena a{base};
-  p.x = a.take<float>(Mc * C);
-  p.u = a.take<bf16_t>(Mc * C);
-  p.r1 = a.take<bf16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * 3 * C, (size_t)p.Ic * p.Np * m->Kp)));
+  for (int l = 0; l < 2; ++l) {  // always two sets, so the workspace size does not depend on the profiling mode
+    p.x[l] = a.take<float>(Mc * C);
+    p.u[l] = a.take<bf16_t>(Mc * C);
+    p.r1[l] = a.take<bf16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * 3 * C, (size_t)p.Ic * p.Np * m->Kp)));
+  }
   p.xq = a.take<float>(M * C);
   p.y = a.take<float>(M * C);
   p.q_bf = a.take<bf16_t>(M * C);
@@ -279,6 +287,8 @@ void cs_destroy(cs_handle h) {
   if (h->pos_tab && h->pos_tab_owned) hipFree(h->pos_tab);
   if (h->pe_tab && h->pe_tab != h->pe) hipFree(h->pe_tab);
   if (h->ws) hipFree(h->ws);
+  for (int l = 0; l < 2; ++l) { if (h->lane_st[l]) hipStreamDestroy(h->lane_st[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   delete h;
 }
@@ -440,105 +450,164 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
   Plan p = make_plan(h, B, N, H, W, h->ws);
   if ((long long)B * N * p.Np * 2 * C * c.dec_layers >= (1ll << 31)) return fail(CS_ERR_UNSUPPORTED, "batch too large for 32-bit offsets; split the batch");
   if (int r = ensure_tables(h, p.gh, p.gw, H == W, st)) return r;
-  Launcher L{h, st};
   const int enc_dh = C / c.enc_heads, dec_dh = C / c.dec_heads;
   const int F = c.mlp_ratio * C;
   const float LOG2E = 1.4426950408889634f;
+  const int KV = 2 * C * c.dec_layers;
 
-  // ================= encoder (Dinov2Model.forward, HF:451-477), Ic images per pass =================
-  for (int i0 = 0; i0 < p.I; i0 += p.Ic) {
-    const int ic = std::min(p.Ic, p.I - i0);
+  // ---- lanes: fork from the caller's stream, join back before returning (everything stays stream-ordered on `st`) ----
+  const int NL = p.lanes;
+  hipStream_t lst[2] = {st, st};
+  if (NL == 2) {
+    for (int l = 0; l < 2; ++l) {
+      if (!h->lane_st[l]) HIPCHK(hipStreamCreateWithFlags(&h->lane_st[l], hipStreamNonBlocking));
+      if (!h->ev_join[l]) HIPCHK(hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming));
+      lst[l] = h->lane_st[l];
+    }
+    if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  }
+  auto fork = [&]() -> int {
+    if (NL == 1) return 0;
+    HIPCHK(hipEventRecord(h->ev_fork, st));
+    for (int l = 0; l < 2; ++l) HIPCHK(hipStreamWaitEvent(lst[l], h->ev_fork, 0));
+    return 0;
+  };
+  auto join = [&]() -> int {
+    if (NL == 1) return 0;
+    for (int l = 0; l < 2; ++l) {
+      HIPCHK(hipEventRecord(h->ev_join[l], lst[l]));
+      HIPCHK(hipStreamWaitEvent(st, h->ev_join[l], 0));
+    }
+    return 0;
+  };
+
+  // ================= encoder (Dinov2Model.forward, HF:451-477): image chunks, alternating lanes =================
+  auto enc_chunk = [&](Launcher& L, int slot, int i0, int ic) {
+    hipStream_t s = L.st;
+    float* x = p.x[slot]; bf16_t* u = p.u[slot]; bf16_t* r1 = p.r1[slot];
     const int Mc = ic * p.T;
-    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N, i0, p.r1, ic, H, W, P, h->Kp, st), "im2col"); L.end();
-    L.begin(32, 0); L.misc(cs_cls_rows_launch(p.x, ic, p.T, C, h->cls, h->pos_tab, st), "cls"); L.end();
+    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N, i0, r1, ic, H, W, P, h->Kp, s), "im2col"); L.end();
+    L.begin(32, 0); L.misc(cs_cls_rows_launch(x, ic, p.T, C, h->cls, h->pos_tab, s), "cls"); L.end();
     {
-      CsGemmParams g = gp(p.r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, p.x, C);
+      CsGemmParams g = gp(r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, x, C);
       g.pos = h->pos_tab; g.Np = p.Np;
       L.gemm(g, CS_EPI_PATCH_F32, 3.0 * P * P);
     }
     for (int l = 0; l < c.enc_layers; ++l) {
       const EncLayer& E = h->enc[l];
-      L.begin(32, 0); L.misc(cs_layernorm_launch(p.x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, p.u, st), "ln1"); L.end();
-      L.gemm(gp(p.u, C, E.Wqkv, C, Mc, 3 * C, C, E.bqkv, p.r1, 3 * C), CS_EPI_BIAS_BF16);
+      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, u, s), "ln1"); L.end();
+      L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.bqkv, r1, 3 * C), CS_EPI_BIAS_BF16);
       {
         CsAttnParams a{};
-        a.Q = p.r1; a.K = p.r1 + C; a.V = p.r1 + 2 * C; a.O = p.u;
+        a.Q = r1; a.K = r1 + C; a.V = r1 + 2 * C; a.O = u;
         a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
         a.q_bs = a.k_bs = a.v_bs = (long long)p.T * 3 * C; a.o_bs = (long long)p.T * C;
         a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = LOG2E / std::sqrt((float)enc_dh); a.lse = nullptr;
         L.attn(a, enc_dh, ic);
       }
       {
-        CsGemmParams g = gp(p.u, C, E.Wo, C, Mc, C, C, E.bo, p.x, C);
-        g.scale = E.ls1; g.resid = p.x; g.ldr = C;
+        CsGemmParams g = gp(u, C, E.Wo, C, Mc, C, C, E.bo, x, C);
+        g.scale = E.ls1; g.resid = x; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
-      L.begin(32, 0); L.misc(cs_layernorm_launch(p.x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, p.u, st), "ln2"); L.end();
-      L.gemm(gp(p.u, C, E.W1, C, Mc, F, C, E.b1, p.r1, F), CS_EPI_BIAS_GELU_BF16);
+      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, u, s), "ln2"); L.end();
+      L.gemm(gp(u, C, E.W1, C, Mc, F, C, E.b1, r1, F), CS_EPI_BIAS_GELU_BF16);
       {
-        CsGemmParams g = gp(p.r1, F, E.W2, F, Mc, C, F, E.b2, p.x, C);
-        g.scale = E.ls2; g.resid = p.x; g.ldr = C;
+        CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);
+        g.scale = E.ls2; g.resid = x; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
     }
     L.begin(32, 0);
-    L.misc(cs_final_ln_split_launch(p.x, ic, i0, p.Np, C, N, h->lnfg, h->lnfb, 1e-6f, h->pe_tab, p.xq, p.q_bf, p.mem_bf, st), "final_ln");
+    L.misc(cs_final_ln_split_launch(x, ic, i0, p.Np, C, N, h->lnfg, h->lnfb, 1e-6f, h->pe_tab, p.xq, p.q_bf, p.mem_bf, s), "final_ln");
     L.end();
-    if (L.rc) return L.rc;
-  }
+  };
 
-  // ================= decoder (transformer.py:213-268, post-norm layers :157-173) =================
-  const int M = B * p.Np, Mk = B * N * p.Np, KV = 2 * C * c.dec_layers;
-  L.gemm(gp(p.mem_bf, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, p.kv, KV), CS_EPI_BIAS_BF16);
-  for (int l = 0; l < c.dec_layers; ++l) {
-    const DecLayer& D = h->dec[l];
-    if (c.do_self_attn) {
-      L.gemm(gp(p.q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, p.dqkv, 3 * C), CS_EPI_BIAS_BF16);
+  // ================= decoder (transformer.py:213-268, post-norm layers :157-173) + head, batch items [b0, b0+nb) =================
+  auto dec_group = [&](Launcher& L, int b0, int nb) {
+    hipStream_t s = L.st;
+    const int M = nb * p.Np, Mk = nb * N * p.Np;
+    const size_t ro = (size_t)b0 * p.Np;          // first query row of the group
+    const size_t ko = (size_t)b0 * N * p.Np;      // first memory row of the group
+    float* xq = p.xq + ro * C; float* y = p.y + ro * C; bf16_t* q_bf = p.q_bf + ro * C;
+    bf16_t* mem = p.mem_bf + ko * C; bf16_t* kv = p.kv + ko * KV;
+    bf16_t* dqkv = p.dqkv + ro * 3 * C; bf16_t* dq = p.dq + ro * C; bf16_t* dob = p.dob + ro * C; bf16_t* dhid = p.dhid + ro * C;
+    float* lse = p.lse + (size_t)b0 * c.dec_heads * p.Np;
+    L.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_BF16);
+    for (int l = 0; l < c.dec_layers; ++l) {
+      const DecLayer& D = h->dec[l];
+      if (c.do_self_attn) {
+        L.gemm(gp(q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_BF16);
+        CsAttnParams a{};
+        a.Q = dqkv; a.K = dqkv + C; a.V = dqkv + 2 * C; a.O = dob;
+        a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+        a.q_bs = a.k_bs = a.v_bs = (long long)p.Np * 3 * C; a.o_bs = (long long)p.Np * C;
+        a.Lq = a.Lk = p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
+        L.attn(a, dec_dh, nb);
+        CsGemmParams g = gp(dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, y, C);
+        g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
+        L.gemm(g, CS_EPI_RESID_F32);
+        L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n1g, D.n1b, 1e-5f, xq, q_bf, s), "norm1"); L.end();
+      }
+      L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_BF16);
       CsAttnParams a{};
-      a.Q = p.dqkv; a.K = p.dqkv + C; a.V = p.dqkv + 2 * C; a.O = p.dob;
-      a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
-      a.q_bs = a.k_bs = a.v_bs = (long long)p.Np * 3 * C; a.o_bs = (long long)p.Np * C;
-      a.Lq = a.Lk = p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
-      L.attn(a, dec_dh, B);
-      CsGemmParams g = gp(p.dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, p.y, C);
-      g.resid = c.do_short_cut ? p.xq : nullptr; g.ldr = C;
-      L.gemm(g, CS_EPI_RESID_F32);
-      L.begin(32, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n1g, D.n1b, 1e-5f, p.xq, p.q_bf, st), "norm1"); L.end();
+      a.Q = dq; a.K = kv + (size_t)l * 2 * C; a.V = kv + (size_t)l * 2 * C + C; a.O = dob;
+      a.ldq = C; a.ldk = a.ldv = KV; a.ldo = C;
+      a.q_bs = (long long)p.Np * C; a.k_bs = a.v_bs = (long long)N * p.Np * KV; a.o_bs = (long long)p.Np * C;
+      a.Lq = p.Np; a.Lk = N * p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
+      const bool want_w = attn_out && l == c.dec_layers - 1;  // only the last layer's weights are returned (transformer.py:266-268)
+      a.lse = want_w ? lse : nullptr;
+      L.attn(a, dec_dh, nb);
+      if (want_w && !L.rc) {
+        L.begin(32, 0);
+        L.misc(cs_attn_weights_launch(&a, dec_dh, nb, head_id, attn_out + (size_t)b0 * p.Np * N * p.Np, s), "attn_weights");
+        L.end();
+      }
+      {
+        CsGemmParams g = gp(dob, C, D.ca_Wo, C, M, C, C, D.ca_bo, y, C);
+        g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
+        L.gemm(g, CS_EPI_RESID_F32);
+      }
+      L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n2g, D.n2b, 1e-5f, xq, q_bf, s), "norm2"); L.end();
+      L.gemm(gp(q_bf, C, D.l1W, C, M, C, C, D.l1b, dhid, C), CS_EPI_BIAS_RELU_BF16);
+      {
+        CsGemmParams g = gp(dhid, C, D.l2W, C, M, C, C, D.l2b, y, C);
+        g.resid = xq; g.ldr = C;
+        L.gemm(g, CS_EPI_RESID_F32);
+      }
+      L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n3g, D.n3b, 1e-5f, xq, q_bf, s), "norm3"); L.end();
     }
-    L.gemm(gp(p.q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, p.dq, C), CS_EPI_BIAS_BF16);
-    CsAttnParams a{};
-    a.Q = p.dq; a.K = p.kv + (size_t)l * 2 * C; a.V = p.kv + (size_t)l * 2 * C + C; a.O = p.dob;
-    a.ldq = C; a.ldk = a.ldv = KV; a.ldo = C;
-    a.q_bs = (long long)p.Np * C; a.k_bs = a.v_bs = (long long)N * p.Np * KV; a.o_bs = (long long)p.Np * C;
-    a.Lq = p.Np; a.Lk = N * p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
-    const bool want_w = attn_out && l == c.dec_layers - 1;  // only the last layer's weights are returned (transformer.py:266-268)
-    a.lse = want_w ? p.lse : nullptr;
-    L.attn(a, dec_dh, B);
-    if (want_w && !L.rc) {
-      L.begin(32, 0); L.misc(cs_attn_weights_launch(&a, dec_dh, B, head_id, attn_out, st), "attn_weights"); L.end();
-    }
+    // head + RegressionLayer + jigsaw (cross_reference.py:45-50,82-87)
+    L.gemm(gp(q_bf, C, h->Wh0, C, M, C, C, h->bh0, dhid, C), CS_EPI_BIAS_LEAKY_BF16);
     {
-      CsGemmParams g = gp(p.dob, C, D.ca_Wo, C, M, C, C, D.ca_bo, p.y, C);
-      g.resid = c.do_short_cut ? p.xq : nullptr; g.ldr = C;
-      L.gemm(g, CS_EPI_RESID_F32);
+      CsGemmParams g = gp(dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4);
+      g.Np = p.Np; g.gw = p.gw; g.P = P; g.act = c.act; g.powp = c.pow_p;
+      L.gemm(g, CS_EPI_HEAD_SCORE);
     }
-    L.begin(32, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n2g, D.n2b, 1e-5f, p.xq, p.q_bf, st), "norm2"); L.end();
-    L.gemm(gp(p.q_bf, C, D.l1W, C, M, C, C, D.l1b, p.dhid, C), CS_EPI_BIAS_RELU_BF16);
-    {
-      CsGemmParams g = gp(p.dhid, C, D.l2W, C, M, C, C, D.l2b, p.y, C);
-      g.resid = p.xq; g.ldr = C;
-      L.gemm(g, CS_EPI_RESID_F32);
-    }
-    L.begin(32, 0); L.misc(cs_layernorm_launch(p.y, M, C, D.n3g, D.n3b, 1e-5f, p.xq, p.q_bf, st), "norm3"); L.end();
-  }
-  // ================= head + RegressionLayer + jigsaw (cross_reference.py:45-50,82-87) =================
-  L.gemm(gp(p.q_bf, C, h->Wh0, C, M, C, C, h->bh0, p.dhid, C), CS_EPI_BIAS_LEAKY_BF16);
+  };
+
+  Launcher LL[2] = {Launcher{h, lst[0]}, Launcher{h, lst[1]}};
+  if (int r = fork()) return r;
   {
-    CsGemmParams g = gp(p.dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out, 4);
-    g.Np = p.Np; g.gw = p.gw; g.P = P; g.act = c.act; g.powp = c.pow_p;
-    L.gemm(g, CS_EPI_HEAD_SCORE);
+    int chunk = 0;
+    for (int i0 = 0; i0 < p.I; i0 += p.Ic, ++chunk) enc_chunk(LL[chunk % NL], chunk % NL, i0, std::min(p.Ic, p.I - i0));
   }
-  if (mean_out && !L.rc) {
+  if (int r = join()) return r;   // every image's tokens are in place before any decoder group starts
+  if (LL[0].rc) return LL[0].rc;
+  if (LL[1].rc) return LL[1].rc;
+  if (int r = fork()) return r;
+  if (NL == 2 && B >= 2) {
+    const int b_half = (B + 1) / 2;
+    dec_group(LL[0], 0, b_half);
+    dec_group(LL[1], b_half, B - b_half);
+  } else {
+    dec_group(LL[0], 0, B);
+  }
+  if (int r = join()) return r;
+  if (LL[0].rc) return LL[0].rc;
+  if (LL[1].rc) return LL[1].rc;
+  Launcher L{h, st};
+  if (mean_out) {
     L.begin(32, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();
   }
   return L.rc;

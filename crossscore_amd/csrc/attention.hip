@@ -42,9 +42,16 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31;   // MFMA row/col index inside a 32-tile
   const int hh = lane >> 5;  // lane half
-  const int head = blockIdx.y;
-  const int bat = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wv * 32;
+  // XCD-aware 1-D grid: the QB query blocks of one (batch, head) re-read the same K/V, so they are placed on one XCD
+  // (blocks b, b+8, .. share an XCD under round-robin dispatch; speed only): group g = gi*8 + (b%8), j = b/8 = gi*QB + qb.
+  const int QB = (p.Lq + 127) / 128;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int gi = jj / QB, qb = jj - gi * QB;
+  const int grp = gi * 8 + xcd;
+  if (grp >= p.heads * p.nbatch) return;  // whole block exits together (before any barrier)
+  const int head = grp % p.heads;
+  const int bat = grp / p.heads;
+  const int q0 = qb * 128 + wv * 32;
 
   const bf16_t* Qb = p.Q + (size_t)bat * p.q_bs + head * DH;
   const bf16_t* Kb = p.K + (size_t)bat * p.k_bs + head * DH;
@@ -210,8 +217,10 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
 }
 
 template <int DH>
-hipError_t launch(const CsAttnParams& p, int batch, hipStream_t stream) {
-  dim3 grid((p.Lq + 127) / 128, p.heads, batch);
+hipError_t launch(CsAttnParams p, int batch, hipStream_t stream) {
+  p.nbatch = batch;
+  const int groups = p.heads * batch;
+  dim3 grid(((groups + 7) / 8) * 8 * ((p.Lq + 127) / 128));
   const int lds = 2 * AttnCfg<DH>::STAGE + 64;  // +64: the last rows' transposed reads of a padded d tile may run past the image
   hipLaunchKernelGGL(cs_attn_kernel<DH>, grid, dim3(256), lds, stream, p);
   return hipGetLastError();
@@ -222,7 +231,7 @@ hipError_t launch(const CsAttnParams& p, int batch, hipStream_t stream) {
 extern "C" const char* cs_attn_check(const CsAttnParams* p, int dh, int batch) {
   if (dh != 16 && dh != 48 && dh != 64 && dh != 96) return "attention: head dim must be 16, 48, 64 or 96";
   if (p->Lq <= 0 || p->Lk <= 0 || p->heads <= 0 || batch <= 0) return "attention: empty shape";
-  if (batch > 65535 || p->heads > 65535) return "attention: grid too large";
+  if ((long long)batch * p->heads * ((p->Lq + 127) / 128) > (1ll << 30)) return "attention: grid too large";
   if (p->ldq % 8 || p->ldk % 8 || p->ldv % 8 || p->ldo % 4) return "attention: row strides must keep 16-byte rows";
   if (p->q_bs % 8 || p->k_bs % 8 || p->v_bs % 8 || p->o_bs % 4) return "attention: batch strides must keep 16-byte rows";
   if (!p->Q || !p->K || !p->V || !p->O) return "attention: null operand";

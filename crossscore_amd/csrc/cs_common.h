@@ -66,6 +66,7 @@ struct CsGemmParams {
   int P;              // patch size (head)
   int act;            // 0 sigmoid, 1 tanh
   float powp;         // 1 -> identity
+  int ablate;         // debug timing builds only (CS_ABLATE); 0 in the product
 };
 
 struct CsAttnParams {
@@ -73,6 +74,7 @@ struct CsAttnParams {
   int ldq, ldk, ldv, ldo;                              // row strides (elements)
   long long q_bs, k_bs, v_bs, o_bs;                    // batch strides (elements)
   int Lq, Lk, heads;
+  int nbatch;                                          // filled by the launcher
   float scale_log2e;                                   // (1/sqrt(dh)) * log2(e)
   float* lse;                                          // optional [batch][heads][Lq]: m*ln2-scaled log-sum-exp (base 2)
 };
