@@ -56,6 +56,22 @@ def kernel_table(net):
     return rows
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (FETCH_SIZE x2-corrected + WRITE_SIZE,
+    separate --pmc passes, tools/summarise_prof.py); None when no summary is committed."""
+    path = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tab = json.load(open(path))
+    if kernel_name.startswith("cs_gemm_kernel<"):
+        epi = GEMM_EPI.index(kernel_name[len("cs_gemm_kernel<"):-1])
+        keys = [k for k in tab if k.startswith(f"cs_gemm_kernel<{epi},")]
+    else:
+        keys = [k for k in tab if k == kernel_name]
+    n = sum(tab[k]["launches"] for k in keys)
+    return (sum(tab[k]["hbm_bytes_per_launch"] * tab[k]["launches"] for k in keys) / n) if n else None
+
+
 def cpu_baseline(arch, sd, H, W, N, hip_score_item0, seed, max_seconds=40.0):
     """Oracle (CPU fp32 restatement = 'port') timed on the host cores on a bounded sample of the same workload:
     B=1 items of the benchmark batch, 1 untimed warm-up + timed repeats while under ~max_seconds."""
@@ -148,7 +164,7 @@ def main():
             "whole_path": {"achieved_tflops": value * flops_q / 1e12 / world, "peak_tflops": PEAK_BF16_TFLOPS,
                            "frac": value * flops_q / 1e12 / world / PEAK_BF16_TFLOPS},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom["kernel"]),
                          "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
                          "flop_per_launch": dom["flops"] / dom["launches"]},
             "kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in x.items() if k != "flops"} for x in rows],
