@@ -96,6 +96,47 @@ def cpu_baseline(arch, sd, H, W, N, hip_score_item0, seed, max_seconds=40.0):
                 sample=f"{n} timed + 1 warm-up forward(s) of batch item 0 (B=1, {N} refs, {H}x{W}), fp32 oracle"), mae
 
 
+def eager_baseline(arch, sd, tq, tr, dev, steps=3):
+    """The 'PyTorch-ROCm eager reference' of the north-star target: the same fp32 restatement (plain torch ops, i.e. what the
+    reference's nn.Linear / SDPA-free attention / LayerNorm sequence executes) run on the GPU, in fp32 and under bf16 autocast
+    (mirrors trainer.precision=16-mixed).  Reported next to `value`; never part of it."""
+    from oracle import crossscore_oracle as orc
+
+    Wt = {k: v.to(dev) for k, v in orc.to_torch(sd).items()}
+    cfg = dict(enc_heads=arch.enc_heads)
+    out = {}
+
+    def sdpa_attention(q, k, v, heads, rnd, need_weights=False):
+        # what the reference actually executes on a GPU: F.scaled_dot_product_attention (HF sdpa attention and the
+        # need_weights=False branch of nn.MultiheadAttention, torch functional.py:6613-6642)
+        B, Lq, C = q.shape
+        dh = C // heads
+        qh, kh, vh = (t.view(B, -1, heads, dh).transpose(1, 2) for t in (q, k, v))
+        o = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh)
+        return o.transpose(1, 2).reshape(B, Lq, C), None
+
+    explicit_attention = orc.attention
+    variants = (("fp32", torch.autocast("cuda", enabled=False), explicit_attention),
+                ("bf16_autocast", torch.autocast("cuda", dtype=torch.bfloat16), explicit_attention),
+                ("fp32_sdpa", torch.autocast("cuda", enabled=False), sdpa_attention),
+                ("bf16_autocast_sdpa", torch.autocast("cuda", dtype=torch.bfloat16), sdpa_attention))
+    for name, ctx, attn_fn in variants:
+        orc.attention = attn_fn
+        try:
+            with torch.no_grad(), ctx:
+                orc.forward(Wt, cfg, tq, tr)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    orc.forward(Wt, cfg, tq, tr)
+                torch.cuda.synchronize(dev)
+            out[name] = dict(value=tq.shape[0] * steps / (time.perf_counter() - t0), unit="query-images/sec", batch=int(tq.shape[0]))
+        except Exception as e:  # e.g. out of memory for the materialised attention at large batch
+            out[name] = dict(error=str(e)[:200])
+    orc.attention = explicit_attention
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +145,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--eager", action="store_true", help="also time the plain-PyTorch (eager, GPU) restatement: fp32 and bf16 autocast")
     args = ap.parse_args()
 
     rank, local_rank, world = parallel.init_from_env()
@@ -177,6 +219,12 @@ def main():
             result["cpu_baseline"] = cb
             result["score_map_mae"] = mae
             result["speedup_vs_cpu_baseline"] = value / cb["value"]
+        if world == 1 and args.eager:
+            eb = eager_baseline(arch, sd, tq, tr, dev)
+            result["eager_baseline"] = eb
+            for k, v in eb.items():
+                if "value" in v:
+                    result[f"speedup_vs_eager_{k}"] = value / v["value"]
     parallel.barrier()
     if rank == 0:
         print(json.dumps(result))

@@ -68,6 +68,7 @@ struct DecLayer {
 };
 
 struct ProfRec { hipEvent_t a, b; int family; double flops; };
+constexpr int CS_MAX_LANES = 4;
 
 }  // namespace
 
@@ -92,8 +93,8 @@ struct cs_model {
   char* ws = nullptr; size_t ws_bytes = 0;
   // lanes: internal streams that run independent image chunks / batch groups concurrently (forked from and joined to
   // the caller's stream with events), so one kernel's tail and the memory-bound stages overlap another's MFMA work
-  hipStream_t lane_st[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  hipStream_t lane_st[CS_MAX_LANES] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[CS_MAX_LANES] = {};
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -149,7 +150,7 @@ struct Plan {
   int B, N, H, W, gh, gw, Np, T, I, Ic, C, lanes;
   size_t total;
   // encoder chunk buffers, one set per lane
-  float* x[2]; bf16_t* u[2]; bf16_t* r1[2];
+  float* x[CS_MAX_LANES]; bf16_t* u[CS_MAX_LANES]; bf16_t* r1[CS_MAX_LANES];
   // decoder
   float *xq, *y, *lse; bf16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
 };
@@ -159,15 +160,16 @@ Plan make_plan(const cs_model* m, int B, int N, int H, int W, char* base) {
   const cs_config& c = m->cfg;
   p.B = B; p.N = N; p.H = H; p.W = W; p.C = c.hidden;
   p.gh = H / c.patch; p.gw = W / c.patch; p.Np = p.gh * p.gw; p.T = p.Np + 1; p.I = B * (1 + N);
-  p.lanes = (c.lanes == 1 || m->prof) ? 1 : 2;  // per-kernel profiling times kernels in isolation: one lane
-  int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 32 : 16);
+  p.lanes = m->prof ? 1 : (c.lanes <= 0 ? 2 : std::min(c.lanes, CS_MAX_LANES));  // profiling times kernels in isolation
+  int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 16 : 8);
   // balanced chunks: a multiple of the lane count, near-equal sizes
   int passes = (p.I + ic - 1) / ic;
   if (p.I >= p.lanes) passes = ((passes + p.lanes - 1) / p.lanes) * p.lanes;
   p.Ic = (p.I + passes - 1) / passes;
   const size_t C = c.hidden, Mc = (size_t)p.Ic * p.T, M = (size_t)B * p.Np, Mk = (size_t)B * N * p.Np;
   Arena a{base};
-  for (int l = 0; l < 2; ++l) {  // always two sets, so the workspace size does not depend on the profiling mode
+  const int nsets = c.lanes <= 0 ? 2 : std::min(c.lanes, CS_MAX_LANES);  // independent of the profiling mode
+  for (int l = 0; l < nsets; ++l) {
     p.x[l] = a.take<float>(Mc * C);
     p.u[l] = a.take<bf16_t>(Mc * C);
     p.r1[l] = a.take<bf16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * 3 * C, (size_t)p.Ic * p.Np * m->Kp)));
@@ -287,7 +289,7 @@ void cs_destroy(cs_handle h) {
   if (h->pos_tab && h->pos_tab_owned) hipFree(h->pos_tab);
   if (h->pe_tab && h->pe_tab != h->pe) hipFree(h->pe_tab);
   if (h->ws) hipFree(h->ws);
-  for (int l = 0; l < 2; ++l) { if (h->lane_st[l]) hipStreamDestroy(h->lane_st[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
+  for (int l = 0; l < CS_MAX_LANES; ++l) { if (h->lane_st[l]) hipStreamDestroy(h->lane_st[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   delete h;
@@ -457,9 +459,9 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
 
   // ---- lanes: fork from the caller's stream, join back before returning (everything stays stream-ordered on `st`) ----
   const int NL = p.lanes;
-  hipStream_t lst[2] = {st, st};
-  if (NL == 2) {
-    for (int l = 0; l < 2; ++l) {
+  hipStream_t lst[CS_MAX_LANES] = {st, st, st, st};
+  if (NL >= 2) {
+    for (int l = 0; l < NL; ++l) {
       if (!h->lane_st[l]) HIPCHK(hipStreamCreateWithFlags(&h->lane_st[l], hipStreamNonBlocking));
       if (!h->ev_join[l]) HIPCHK(hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming));
       lst[l] = h->lane_st[l];
@@ -469,12 +471,12 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
   auto fork = [&]() -> int {
     if (NL == 1) return 0;
     HIPCHK(hipEventRecord(h->ev_fork, st));
-    for (int l = 0; l < 2; ++l) HIPCHK(hipStreamWaitEvent(lst[l], h->ev_fork, 0));
+    for (int l = 0; l < NL; ++l) HIPCHK(hipStreamWaitEvent(lst[l], h->ev_fork, 0));
     return 0;
   };
   auto join = [&]() -> int {
     if (NL == 1) return 0;
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NL; ++l) {
       HIPCHK(hipEventRecord(h->ev_join[l], lst[l]));
       HIPCHK(hipStreamWaitEvent(st, h->ev_join[l], 0));
     }
@@ -586,26 +588,25 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
     }
   };
 
-  Launcher LL[2] = {Launcher{h, lst[0]}, Launcher{h, lst[1]}};
+  Launcher LL[CS_MAX_LANES] = {Launcher{h, lst[0]}, Launcher{h, lst[1]}, Launcher{h, lst[2]}, Launcher{h, lst[3]}};
+  auto lanes_rc = [&]() { for (int l = 0; l < CS_MAX_LANES; ++l) if (LL[l].rc) return LL[l].rc; return 0; };
   if (int r = fork()) return r;
   {
     int chunk = 0;
     for (int i0 = 0; i0 < p.I; i0 += p.Ic, ++chunk) enc_chunk(LL[chunk % NL], chunk % NL, i0, std::min(p.Ic, p.I - i0));
   }
   if (int r = join()) return r;   // every image's tokens are in place before any decoder group starts
-  if (LL[0].rc) return LL[0].rc;
-  if (LL[1].rc) return LL[1].rc;
+  if (int r = lanes_rc()) return r;
   if (int r = fork()) return r;
-  if (NL == 2 && B >= 2) {
-    const int b_half = (B + 1) / 2;
-    dec_group(LL[0], 0, b_half);
-    dec_group(LL[1], b_half, B - b_half);
-  } else {
-    dec_group(LL[0], 0, B);
+  {
+    const int groups = std::min(NL, B);
+    for (int g = 0; g < groups; ++g) {
+      const int b0 = (int)((long long)B * g / groups), b1 = (int)((long long)B * (g + 1) / groups);
+      dec_group(LL[g], b0, b1 - b0);
+    }
   }
   if (int r = join()) return r;
-  if (LL[0].rc) return LL[0].rc;
-  if (LL[1].rc) return LL[1].rc;
+  if (int r = lanes_rc()) return r;
   Launcher L{h, st};
   if (mean_out) {
     L.begin(32, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();

@@ -67,6 +67,8 @@ struct CsGemmParams {
   int act;            // 0 sigmoid, 1 tanh
   float powp;         // 1 -> identity
   int ablate;         // debug timing builds only (CS_ABLATE); 0 in the product
+  int stagger_ticks;  // start delay (100 MHz ticks) of every other resident block; 0 = none
+  int stagger_mode;   // 0: second half of the slots, 1: odd slots
 };
 
 struct CsAttnParams {

@@ -27,7 +27,12 @@ constexpr int A_BYTES = BM * BK * 2;  // 8 KiB per stage
 template <int NSUB> struct GemmCfg {
   static constexpr int BN = 64 * NSUB;
   static constexpr int STAGE_BYTES = (BM + BN) * BK * 2;           // 24 / 20 / 16 KiB
+#ifdef CS_NS_OVERRIDE
+  static constexpr int NS = CS_NS_OVERRIDE;
+#else
   static constexpr int NS = NSUB == 4 ? 2 : 3;                     // ring slots: 48 / 60 / 48 KiB of LDS
+#endif
+  static constexpr int BLOCKS_PER_CU = 2;
   static constexpr int D = NS - 1;                                 // K slices kept in flight
   static constexpr int WL = NSUB;                                  // W LDS-DMA instructions per wave per slice
   static constexpr int LPS = 2 + WL;                               // LDS-DMA instructions per wave per slice
@@ -76,7 +81,7 @@ __device__ __noinline__ float head_activation(float v, int act, float powp) {
 // (one wave of each per SIMD): with K of only 384-1536 the epilogue (activation, transpose, stores) costs as much issue
 // time as the K loop, and it can only hide under MFMAs that belong to ANOTHER block in a different phase.
 template <int EPI, int NSUB>
-__global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
+__global__ __launch_bounds__(256, GemmCfg<NSUB>::BLOCKS_PER_CU) void cs_gemm_kernel(CsGemmParams p) {
   using Cfg = GemmCfg<NSUB>;
   constexpr int BN = Cfg::BN, NS = Cfg::NS, D = Cfg::D, LPS = Cfg::LPS, STAGE_BYTES = Cfg::STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,6 +135,17 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
       __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.W + offW[j] + kt * BK), CS_LDS_PTR(base + A_BYTES + (j * 4 + wv) * 1024), 16, 0, 0);
   };
 
+  // stagger: blocks that share a CU run the same program on equal tiles and would stay in phase (all in the K loop, then
+  // all in the epilogue); delaying every other resident block once desynchronises them so one block's epilogue
+  // (VALU/LDS/stores) runs under the other's MFMAs
+  if (p.stagger_ticks > 0) {
+    const bool late = p.stagger_mode == 0 ? (slot >= (slots >> 1)) : (slot & 1);
+    if (late) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+
   // load cursor (runs D slices ahead of the compute cursor, across tile boundaries)
   int issued = 0, l_idx = slot, l_kt = 0, l_ring = 0;
   if (total > 0) {
@@ -169,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
       // slice `it` must have landed: all but the `ahead` younger slices of this wave's LDS-DMA queue are done
       const int ahead = min(total - 1 - it, D - 1);
       if (ahead >= D - 1) CS_VMCNT((D - 1) * LPS);
+      else if (D > 3 && ahead == 2) CS_VMCNT(2 * LPS);
       else if (D > 2 && ahead == 1) CS_VMCNT(1 * LPS);
       else CS_VMCNT(0);
       __builtin_amdgcn_s_barrier();  // every wave's part of slice `it` landed; everyone has left ring slot (it-1)%NS
@@ -339,7 +356,10 @@ hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   // two persistent blocks per CU (LDS and registers admit two); grid is a multiple of 8 so that b%8 labels the XCD group
-  int grid = (2 * g_num_cus / 8) * 8;
+  int grid = (GemmCfg<NSUB>::BLOCKS_PER_CU * g_num_cus / 8) * 8;
+#ifdef CS_ABLATE
+  if (const char* e = getenv("CS_GEMM_GRID")) grid = atoi(e);
+#endif
   const int need = ((tiles_m + 7) / 8) * tiles_n * 8;
   if (grid > need) grid = need;
   if (grid < 8) grid = 8;
@@ -380,6 +400,8 @@ extern "C" hipError_t cs_gemm_launch(const CsGemmParams* p0, int epi, hipStream_
   CsGemmParams pp = *p0;
 #ifdef CS_ABLATE
   if (const char* e = getenv("CS_GEMM_ABLATE")) pp.ablate = atoi(e);
+  if (const char* e = getenv("CS_GEMM_STAGGER")) pp.stagger_ticks = atoi(e);
+  if (const char* e = getenv("CS_GEMM_STAGGER_MODE")) pp.stagger_mode = atoi(e);
 #endif
   const CsGemmParams* p = &pp;
   switch (epi) {

@@ -50,7 +50,7 @@ typedef struct cs_config {
   int act;           /* 0 sigmoid (metric.min == 0), 1 tanh (metric.min == -1), model/regression_layer.py:31-38 */
   float pow_p;       /* exponent after the activation; 1 = identity, model/regression_layer.py:40-62 */
   int enc_chunk_images; /* images per encoder pass (0 = library default) */
-  int lanes;         /* 0/2: two internal streams run independent image chunks / batch groups concurrently; 1: serial */
+  int lanes;         /* internal streams that run independent image chunks / batch groups concurrently: 0 = default (2), 1 = serial, up to 4 */
 } cs_config;
 
 /* Replaces CrossScoreNet.__init__ (task/core.py:27-56). NULL on failure. */

@@ -97,17 +97,17 @@ def bicubic_resize_grid(grid: Tensor, oh: int, ow: int) -> Tensor:
         t = src - i0
         i0 = i0.to(torch.int64)
         w = _cubic_coeffs(t)
-        idx = [torch.clamp(i0 + d, 0, n_in - 1) for d in (-1, 0, 1, 2)]
-        return idx, w
+        idx = [torch.clamp(i0 + d, 0, n_in - 1).to(grid.device) for d in (-1, 0, 1, 2)]
+        return idx, [c.to(grid.device) for c in w]
 
     iy, wy = axis(gh, oh)
     ix, wx = axis(gw, ow)
     # interpolate along x for each needed source row, then along y (same order as aten: for each y tap,
     # x-interpolate, then combine)
-    out = torch.zeros(oh, ow, C, dtype=grid.dtype)
+    out = torch.zeros(oh, ow, C, dtype=grid.dtype, device=grid.device)
     for a in range(4):
         rows = grid[iy[a]]  # (oh,gw,C)
-        acc = torch.zeros(oh, ow, C, dtype=grid.dtype)
+        acc = torch.zeros(oh, ow, C, dtype=grid.dtype, device=grid.device)
         for b in range(4):
             acc = acc + rows[:, ix[b]] * wx[b][None, :, None]
         out = out + acc * wy[a][:, None, None]
@@ -126,7 +126,8 @@ def bilinear_resize_grid_align_corners(grid: Tensor, oh: int, ow: int) -> Tensor
         i0 = src.to(torch.int64)
         i1 = torch.clamp(i0 + 1, max=n_in - 1)
         l1 = src - i0.to(torch.float32)
-        return i0, i1, 1.0 - l1, l1
+        d = grid.device
+        return i0.to(d), i1.to(d), (1.0 - l1).to(d), l1.to(d)
 
     y0, y1, wy0, wy1 = axis(gh, oh)
     x0, x1, wx0, wx1 = axis(gw, ow)
