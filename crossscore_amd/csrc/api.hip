@@ -163,9 +163,13 @@ Plan make_plan(const cs_model* m, int B, int N, int H, int W, char* base) {
   p.lanes = m->prof ? 1 : (c.lanes <= 0 ? 2 : std::min(c.lanes, CS_MAX_LANES));  // profiling times kernels in isolation
   int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 16 : 8);
   // balanced chunks: a multiple of the lane count, near-equal sizes
-  int passes = (p.I + ic - 1) / ic;
-  if (p.I >= p.lanes) passes = ((passes + p.lanes - 1) / p.lanes) * p.lanes;
-  p.Ic = (p.I + passes - 1) / passes;
+  if (c.enc_chunk_images > 0) {
+    p.Ic = std::min(ic, p.I);  // explicit: used verbatim (a shorter remainder chunk runs first)
+  } else {
+    int passes = (p.I + ic - 1) / ic;
+    if (p.I >= p.lanes) passes = ((passes + p.lanes - 1) / p.lanes) * p.lanes;
+    p.Ic = (p.I + passes - 1) / passes;
+  }
   const size_t C = c.hidden, Mc = (size_t)p.Ic * p.T, M = (size_t)B * p.Np, Mk = (size_t)B * N * p.Np;
   Arena a{base};
   const int nsets = c.lanes <= 0 ? 2 : std::min(c.lanes, CS_MAX_LANES);  // independent of the profiling mode
@@ -593,7 +597,11 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
   if (int r = fork()) return r;
   {
     int chunk = 0;
-    for (int i0 = 0; i0 < p.I; i0 += p.Ic, ++chunk) enc_chunk(LL[chunk % NL], chunk % NL, i0, std::min(p.Ic, p.I - i0));
+    // chunk sizes: the short remainder (if any) goes FIRST so that it overlaps the long chunks instead of trailing them
+    const int rem = p.I % p.Ic;
+    int i0 = 0;
+    if (rem) { enc_chunk(LL[chunk % NL], chunk % NL, 0, rem); i0 = rem; ++chunk; }
+    for (; i0 < p.I; i0 += p.Ic, ++chunk) enc_chunk(LL[chunk % NL], chunk % NL, i0, p.Ic);
   }
   if (int r = join()) return r;   // every image's tokens are in place before any decoder group starts
   if (int r = lanes_rc()) return r;

@@ -69,6 +69,7 @@ struct CsGemmParams {
   int ablate;         // debug timing builds only (CS_ABLATE); 0 in the product
   int stagger_ticks;  // start delay (100 MHz ticks) of every other resident block; 0 = none
   int stagger_mode;   // 0: second half of the slots, 1: odd slots
+  int tall;           // 1: 256-row tiles (8 waves, 1 block/CU) where M is large; 0: 128-row tiles (2 blocks/CU)
 };
 
 struct CsAttnParams {

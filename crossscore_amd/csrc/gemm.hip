@@ -21,27 +21,31 @@
 
 namespace {
 
-constexpr int BM = 128, BK = 32;
-constexpr int A_BYTES = BM * BK * 2;  // 8 KiB per stage
+constexpr int BK = 32;
 
-template <int NSUB> struct GemmCfg {
+// WM = wave rows: block tile = (128*WM) x (64*NSUB), 4*WM waves
+template <int NSUB, int WM> struct GemmCfg {
+  static constexpr int BM = 128 * WM;
+  static constexpr int A_BYTES = BM * BK * 2;
+  static constexpr int WAVES = 4 * WM;
   static constexpr int BN = 64 * NSUB;
   static constexpr int STAGE_BYTES = (BM + BN) * BK * 2;           // 24 / 20 / 16 KiB
 #ifdef CS_NS_OVERRIDE
   static constexpr int NS = CS_NS_OVERRIDE;
 #else
-  static constexpr int NS = NSUB == 4 ? 2 : 3;                     // ring slots: 48 / 60 / 48 KiB of LDS
+  static constexpr int NS = (WM == 2 || NSUB == 4) ? 2 : 3;        // ring slots (deeper rings measured slower: the LDS-DMA
+                                                                   // path is throughput bound, a fuller queue only blocks issue)
 #endif
-  static constexpr int BLOCKS_PER_CU = 2;
+  static constexpr int BLOCKS_PER_CU = WM == 2 ? 1 : 2;
   static constexpr int D = NS - 1;                                 // K slices kept in flight
-  static constexpr int WL = NSUB;                                  // W LDS-DMA instructions per wave per slice
+  static constexpr int WL = (4 * NSUB + WAVES - 1) / WAVES;        // W LDS-DMA instructions per wave per slice (BN=192, 8 waves: 2, 4 duplicated)
   static constexpr int LPS = 2 + WL;                               // LDS-DMA instructions per wave per slice
   static constexpr int RING = NS * STAGE_BYTES;
   static constexpr int WN = 16 * NSUB;                             // wave tile columns
   static constexpr int PROW_F = WN * 4 + 16;                       // epilogue patch row (fp32), padded: conflict-free b128 writes
   static constexpr int PROW_H = WN * 2 + 16;                       // epilogue patch row (bf16)
   static constexpr int PATCH = 16 * PROW_F;                        // one 16-row patch per wave
-  static constexpr int LDS = RING + 4 * PATCH;                      // 65.4 / 73.3 / 57.2 KiB -> two blocks per CU
+  static constexpr int LDS = RING + WAVES * PATCH;
 };
 
 #define CS_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -80,17 +84,18 @@ __device__ __noinline__ float head_activation(float v, int act, float powp) {
 // barriers (counted s_waitcnt vmcnt, raw s_barrier), also across tile boundaries.  TWO such blocks are resident per CU
 // (one wave of each per SIMD): with K of only 384-1536 the epilogue (activation, transpose, stores) costs as much issue
 // time as the K loop, and it can only hide under MFMAs that belong to ANOTHER block in a different phase.
-template <int EPI, int NSUB>
-__global__ __launch_bounds__(256, GemmCfg<NSUB>::BLOCKS_PER_CU) void cs_gemm_kernel(CsGemmParams p) {
-  using Cfg = GemmCfg<NSUB>;
+template <int EPI, int NSUB, int WM>
+__global__ __launch_bounds__(256 * WM, 2) void cs_gemm_kernel(CsGemmParams p) {
+  using Cfg = GemmCfg<NSUB, WM>;
   constexpr int BN = Cfg::BN, NS = Cfg::NS, D = Cfg::D, LPS = Cfg::LPS, STAGE_BYTES = Cfg::STAGE_BYTES;
+  constexpr int BM = Cfg::BM, A_BYTES = Cfg::A_BYTES, WAVES = Cfg::WAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int wm = 0, wn = wv;
+  const int wm = wv >> 2, wn = wv & 3;
   const int nk = p.K / BK;
 
   // ---- persistent tile walk, XCD aware: blocks b, b+8, .. share an XCD (round-robin dispatch); XCD x owns the A row
@@ -114,13 +119,15 @@ __global__ __launch_bounds__(256, GemmCfg<NSUB>::BLOCKS_PER_CU) void cs_gemm_ker
   auto set_tile = [&](int m0, int n0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int ga = m0 + (j * 4 + wv) * 16 + srow;     // A tile: 8 groups of 16 rows, 2 per wave
+      int ga = m0 + (j * WAVES + wv) * 16 + srow;  // A tile: 8*WM groups of 16 rows, 2 per wave
       ga = ga < p.M ? ga : p.M - 1;
       offA[j] = ga * p.lda + gchunk * 8;
     }
 #pragma unroll
     for (int j = 0; j < Cfg::WL; ++j) {
-      int gw = n0 + (j * 4 + wv) * 16 + srow;     // W tile: 4*NSUB groups of 16 rows, NSUB per wave
+      int grp = j * WAVES + wv;                    // W tile: 4*NSUB groups of 16 rows
+      if (grp >= 4 * NSUB) grp = wv;               // 192-wide tile on 8 waves: waves 4-7 re-issue their first group (uniform LPS)
+      int gw = n0 + grp * 16 + srow;
       gw = gw < p.N ? gw : p.N - 1;
       offW[j] = gw * p.ldw + gchunk * 8;
     }
@@ -129,10 +136,13 @@ __global__ __launch_bounds__(256, GemmCfg<NSUB>::BLOCKS_PER_CU) void cs_gemm_ker
     char* base = smem + ring * STAGE_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.A + offA[j] + kt * BK), CS_LDS_PTR(base + (j * 4 + wv) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.A + offA[j] + kt * BK), CS_LDS_PTR(base + (j * WAVES + wv) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < Cfg::WL; ++j)
-      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.W + offW[j] + kt * BK), CS_LDS_PTR(base + A_BYTES + (j * 4 + wv) * 1024), 16, 0, 0);
+    for (int j = 0; j < Cfg::WL; ++j) {
+      int grp = j * WAVES + wv;
+      if (grp >= 4 * NSUB) grp = wv;
+      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.W + offW[j] + kt * BK), CS_LDS_PTR(base + A_BYTES + grp * 1024), 16, 0, 0);
+    }
   };
 
   // stagger: blocks that share a CU run the same program on equal tiles and would stay in phase (all in the K loop, then
@@ -337,13 +347,13 @@ __global__ __launch_bounds__(256, GemmCfg<NSUB>::BLOCKS_PER_CU) void cs_gemm_ker
 
 int g_num_cus = 0;
 
-template <int EPI, int NSUB>
+template <int EPI, int NSUB, int WM>
 hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
-  constexpr int BN = 64 * NSUB;
-  constexpr int LDS = GemmCfg<NSUB>::LDS;
+  constexpr int BN = 64 * NSUB, BM = 128 * WM;
+  constexpr int LDS = GemmCfg<NSUB, WM>::LDS;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm_kernel<EPI, NSUB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm_kernel<EPI, NSUB, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
@@ -356,14 +366,14 @@ hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   // two persistent blocks per CU (LDS and registers admit two); grid is a multiple of 8 so that b%8 labels the XCD group
-  int grid = (GemmCfg<NSUB>::BLOCKS_PER_CU * g_num_cus / 8) * 8;
+  int grid = (GemmCfg<NSUB, WM>::BLOCKS_PER_CU * g_num_cus / 8) * 8;
 #ifdef CS_ABLATE
   if (const char* e = getenv("CS_GEMM_GRID")) grid = atoi(e);
 #endif
   const int need = ((tiles_m + 7) / 8) * tiles_n * 8;
   if (grid > need) grid = need;
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((cs_gemm_kernel<EPI, NSUB>), dim3(grid), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((cs_gemm_kernel<EPI, NSUB, WM>), dim3(grid), dim3(256 * WM), LDS, stream, p);
   return hipGetLastError();
 }
 
@@ -371,10 +381,18 @@ template <int EPI>
 hipError_t launch(const CsGemmParams& p, hipStream_t stream) {
   // column tile: 256 where it divides N, else 192, else 128 (every N of the path is a multiple of 384, 128 or the 196 head)
   // 192 first: its ring has 3 slots inside the 80 KiB a block may use with two blocks per CU (256-wide has only 2)
-  if (p.N % 192 == 0) return launch_n<EPI, 3>(p, stream);
-  if (p.N % 256 == 0) return launch_n<EPI, 4>(p, stream);
-  if (p.N % 128 == 0 || p.N < 192) return launch_n<EPI, 2>(p, stream);
-  return launch_n<EPI, 4>(p, stream);
+#ifdef CS_ABLATE
+  // 256-row tiles (8 waves, one block per CU) stage ~30 % fewer bytes per FLOP; measured (tools/gemm_ablate.py, QKV shape):
+  // LDS-DMA stream alone 50 vs 60 us, whole kernel 91 vs 83 us -- with one block per CU the epilogue no longer hides.
+  // Kept for experiments only.
+  const bool tall = p.tall > 0 && p.M >= 4096;
+  if (tall && p.N % 192 == 0) return launch_n<EPI, 3, 2>(p, stream);
+  if (tall && p.N % 256 == 0) return launch_n<EPI, 4, 2>(p, stream);
+#endif
+  if (p.N % 192 == 0) return launch_n<EPI, 3, 1>(p, stream);
+  if (p.N % 256 == 0) return launch_n<EPI, 4, 1>(p, stream);
+  if (p.N % 128 == 0 || p.N < 192) return launch_n<EPI, 2, 1>(p, stream);
+  return launch_n<EPI, 4, 1>(p, stream);
 }
 
 }  // namespace
@@ -402,6 +420,7 @@ extern "C" hipError_t cs_gemm_launch(const CsGemmParams* p0, int epi, hipStream_
   if (const char* e = getenv("CS_GEMM_ABLATE")) pp.ablate = atoi(e);
   if (const char* e = getenv("CS_GEMM_STAGGER")) pp.stagger_ticks = atoi(e);
   if (const char* e = getenv("CS_GEMM_STAGGER_MODE")) pp.stagger_mode = atoi(e);
+  if (const char* e = getenv("CS_GEMM_TALL")) pp.tall = atoi(e);
 #endif
   const CsGemmParams* p = &pp;
   switch (epi) {

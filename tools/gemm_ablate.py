@@ -23,25 +23,15 @@ for sn, (M, N, K, epi) in shapes.items():
     resid = torch.randn(M, N, device=dev) if epi == _lib.EPI_RESID_F32 else None
     o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.bfloat16)
     line = [f"{sn:8s} M={M} N={N} K={K}:"]
-    os.environ["CS_GEMM_ABLATE"] = "0"
-    for mode in (0,):
-        for ticks in (128, 256, 384, 512, 768, 1024):
-            os.environ["CS_GEMM_GRID"] = str(ticks)
+    for tall in (0, 1, 0, 1):
+        os.environ["CS_GEMM_TALL"] = str(tall)
+        for ab, nm in ((0, "full"), (1, "no-epi"), (3, "dma-only"), (5, "mfma-only")):
+            os.environ["CS_GEMM_ABLATE"] = str(ab)
             for _ in range(3):
                 hh.gemm(A, W, b, epi, resid=resid, out=o)
             torch.cuda.synchronize(); e0 = torch.cuda.Event(True); e1 = torch.cuda.Event(True); e0.record()
             for _ in range(10):
                 hh.gemm(A, W, b, epi, resid=resid, out=o)
             e1.record(); torch.cuda.synchronize()
-            line.append(f"grid{ticks}={e0.elapsed_time(e1) * 100:.1f}")
-    os.environ.pop("CS_GEMM_GRID")
-    for ab in (0,):
-        os.environ["CS_GEMM_ABLATE"] = str(ab)
-        for _ in range(3):
-            hh.gemm(A, W, b, epi, resid=resid, out=o)
-        torch.cuda.synchronize(); e0 = torch.cuda.Event(True); e1 = torch.cuda.Event(True); e0.record()
-        for _ in range(10):
-            hh.gemm(A, W, b, epi, resid=resid, out=o)
-        e1.record(); torch.cuda.synchronize()
-        line.append(f"{names[ab]}={e0.elapsed_time(e1) * 100:.1f}us")
+            line.append(f"t{tall}/{nm}={e0.elapsed_time(e1) * 100:.1f}")
     print(" ".join(line), flush=True)
