@@ -166,9 +166,14 @@ Plan make_plan(const cs_model* m, int B, int N, int H, int W, char* base) {
   if (c.enc_chunk_images > 0) {
     p.Ic = std::min(ic, p.I);  // explicit: used verbatim (a shorter remainder chunk runs first)
   } else {
-    int passes = (p.I + ic - 1) / ic;
-    if (p.I >= p.lanes) passes = ((passes + p.lanes - 1) / p.lanes) * p.lanes;
-    p.Ic = (p.I + passes - 1) / passes;
+    // whole batch items per chunk (so a lane can decode what it just encoded), about `ic` images, balanced over the lanes
+    const int per_item = 1 + N;
+    int items = std::max(1, ic / per_item);
+    int passes = (B + items - 1) / items;
+    if (B >= p.lanes) passes = ((passes + p.lanes - 1) / p.lanes) * p.lanes;
+    passes = std::min(passes, B);
+    items = (B + passes - 1) / passes;
+    p.Ic = items * per_item;
   }
   const size_t C = c.hidden, Mc = (size_t)p.Ic * p.T, M = (size_t)B * p.Np, Mk = (size_t)B * N * p.Np;
   Arena a{base};
@@ -594,27 +599,38 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
 
   Launcher LL[CS_MAX_LANES] = {Launcher{h, lst[0]}, Launcher{h, lst[1]}, Launcher{h, lst[2]}, Launcher{h, lst[3]}};
   auto lanes_rc = [&]() { for (int l = 0; l < CS_MAX_LANES; ++l) if (LL[l].rc) return LL[l].rc; return 0; };
+  const int per_item = 1 + N;
+  // Decoding each chunk's items on its lane right after encoding them (no global join) was measured SLOWER (833 vs 875
+  // query-images/s on cfg-2): it doubles the number of small decoder launches and the host enqueue rate becomes the
+  // limit.  The decoder therefore runs after a join, split over the lanes by batch halves.
+  const bool chunk_decodes = false;
+  (void)per_item;
   if (int r = fork()) return r;
   {
-    int chunk = 0;
     // chunk sizes: the short remainder (if any) goes FIRST so that it overlaps the long chunks instead of trailing them
+    int chunk = 0, i0 = 0;
     const int rem = p.I % p.Ic;
-    int i0 = 0;
-    if (rem) { enc_chunk(LL[chunk % NL], chunk % NL, 0, rem); i0 = rem; ++chunk; }
-    for (; i0 < p.I; i0 += p.Ic, ++chunk) enc_chunk(LL[chunk % NL], chunk % NL, i0, p.Ic);
+    auto run_chunk = [&](int ic) {
+      Launcher& L = LL[chunk % NL];
+      enc_chunk(L, chunk % NL, i0, ic);
+      if (chunk_decodes) dec_group(L, i0 / per_item, ic / per_item);
+      i0 += ic; ++chunk;
+    };
+    if (rem) run_chunk(rem);
+    while (i0 < p.I) run_chunk(p.Ic);
   }
-  if (int r = join()) return r;   // every image's tokens are in place before any decoder group starts
+  if (int r = join()) return r;
   if (int r = lanes_rc()) return r;
-  if (int r = fork()) return r;
-  {
+  if (!chunk_decodes) {  // every image's tokens are in place (join above) before any decoder group starts
+    if (int r = fork()) return r;
     const int groups = std::min(NL, B);
     for (int g = 0; g < groups; ++g) {
       const int b0 = (int)((long long)B * g / groups), b1 = (int)((long long)B * (g + 1) / groups);
       dec_group(LL[g], b0, b1 - b0);
     }
+    if (int r = join()) return r;
+    if (int r = lanes_rc()) return r;
   }
-  if (int r = join()) return r;
-  if (int r = lanes_rc()) return r;
   Launcher L{h, st};
   if (mean_out) {
     L.begin(32, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();
