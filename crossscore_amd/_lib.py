@@ -34,6 +34,8 @@ SYMBOLS = {
     "cs_weight_name": (C.c_char_p, [_vp, _i]),
     "cs_finalize": (_i, [_vp]),
     "cs_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "cs_encode_references": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "cs_forward_cached": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "cs_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "cs_profile_enable": (_i, [_vp, _i]),
     "cs_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),

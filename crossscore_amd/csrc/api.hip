@@ -155,11 +155,11 @@ struct Plan {
   float *xq, *y, *lse; bf16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
 };
 
-Plan make_plan(const cs_model* m, int B, int N, int H, int W, char* base) {
+Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* base) {
   Plan p{};
   const cs_config& c = m->cfg;
   p.B = B; p.N = N; p.H = H; p.W = W; p.C = c.hidden;
-  p.gh = H / c.patch; p.gw = W / c.patch; p.Np = p.gh * p.gw; p.T = p.Np + 1; p.I = B * (1 + N);
+  p.gh = H / c.patch; p.gw = W / c.patch; p.Np = p.gh * p.gw; p.T = p.Np + 1; p.I = B * (1 + N_enc);
   p.lanes = m->prof ? 1 : (c.lanes <= 0 ? 2 : std::min(c.lanes, CS_MAX_LANES));  // profiling times kernels in isolation
   int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 16 : 8);
   // balanced chunks: a multiple of the lane count, near-equal sizes
@@ -167,7 +167,7 @@ Plan make_plan(const cs_model* m, int B, int N, int H, int W, char* base) {
     p.Ic = std::min(ic, p.I);  // explicit: used verbatim (a shorter remainder chunk runs first)
   } else {
     // whole batch items per chunk (so a lane can decode what it just encoded), about `ic` images, balanced over the lanes
-    const int per_item = 1 + N;
+    const int per_item = 1 + N_enc;
     int items = std::max(1, ic / per_item);
     int passes = (B + items - 1) / items;
     if (B >= p.lanes) passes = ((passes + p.lanes - 1) / p.lanes) * p.lanes;
@@ -436,21 +436,28 @@ int cs_finalize(cs_handle h) {
 
 size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W) {
   if (!h || B <= 0 || N <= 0 || H < h->cfg.patch || W < h->cfg.patch) return 0;
-  return make_plan(h, B, N, H, W, nullptr).total;
+  return make_plan(h, B, N, N, H, W, nullptr).total;
 }
 
-int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N, int H, int W, float* score_out, float* attn_out,
-               int head_id, float* mean_out, cs_stream stream) {
+// mode 0: full forward (query + reference images); mode 1: query images + cached reference tokens (`ref_tokens`, bf16
+// [B][N][Np][C]); mode 2: encode `B` images as references into `tokens_out` (bf16 [B][Np][C]), no decoder.
+static int forward_impl(cs_handle h, int mode, const float* query, const float* refs, const bf16_t* ref_tokens, bf16_t* tokens_out,
+                        int B, int N, int H, int W, float* score_out, float* attn_out, int head_id, float* mean_out,
+                        cs_stream stream) {
   if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
   if (!h->finalized) return fail(CS_ERR_STATE, "cs_forward before cs_finalize");
   const cs_config& c = h->cfg;
-  if (!query || !refs || !score_out) return fail(CS_ERR_BAD_ARG, "null tensor (ref_cross_imgs is required when do_reference_cross)");
-  if (B <= 0 || N <= 0) return fail(CS_ERR_BAD_ARG, "empty batch or no reference views");
+  if (mode == 0 && (!query || !refs || !score_out)) return fail(CS_ERR_BAD_ARG, "null tensor (ref_cross_imgs is required when do_reference_cross)");
+  if (mode == 1 && (!query || !ref_tokens || !score_out)) return fail(CS_ERR_BAD_ARG, "null tensor");
+  if (mode == 2 && (!query || !tokens_out)) return fail(CS_ERR_BAD_ARG, "null tensor");
+  if (B <= 0 || (mode != 2 && N <= 0)) return fail(CS_ERR_BAD_ARG, "empty batch or no reference views");
   if (H < c.patch || W < c.patch) return fail(CS_ERR_BAD_ARG, "image smaller than one patch");
   if (attn_out && (head_id < 0 || head_id >= c.dec_heads)) return fail(CS_ERR_BAD_ARG, "need_attn_weights_head_id %d out of range", head_id);
   hipStream_t st = (hipStream_t)stream;
   const int C = c.hidden, P = c.patch;
-  const size_t need = cs_workspace_bytes(h, B, N, H, W);
+  const int N_enc = mode == 0 ? N : 0;          // reference views that go through the encoder with their query
+  const int N_plan = mode == 2 ? 0 : N;
+  const size_t need = make_plan(h, B, N_plan, N_enc, H, W, nullptr).total;
   if (need > h->ws_bytes) {
     HIPCHK(hipStreamSynchronize(st));
     if (h->ws) hipFree(h->ws);
@@ -458,7 +465,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
     HIPCHK(hipMalloc(&h->ws, need));
     h->ws_bytes = need;
   }
-  Plan p = make_plan(h, B, N, H, W, h->ws);
+  Plan p = make_plan(h, B, N_plan, N_enc, H, W, h->ws);
   if ((long long)B * N * p.Np * 2 * C * c.dec_layers >= (1ll << 31)) return fail(CS_ERR_UNSUPPORTED, "batch too large for 32-bit offsets; split the batch");
   if (int r = ensure_tables(h, p.gh, p.gw, H == W, st)) return r;
   const int enc_dh = C / c.enc_heads, dec_dh = C / c.dec_heads;
@@ -497,7 +504,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
     hipStream_t s = L.st;
     float* x = p.x[slot]; bf16_t* u = p.u[slot]; bf16_t* r1 = p.r1[slot];
     const int Mc = ic * p.T;
-    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N, i0, r1, ic, H, W, P, h->Kp, s), "im2col"); L.end();
+    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, s), "im2col"); L.end();
     L.begin(32, 0); L.misc(cs_cls_rows_launch(x, ic, p.T, C, h->cls, h->pos_tab, s), "cls"); L.end();
     {
       CsGemmParams g = gp(r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, x, C);
@@ -530,7 +537,8 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
       }
     }
     L.begin(32, 0);
-    L.misc(cs_final_ln_split_launch(x, ic, i0, p.Np, C, N, h->lnfg, h->lnfb, 1e-6f, h->pe_tab, p.xq, p.q_bf, p.mem_bf, s), "final_ln");
+    L.misc(cs_final_ln_split_launch(x, ic, i0, p.Np, C, mode == 2 ? -1 : N_enc, h->lnfg, h->lnfb, 1e-6f, h->pe_tab, p.xq, p.q_bf,
+                                    mode == 2 ? tokens_out : p.mem_bf, s), "final_ln");
     L.end();
   };
 
@@ -541,7 +549,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
     const size_t ro = (size_t)b0 * p.Np;          // first query row of the group
     const size_t ko = (size_t)b0 * N * p.Np;      // first memory row of the group
     float* xq = p.xq + ro * C; float* y = p.y + ro * C; bf16_t* q_bf = p.q_bf + ro * C;
-    bf16_t* mem = p.mem_bf + ko * C; bf16_t* kv = p.kv + ko * KV;
+    const bf16_t* mem = (mode == 1 ? ref_tokens : p.mem_bf) + ko * C; bf16_t* kv = p.kv + ko * KV;
     bf16_t* dqkv = p.dqkv + ro * 3 * C; bf16_t* dq = p.dq + ro * C; bf16_t* dob = p.dob + ro * C; bf16_t* dhid = p.dhid + ro * C;
     float* lse = p.lse + (size_t)b0 * c.dec_heads * p.Np;
     L.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_BF16);
@@ -599,7 +607,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
 
   Launcher LL[CS_MAX_LANES] = {Launcher{h, lst[0]}, Launcher{h, lst[1]}, Launcher{h, lst[2]}, Launcher{h, lst[3]}};
   auto lanes_rc = [&]() { for (int l = 0; l < CS_MAX_LANES; ++l) if (LL[l].rc) return LL[l].rc; return 0; };
-  const int per_item = 1 + N;
+  const int per_item = 1 + N_enc;
   // Decoding each chunk's items on its lane right after encoding them (no global join) was measured SLOWER (833 vs 875
   // query-images/s on cfg-2): it doubles the number of small decoder launches and the host enqueue rate becomes the
   // limit.  The decoder therefore runs after a join, split over the lanes by batch halves.
@@ -621,6 +629,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
   }
   if (int r = join()) return r;
   if (int r = lanes_rc()) return r;
+  if (mode == 2) return 0;
   if (!chunk_decodes) {  // every image's tokens are in place (join above) before any decoder group starts
     if (int r = fork()) return r;
     const int groups = std::min(NL, B);
@@ -636,6 +645,20 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
     L.begin(32, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();
   }
   return L.rc;
+}
+
+int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N, int H, int W, float* score_out, float* attn_out,
+               int head_id, float* mean_out, cs_stream stream) {
+  return forward_impl(h, 0, query, refs, nullptr, nullptr, B, N, H, W, score_out, attn_out, head_id, mean_out, stream);
+}
+
+int cs_encode_references(cs_handle h, const float* imgs, int R, int H, int W, uint16_t* tokens_out, cs_stream stream) {
+  return forward_impl(h, 2, imgs, nullptr, nullptr, tokens_out, R, 0, H, W, nullptr, nullptr, 0, nullptr, stream);
+}
+
+int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_tokens, int B, int N, int H, int W, float* score_out,
+                      float* attn_out, int head_id, float* mean_out, cs_stream stream) {
+  return forward_impl(h, 1, query, nullptr, ref_tokens, nullptr, B, N, H, W, score_out, attn_out, head_id, mean_out, stream);
 }
 
 int cs_profile_enable(cs_handle h, int on) {

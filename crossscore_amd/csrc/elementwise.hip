@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __rest
   if (row >= (long long)I * Np) return;
   const int img = (int)(row / Np);
   const int pp = (int)(row - (long long)img * Np);
-  const int bb = (img0 + img) / (1 + N), v = (img0 + img) - bb * (1 + N);
+  // N < 0: every image is a reference view (reference-token cache): row goes to mem_bf[(img0+img)*Np + pp]
+  const int bb = N < 0 ? 0 : (img0 + img) / (1 + N), v = N < 0 ? 1 + img0 + img : (img0 + img) - bb * (1 + N);
   const int C4 = C / 4;
   LnRow r;
   ln_load(x + ((size_t)img * (Np + 1) + 1 + pp) * C, C4, lane, r);
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __rest
     const size_t o = ((size_t)bb * Np + pp) * C;
     ln_store(r, C4, lane, q_f32 + o, q_bf + o);
   } else {
-    const size_t o = (((size_t)bb * N + (v - 1)) * Np + pp) * C;
+    const size_t o = (((size_t)bb * (N < 0 ? 0 : N) + (v - 1)) * Np + pp) * C;
     ln_store(r, C4, lane, nullptr, mem_bf + o);
   }
 }

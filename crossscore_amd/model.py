@@ -183,14 +183,70 @@ class CrossScoreNet(torch.nn.Module):
             attn = torch.empty((B, h, w, N, h, w), dtype=torch.float32, device=dev) if need_attn_weights else None
             mean_out = torch.empty((B,), dtype=torch.float32, device=dev) if return_mean else None
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = lib.cs_forward(handle, C.c_void_p(q.data_ptr()), C.c_void_p(r.data_ptr()), B, N, H, W,
-                                C.c_void_p(score.data_ptr()), C.c_void_p(attn.data_ptr()) if attn is not None else None,
-                                int(need_attn_weights_head_id), C.c_void_p(mean_out.data_ptr()) if mean_out is not None else None,
-                                C.c_void_p(stream))
-            _lib.check(rc)
+            # Items are independent, so a batch whose decoder buffers would overflow the kernels' 32-bit element offsets
+            # (B*N*Np*4C >= 2^31, e.g. ViT-B with 128 items) is scored in sub-batches; results are identical either way.
+            kv_per_item = N * h * w * 2 * self.arch.hidden * self.arch.dec_layers
+            step = max(1, min(B, (2 ** 31 - 1) // max(kv_per_item, 1)))
+            for b0 in range(0, B, step):
+                b1 = min(B, b0 + step)
+                rc = lib.cs_forward(handle, C.c_void_p(q[b0:b1].data_ptr()), C.c_void_p(r[b0:b1].data_ptr()), b1 - b0, N, H, W,
+                                    C.c_void_p(score[b0:b1].data_ptr()),
+                                    C.c_void_p(attn[b0:b1].data_ptr()) if attn is not None else None,
+                                    int(need_attn_weights_head_id),
+                                    C.c_void_p(mean_out[b0:b1].data_ptr()) if mean_out is not None else None,
+                                    C.c_void_p(stream))
+                _lib.check(rc)
         results = {"score_map_ref_cross": score, "attn_weights_map_ref_cross": attn}
         if return_mean:
             results["score_mean_ref_cross"] = mean_out  # key does not start with "score_map": writers ignore it
+        return results
+
+    # -- reference-feature cache: a separate mode, bit-identical results ---------------------------
+    @torch.no_grad()
+    def encode_references(self, ref_imgs):
+        """(R,3,H,W) normalised reference images -> (R, h*w, C) bf16 decoder-ready tokens (final LN + multi-view PE).
+        A reference's tokens depend neither on the query nor on its view slot, so they can be computed once per image of
+        reference_dir and gathered per query."""
+        if ref_imgs.dim() != 4 or ref_imgs.shape[1] != 3 or not ref_imgs.is_cuda:
+            raise ValueError("expected CUDA ref_imgs (R,3,H,W)")
+        dev = ref_imgs.device
+        x = ref_imgs.to(torch.float32).contiguous()
+        R, _, H, W = x.shape
+        P = self.arch.patch
+        handle = self._ensure_handle(dev)
+        with torch.cuda.device(dev):
+            tok = torch.empty((R, (H // P) * (W // P), self.arch.hidden), dtype=torch.bfloat16, device=dev)
+            _lib.check(_lib.load().cs_encode_references(handle, C.c_void_p(x.data_ptr()), R, H, W, C.c_void_p(tok.data_ptr()),
+                                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return tok
+
+    @torch.no_grad()
+    def forward_cached(self, query_img, ref_tokens, need_attn_weights=False, need_attn_weights_head_id=0, return_mean=False):
+        """forward() with the reference views given as cached tokens (B, N, h*w, C) bf16 from encode_references."""
+        if query_img.dim() != 4 or ref_tokens.dim() != 4 or ref_tokens.shape[0] != query_img.shape[0]:
+            raise ValueError("expected query_img (B,3,H,W) and ref_tokens (B,N,h*w,C)")
+        dev = query_img.device
+        q = query_img.to(torch.float32).contiguous()
+        t = ref_tokens.to(torch.bfloat16).contiguous()
+        B, _, H, W = q.shape
+        N = t.shape[1]
+        P = self.arch.patch
+        h, w = H // P, W // P
+        if t.shape[2] != h * w or t.shape[3] != self.arch.hidden:
+            raise ValueError("ref_tokens do not match the query's patch grid / hidden size")
+        handle = self._ensure_handle(dev)
+        with torch.cuda.device(dev):
+            score = torch.empty((B, h * P, w * P), dtype=torch.float32, device=dev)
+            attn = torch.empty((B, h, w, N, h, w), dtype=torch.float32, device=dev) if need_attn_weights else None
+            mean_out = torch.empty((B,), dtype=torch.float32, device=dev) if return_mean else None
+            _lib.check(_lib.load().cs_forward_cached(
+                handle, C.c_void_p(q.data_ptr()), C.c_void_p(t.data_ptr()), B, N, H, W, C.c_void_p(score.data_ptr()),
+                C.c_void_p(attn.data_ptr()) if attn is not None else None, int(need_attn_weights_head_id),
+                C.c_void_p(mean_out.data_ptr()) if mean_out is not None else None,
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        results = {"score_map_ref_cross": score, "attn_weights_map_ref_cross": attn}
+        if return_mean:
+            results["score_mean_ref_cross"] = mean_out
         return results
 
     # -- profiling hooks used by bench.py --------------------------------------------------------------------

@@ -75,6 +75,15 @@ int cs_finalize(cs_handle h);
  *   mean_out:  NULL, or (B) fp32 device = per-image mean of the score map (utils/io/score_summariser.py:180-192) */
 int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N, int H, int W, float* score_out,
                float* attn_out, int head_id, float* mean_out, cs_stream stream);
+/* Reference-feature cache.  In predict the N references of every query are drawn from one finite
+ * reference_dir (dataloading/dataset/simple_reference.py:55-58, utils/neighbour/sampler.py:27-34), and a reference's
+ * decoder input -- final LayerNorm of its DINOv2 tokens + multi-view PE, task/core.py:141-153,93-98 -- does not depend on the
+ * query or on its view slot.  cs_encode_references encodes R images once into bf16 tokens (R, h*w, C); cs_forward_cached
+ * scores B queries against gathered tokens (B, N, h*w, C).  Results are bit-identical to cs_forward on the same images; the
+ * encoder work per query drops from 1+N images to 1 (a separate mode: it changes the algorithmic FLOPs). */
+int cs_encode_references(cs_handle h, const float* imgs, int R, int H, int W, uint16_t* tokens_out, cs_stream stream);
+int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_tokens, int B, int N, int H, int W,
+                      float* score_out, float* attn_out, int head_id, float* mean_out, cs_stream stream);
 /* Bytes of library-owned workspace a forward of this shape needs (grown lazily, never shrunk). */
 size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
 

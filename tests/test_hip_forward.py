@@ -143,6 +143,24 @@ def test_encoder_chunking_is_invisible():
         assert torch.equal(net(tq, tr, False, 0, False)["score_map_ref_cross"], base), chunk
 
 
+def test_reference_token_cache_is_bit_identical():
+    """encode each reference image once, gather per query -> the same score map bit for bit (encoder results
+    per image do not depend on the batch they ran in), including when two queries share a reference."""
+    net, arch, sd = _net(TINY, 4)
+    q, r = synth.make_inputs(3, 2, 70, 98, 4)
+    r[2, 0] = r[0, 1]  # query 2 reuses a reference of query 0
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    full = net(tq, tr, True, 5, False)
+    pool = torch.stack([tr[0, 0], tr[0, 1], tr[1, 0], tr[1, 1], tr[2, 1]])     # 5 distinct reference images
+    tok = net.encode_references(pool)
+    assert tok.shape == (5, 5 * 7, arch.hidden) and tok.dtype == torch.bfloat16
+    idx = torch.tensor([[0, 1], [2, 3], [1, 4]], device="cuda")
+    cached = net.forward_cached(tq, tok[idx], True, 5)
+    torch.cuda.synchronize()
+    assert torch.equal(cached["score_map_ref_cross"], full["score_map_ref_cross"])
+    assert torch.equal(cached["attn_weights_map_ref_cross"], full["attn_weights_map_ref_cross"])
+
+
 def test_bad_inputs_raise():
     net, arch, sd = _net(TINY, 2)
     q = torch.zeros(1, 3, 70, 70, device="cuda")
