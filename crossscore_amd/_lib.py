@@ -39,14 +39,14 @@ SYMBOLS = {
     "cs_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "cs_profile_enable": (_i, [_vp, _i]),
     "cs_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
-    "cs_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "cs_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "cs_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_attention_weights": (_i, [_vp, _vp, _i, _i, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "cs_op_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "cs_op_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cs_op_pos_bicubic": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pe_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "cs_op_pack_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "cs_op_pack_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -29,7 +29,8 @@ hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int
 hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, hipStream_t st);
 hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float* out, hipStream_t st);
 hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st);
-hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, hipStream_t st);
+hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, const float* row_scale, hipStream_t st);
+hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
 }
@@ -340,8 +341,8 @@ int cs_finalize(cs_handle h) {
     return &it->second;
   };
   hipStream_t st = nullptr;
-  auto pack = [&](const float* src, int rows, int K, int ldo, bf16_t* dst) -> int {
-    HIPCHK(cs_pack_bf16_launch(src, rows, K, dst, ldo, st));
+  auto pack = [&](const float* src, int rows, int K, int ldo, bf16_t* dst, const float* row_scale = nullptr) -> int {
+    HIPCHK(cs_pack_bf16_launch(src, rows, K, dst, ldo, row_scale, st));
     return 0;
   };
   auto alloc_bf = [&](size_t n) -> bf16_t* { void* p = nullptr; if (hipMalloc(&p, n * sizeof(bf16_t)) != hipSuccess) return nullptr; h->owned.push_back(p); return (bf16_t*)p; };
@@ -372,16 +373,22 @@ int cs_finalize(cs_handle h) {
     NEED(l1, p + "layer_scale1.lambda1", C) NEED(l2, p + "layer_scale2.lambda1", C)
     NEED(f1w, p + "mlp.fc1.weight", F, C) NEED(f1b, p + "mlp.fc1.bias", F)
     NEED(f2w, p + "mlp.fc2.weight", C, F) NEED(f2b, p + "mlp.fc2.bias", C)
-    L.ln1g = n1w->d; L.ln1b = n1b->d; L.ln2g = n2w->d; L.ln2b = n2b->d; L.bo = ob->d; L.b1 = f1b->d; L.b2 = f2b->d; L.ls1 = l1->d; L.ls2 = l2->d;
+    L.ln1g = n1w->d; L.ln1b = n1b->d; L.ln2g = n2w->d; L.ln2b = n2b->d; L.b1 = f1b->d;
+    // LayerScale (x += lambda * (a Wo^T + bo), HF:367-370,376-378) is folded into the projection: rows of Wo / W2 and the
+    // biases are scaled by lambda once, so the GEMM epilogue is a plain residual add
+    ALLOC_F(bo_s, (size_t)C) ALLOC_F(b2_s, (size_t)C)
+    HIPCHK(cs_vec_mul_launch(ob->d, l1->d, bo_s, (int)C, st));
+    HIPCHK(cs_vec_mul_launch(f2b->d, l2->d, b2_s, (int)C, st));
+    L.bo = bo_s; L.b2 = b2_s; L.ls1 = nullptr; L.ls2 = nullptr;
     ALLOC_BF(wqkv, (size_t)3 * C * C) ALLOC_F(bqkv, (size_t)3 * C)
     if (int r = pack(qw->d, (int)C, (int)C, (int)C, wqkv)) return r;
     if (int r = pack(kw->d, (int)C, (int)C, (int)C, wqkv + C * C)) return r;
     if (int r = pack(vw->d, (int)C, (int)C, (int)C, wqkv + 2 * C * C)) return r;
     D2D(bqkv, qb->d, C); D2D(bqkv + C, kb->d, C); D2D(bqkv + 2 * C, vb->d, C);
     ALLOC_BF(wo, (size_t)C * C) ALLOC_BF(w1, (size_t)F * C) ALLOC_BF(w2, (size_t)C * F)
-    if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
+    if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo, l1->d)) return r;
     if (int r = pack(f1w->d, (int)F, (int)C, (int)C, w1)) return r;
-    if (int r = pack(f2w->d, (int)C, (int)F, (int)F, w2)) return r;
+    if (int r = pack(f2w->d, (int)C, (int)F, (int)F, w2, l2->d)) return r;
     L.Wqkv = wqkv; L.bqkv = bqkv; L.Wo = wo; L.W1 = w1; L.W2 = w2;
   }
   { NEED(g, "backbone.layernorm.weight", C) NEED(b, "backbone.layernorm.bias", C) h->lnfg = g->d; h->lnfb = b->d; }
@@ -525,14 +532,14 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
       }
       {
         CsGemmParams g = gp(u, C, E.Wo, C, Mc, C, C, E.bo, x, C);
-        g.scale = E.ls1; g.resid = x; g.ldr = C;
+        g.resid = x; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, u, s), "ln2"); L.end();
       L.gemm(gp(u, C, E.W1, C, Mc, F, C, E.b1, r1, F), CS_EPI_BIAS_GELU_BF16);
       {
         CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);
-        g.scale = E.ls2; g.resid = x; g.ldr = C;
+        g.resid = x; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
     }
@@ -689,11 +696,11 @@ int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, do
 // ---------------------------------------------------------------------------------------------------------
 // single-op entry points
 // ---------------------------------------------------------------------------------------------------------
-int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias, const float* scale,
+int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
                const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np, int gw, int P, int act,
                float powp, cs_stream stream) {
   CsGemmParams g = gp(A, lda, W, ldw, M, N, K, bias, out, ldc);
-  g.scale = scale; g.resid = resid; g.ldr = ldr; g.pos = pos; g.Np = Np; g.gw = gw; g.P = P; g.act = act; g.powp = powp;
+  g.resid = resid; g.ldr = ldr; g.pos = pos; g.Np = Np; g.gw = gw; g.P = P; g.act = act; g.powp = powp;
   if (epi < 0 || epi > CS_EPI_HEAD_SCORE) return fail(CS_ERR_BAD_ARG, "gemm: unknown epilogue %d", epi);
   if (const char* e = cs_gemm_check(&g, epi)) return fail(CS_ERR_BAD_ARG, "%s", e);
   HIPCHK(cs_gemm_launch(&g, epi, (hipStream_t)stream));
@@ -748,9 +755,9 @@ int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, fl
   return 0;
 }
 
-int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, cs_stream stream) {
+int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, cs_stream stream) {
   if (!w || !out || rows <= 0 || K <= 0 || ldo < K) return fail(CS_ERR_BAD_ARG, "pack_bf16: bad arguments");
-  HIPCHK(cs_pack_bf16_launch(w, rows, K, out, ldo, (hipStream_t)stream));
+  HIPCHK(cs_pack_bf16_launch(w, rows, K, out, ldo, row_scale, (hipStream_t)stream));
   return 0;
 }
 

@@ -226,13 +226,21 @@ __global__ void pe_bilinear_kernel(const float* __restrict__ pe, int ph, int pw,
   out[i] = top * (1.f - ly) + bot * ly;
 }
 
-// fp32 -> bf16 weight packing (K-contiguous rows; optional zero padding of K to ldo)
-__global__ void pack_bf16_kernel(const float* __restrict__ w, int rows, int K, bf16_t* __restrict__ out, int ldo) {
+// fp32 -> bf16 weight packing (K-contiguous rows; optional zero padding of K to ldo; optional per-output-row scale:
+// LayerScale lambda folded into the projection, HF modeling_dinov2.py:277-278, so the GEMM epilogue has no scale operand)
+__global__ void pack_bf16_kernel(const float* __restrict__ w, int rows, int K, bf16_t* __restrict__ out, int ldo,
+                                 const float* __restrict__ row_scale) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)rows * ldo) return;
   const int k = (int)(i % ldo);
   const long long rr = i / ldo;
-  out[i] = k < K ? f2bf(w[rr * K + k]) : (bf16_t)0;
+  const float sc = row_scale ? row_scale[rr] : 1.0f;
+  out[i] = k < K ? f2bf(w[rr * K + k] * sc) : (bf16_t)0;
+}
+
+__global__ void vec_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] * b[i];
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -326,9 +334,14 @@ hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh,
   return hipGetLastError();
 }
 
-hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, hipStream_t st) {
+hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, const float* row_scale, hipStream_t st) {
   const long long total = (long long)rows * ldo;
-  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, rows, K, out, ldo);
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, rows, K, out, ldo, row_scale);
+  return hipGetLastError();
+}
+
+hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(vec_mul_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, out, n);
   return hipGetLastError();
 }
 

@@ -94,9 +94,9 @@ int cs_profile_enable(cs_handle h, int on);
 int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, double* flops);
 
 /* ---- single-op entry points (used by the parity tests; same kernels the forward launches) ------------- */
-/* out = epilogue(A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. bf16 = raw uint16. */
+/* out = epilogue(bias + A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. bf16 = raw uint16. */
 int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
-               const float* scale, const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np,
+               const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np,
                int gw, int P, int act, float powp, cs_stream stream);
 /* softmax(QK^T/sqrt(dh))V for `batch` x `heads`; strides in elements; lse may be NULL. */
 int cs_op_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* V, uint16_t* O, int ldq, int ldk, int ldv,
@@ -110,7 +110,8 @@ int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const floa
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream);
 int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream);
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
-int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, cs_stream stream);
+/* fp32 [rows][K] -> bf16 [rows][ldo] (zero padded); row_scale (rows) may be NULL: LayerScale folded into a projection */
+int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, cs_stream stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_BF16, scale=None, resid=None, out=None, pos=None, Np=0, gw=0, P=0, act=0, powp=1.0,
+def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_BF16, resid=None, out=None, pos=None, Np=0, gw=0, P=0, act=0, powp=1.0,
          K=None, ldc=None):
     """A:(M,lda) bf16, W:(N,ldw) bf16 -> out (allocated here unless given)."""
     lib = _lib.load()
@@ -25,7 +25,7 @@ def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_BF16, scale=None, resid=None, out=No
         dt = torch.bfloat16 if epi <= _lib.EPI_BIAS_LEAKY_BF16 else torch.float32
         out = torch.zeros((M, N), dtype=dt, device=A.device)
     ldc = ldc or out.shape[-1]
-    rc = lib.cs_op_gemm(_p(A), lda, _p(W), ldw, M, N, K, _p(bias), _p(scale), _p(resid), resid.shape[-1] if resid is not None else 0,
+    rc = lib.cs_op_gemm(_p(A), lda, _p(W), ldw, M, N, K, _p(bias), _p(resid), resid.shape[-1] if resid is not None else 0,
                         _p(out), ldc, epi, _p(pos), Np, gw, P, act, powp, _stream())
     _lib.check(rc)
     return out
@@ -88,10 +88,10 @@ def pe_bilinear(pe, gh, gw):
     return out
 
 
-def pack_bf16(w, ldo=None):
+def pack_bf16(w, ldo=None, row_scale=None):
     lib = _lib.load()
     rows, K = w.shape
     ldo = ldo or K
     out = torch.zeros((rows, ldo), dtype=torch.bfloat16, device=w.device)
-    _lib.check(lib.cs_op_pack_bf16(_p(w), rows, K, _p(out), ldo, _stream()))
+    _lib.check(lib.cs_op_pack_bf16(_p(w), rows, K, _p(out), ldo, _p(row_scale), _stream()))
     return out

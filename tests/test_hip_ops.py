@@ -29,7 +29,7 @@ def _bf(x):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 384), (1370, 1152, 384), (257, 196 + 60, 128), (65, 1536, 384),
-                                   (1000, 384, 1536), (2740, 2304, 768)])
+                                   (1000, 384, 1536), (2740, 2304, 768), (65760, 1152, 384), (5000, 136, 256), (16440, 384, 128)])
 def test_gemm_bias_bf16(M, N, K):
     g = _rng(M + N + K)
     A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))
@@ -71,20 +71,22 @@ def test_gemm_activations(epi):
     assert (err <= 4e-3 * ref.abs() + 1e-3).all(), float(err.max())
 
 
-@pytest.mark.parametrize("with_scale,with_resid", [(True, True), (False, True), (False, False)])
-def test_gemm_resid_f32(with_scale, with_resid):
-    M, N, K = 700, 384, 1536
-    g = _rng(11)
+@pytest.mark.parametrize("M,with_scale,with_resid", [(700, True, True), (1370, False, True), (700, False, False), (128, True, True)])
+def test_gemm_resid_f32(M, with_scale, with_resid):
+    """x += lambda * (A Wo^T + b): LayerScale is folded into the packed rows of W and into the bias (as cs_finalize does),
+    the epilogue is a plain in-place residual add (full-tile fast path and ragged last row panel)."""
+    N, K = 384, 1536
+    g = _rng(11 + M)
     A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))
-    W = _bf(_t(g.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)))
+    Wf = _t(g.standard_normal((N, K), dtype=np.float32) / math.sqrt(K))
     b = _t(g.standard_normal((N,), dtype=np.float32))
-    s = _t(g.standard_normal((N,), dtype=np.float32)) if with_scale else None
+    s = _t(0.5 + 0.2 * g.standard_normal((N,), dtype=np.float32)) if with_scale else None
     r = _t(g.standard_normal((M, N), dtype=np.float32)) if with_resid else None
+    W = hh.pack_bf16(Wf, row_scale=s)
+    assert torch.equal(W, _bf(Wf * s[:, None] if with_scale else Wf))
     out = r.clone() if with_resid else None  # in-place residual update, as the encoder uses it
-    out = hh.gemm(A, W, b, _lib.EPI_RESID_F32, scale=s, resid=out, out=out)
-    ref = A.float() @ W.float().t() + b
-    if with_scale:
-        ref = ref * s
+    out = hh.gemm(A, W, b * s if with_scale else b, _lib.EPI_RESID_F32, resid=out, out=out)
+    ref = A.float() @ W.float().t() + (b * s if with_scale else b)
     if with_resid:
         ref = ref + r
     torch.cuda.synchronize()

@@ -23,8 +23,7 @@ for sn, (M, N, K, epi) in shapes.items():
     resid = torch.randn(M, N, device=dev) if epi == _lib.EPI_RESID_F32 else None
     o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.bfloat16)
     line = [f"{sn:8s} M={M} N={N} K={K}:"]
-    for tall in (0, 1, 0, 1):
-        os.environ["CS_GEMM_TALL"] = str(tall)
+    for tall in (0, 0):
         for ab, nm in ((0, "full"), (1, "no-epi"), (3, "dma-only"), (5, "mfma-only")):
             os.environ["CS_GEMM_ABLATE"] = str(ab)
             for _ in range(3):
