@@ -25,7 +25,8 @@ from crossscore_amd.model import CrossScoreNet  # noqa: E402
 from crossscore_amd import parallel  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-GEMM_EPI = ["BIAS_BF16", "BIAS_GELU_BF16", "BIAS_RELU_BF16", "BIAS_LEAKY_BF16", "RESID_F32", "PATCH_F32", "HEAD_SCORE"]
+GEMM_EPI = ["BIAS_BF16", "BIAS_GELU_BF16", "BIAS_RELU_BF16", "BIAS_LEAKY_BF16", "RESID_F32", "PATCH_F32", "HEAD_SCORE",
+            "LN_BF16", "LN_GELU_BF16", "RESID_F32_LN"]
 WORKLOADS = {
     # name: (backbone, H, W, N refs, per-GPU batch)
     "cfg2": ("facebook/dinov2-small", 518, 518, 5, 8),
@@ -47,11 +48,11 @@ def algorithmic_flops_per_query(C, L, H, W, N, P=14, dec_layers=2):
 
 def kernel_table(net):
     rows = []
-    for fam in list(range(7)) + [16 + d // 16 for d in (16, 48, 64, 96)] + [32]:
+    for fam in list(range(10)) + [16 + d // 16 for d in (16, 48, 64, 96)] + [32]:
         ms, n, fl = net.profile_read(fam)
         if n == 0:
             continue
-        name = (f"cs_gemm_kernel<{GEMM_EPI[fam]}>" if fam < 7 else f"cs_attn_kernel<{(fam - 16) * 16}>" if fam < 32 else "layernorm/im2col/other")
+        name = (f"cs_gemm_kernel<{GEMM_EPI[fam]}>" if fam < 10 else f"cs_attn_kernel<{(fam - 16) * 16}>" if fam < 32 else "layernorm/im2col/other")
         rows.append(dict(kernel=name, launches=n, total_ms=ms, avg_us=1e3 * ms / n, tflops=(fl / ms / 1e9) if fl else None, flops=fl))
     return rows
 

@@ -26,10 +26,15 @@ hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, con
                                hipStream_t st);
 hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
                                     const float* pe, float* q_f32, bf16_t* q_bf, bf16_t* mem_bf, hipStream_t st);
-hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, hipStream_t st);
+hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, bf16_t* xb, float* stats, int sp,
+                              hipStream_t st);
+hipError_t cs_ln_fold_consts_launch(const bf16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
+                                    float* s_out, float* c_out, hipStream_t st);
+int cs_gemm_column_tiles(int N);
 hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float* out, hipStream_t st);
 hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st);
-hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, const float* row_scale, hipStream_t st);
+hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, const float* row_scale, const float* col_scale,
+                               hipStream_t st);
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
@@ -62,6 +67,8 @@ struct Tensor {
 struct EncLayer {
   float *ln1g, *ln1b, *ln2g, *ln2b, *bqkv, *bo, *b1, *b2, *ls1, *ls2;
   bf16_t *Wqkv, *Wo, *W1, *W2;
+  // LayerNorm fold (CS_EPI_LN_*): Wqkv / W1 above are then the gamma-scaled versions and these hold s[n], c[n]
+  float *s_qkv, *c_qkv, *s_1, *c_1;
 };
 struct DecLayer {
   float *sa_bin, *sa_bo, *ca_bq, *ca_bo, *l1b, *l2b, *n1g, *n1b, *n2g, *n2b, *n3g, *n3b;
@@ -79,6 +86,8 @@ struct cs_model {
   std::map<std::string, Tensor> w;
   bool finalized = false;
   int Kp = 0;  // padded patch K
+  bool lnfold = false;  // encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass)
+  int ln_sp = 0;        // partial-sum slots per row the producing epilogues write (4 per column tile)
   std::vector<void*> owned;  // device allocations of packed weights
   // packed
   bf16_t* Wpatch = nullptr; float* bpatch = nullptr;
@@ -152,6 +161,7 @@ struct Plan {
   size_t total;
   // encoder chunk buffers, one set per lane
   float* x[CS_MAX_LANES]; bf16_t* u[CS_MAX_LANES]; bf16_t* r1[CS_MAX_LANES];
+  bf16_t* ob[CS_MAX_LANES]; float* stats[CS_MAX_LANES];  // LayerNorm fold: attention output, per-row partial sums
   // decoder
   float *xq, *y, *lse; bf16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
 };
@@ -183,6 +193,8 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
     p.x[l] = a.take<float>(Mc * C);
     p.u[l] = a.take<bf16_t>(Mc * C);
     p.r1[l] = a.take<bf16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * 3 * C, (size_t)p.Ic * p.Np * m->Kp)));
+    p.ob[l] = a.take<bf16_t>(m->lnfold ? Mc * C : 0);
+    p.stats[l] = a.take<float>(m->lnfold ? Mc * (size_t)m->ln_sp * 2 : 0);
   }
   p.xq = a.take<float>(M * C);
   p.y = a.take<float>(M * C);
@@ -288,6 +300,10 @@ cs_handle cs_create(const cs_config* cfg) {
   m->cfg = c;
   m->names = expected_names(c);
   m->Kp = ((3 * c.patch * c.patch + 63) / 64) * 64;
+  m->ln_sp = 4 * cs_gemm_column_tiles(c.hidden);
+  // opt-in: measured slower than separate LayerNorm kernels on cfg-2 (kernel-time sum 10.2 vs 9.5 ms: the folded consumers run
+  // at the 256-register limit and their tile-switch loads drain the LDS-DMA queue)
+  m->lnfold = c.ln_fold == 1 && (m->ln_sp == 4 || m->ln_sp == 8 || m->ln_sp == 16);
   return m;
 }
 
@@ -341,8 +357,9 @@ int cs_finalize(cs_handle h) {
     return &it->second;
   };
   hipStream_t st = nullptr;
-  auto pack = [&](const float* src, int rows, int K, int ldo, bf16_t* dst, const float* row_scale = nullptr) -> int {
-    HIPCHK(cs_pack_bf16_launch(src, rows, K, dst, ldo, row_scale, st));
+  auto pack = [&](const float* src, int rows, int K, int ldo, bf16_t* dst, const float* row_scale = nullptr,
+                  const float* col_scale = nullptr) -> int {
+    HIPCHK(cs_pack_bf16_launch(src, rows, K, dst, ldo, row_scale, col_scale, st));
     return 0;
   };
   auto alloc_bf = [&](size_t n) -> bf16_t* { void* p = nullptr; if (hipMalloc(&p, n * sizeof(bf16_t)) != hipSuccess) return nullptr; h->owned.push_back(p); return (bf16_t*)p; };
@@ -381,15 +398,27 @@ int cs_finalize(cs_handle h) {
     HIPCHK(cs_vec_mul_launch(f2b->d, l2->d, b2_s, (int)C, st));
     L.bo = bo_s; L.b2 = b2_s; L.ls1 = nullptr; L.ls2 = nullptr;
     ALLOC_BF(wqkv, (size_t)3 * C * C) ALLOC_F(bqkv, (size_t)3 * C)
-    if (int r = pack(qw->d, (int)C, (int)C, (int)C, wqkv)) return r;
-    if (int r = pack(kw->d, (int)C, (int)C, (int)C, wqkv + C * C)) return r;
-    if (int r = pack(vw->d, (int)C, (int)C, (int)C, wqkv + 2 * C * C)) return r;
+    const float* g1 = h->lnfold ? n1w->d : nullptr;  // LayerNorm gamma folded into the columns of the consuming projection
+    const float* g2 = h->lnfold ? n2w->d : nullptr;
+    if (int r = pack(qw->d, (int)C, (int)C, (int)C, wqkv, nullptr, g1)) return r;
+    if (int r = pack(kw->d, (int)C, (int)C, (int)C, wqkv + C * C, nullptr, g1)) return r;
+    if (int r = pack(vw->d, (int)C, (int)C, (int)C, wqkv + 2 * C * C, nullptr, g1)) return r;
     D2D(bqkv, qb->d, C); D2D(bqkv + C, kb->d, C); D2D(bqkv + 2 * C, vb->d, C);
     ALLOC_BF(wo, (size_t)C * C) ALLOC_BF(w1, (size_t)F * C) ALLOC_BF(w2, (size_t)C * F)
     if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo, l1->d)) return r;
-    if (int r = pack(f1w->d, (int)F, (int)C, (int)C, w1)) return r;
+    if (int r = pack(f1w->d, (int)F, (int)C, (int)C, w1, nullptr, g2)) return r;
     if (int r = pack(f2w->d, (int)C, (int)F, (int)F, w2, l2->d)) return r;
     L.Wqkv = wqkv; L.bqkv = bqkv; L.Wo = wo; L.W1 = w1; L.W2 = w2;
+    L.s_qkv = L.c_qkv = L.s_1 = L.c_1 = nullptr;
+    if (h->lnfold) {
+      ALLOC_F(sq, (size_t)3 * C) ALLOC_F(cq, (size_t)3 * C) ALLOC_F(s1v, (size_t)F) ALLOC_F(c1v, (size_t)F)
+      const float* wsrc[3] = {qw->d, kw->d, vw->d};
+      for (int part = 0; part < 3; ++part)
+        HIPCHK(cs_ln_fold_consts_launch(wqkv + (size_t)part * C * C, (int)C, wsrc[part], n1b->d, bqkv + part * C, (int)C, (int)C,
+                                        sq + part * C, cq + part * C, st));
+      HIPCHK(cs_ln_fold_consts_launch(w1, (int)C, f1w->d, n2b->d, f1b->d, (int)F, (int)C, s1v, c1v, st));
+      L.s_qkv = sq; L.c_qkv = cq; L.s_1 = s1v; L.c_1 = c1v;
+    }
   }
   { NEED(g, "backbone.layernorm.weight", C) NEED(b, "backbone.layernorm.bias", C) h->lnfg = g->d; h->lnfb = b->d; }
   { NEED(pe, "pos_enc_fn.PE", 1, c.pe_h, c.pe_w, C) h->pe = pe->d; }
@@ -512,24 +541,57 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
     float* x = p.x[slot]; bf16_t* u = p.u[slot]; bf16_t* r1 = p.r1[slot];
     const int Mc = ic * p.T;
     L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, s), "im2col"); L.end();
-    L.begin(32, 0); L.misc(cs_cls_rows_launch(x, ic, p.T, C, h->cls, h->pos_tab, s), "cls"); L.end();
+    const bool fold = h->lnfold;
+    bf16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
+    L.begin(32, 0);
+    L.misc(cs_cls_rows_launch(x, ic, p.T, C, h->cls, h->pos_tab, fold ? u : nullptr, fold ? stats : nullptr, h->ln_sp, s), "cls");
+    L.end();
     {
       CsGemmParams g = gp(r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, x, C);
       g.pos = h->pos_tab; g.Np = p.Np;
+      if (fold) { g.out_bf16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }  // bf16 rows + LayerNorm partial sums for layer 0
       L.gemm(g, CS_EPI_PATCH_F32, 3.0 * P * P);
     }
     for (int l = 0; l < c.enc_layers; ++l) {
       const EncLayer& E = h->enc[l];
+      const bool last = l == c.enc_layers - 1;
+      CsAttnParams a{};
+      a.Q = r1; a.K = r1 + C; a.V = r1 + 2 * C;
+      a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+      a.q_bs = a.k_bs = a.v_bs = (long long)p.T * 3 * C; a.o_bs = (long long)p.T * C;
+      a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = LOG2E / std::sqrt((float)enc_dh); a.lse = nullptr;
+      if (fold) {
+        // u holds bf16(x) and `stats` the per-row partial sums, both written by the epilogue that produced x: LayerNorm is
+        // applied inside the consuming projection's epilogue (CS_EPI_LN_*), there is no separate LN pass over x
+        {
+          CsGemmParams g = gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C);
+          g.col_s = E.s_qkv; g.ln_part = stats; g.ln_sp = h->ln_sp; g.ln_eps = 1e-6f;
+          L.gemm(g, CS_EPI_LN_BF16);
+        }
+        a.O = ob;
+        L.attn(a, enc_dh, ic);
+        {
+          CsGemmParams g = gp(ob, C, E.Wo, C, Mc, C, C, E.bo, x, C);
+          g.resid = x; g.ldr = C; g.out_bf16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp;
+          L.gemm(g, CS_EPI_RESID_F32_LN);
+        }
+        {
+          CsGemmParams g = gp(u, C, E.W1, C, Mc, F, C, E.c_1, r1, F);
+          g.col_s = E.s_1; g.ln_part = stats; g.ln_sp = h->ln_sp; g.ln_eps = 1e-6f;
+          L.gemm(g, CS_EPI_LN_GELU_BF16);
+        }
+        {
+          CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);
+          g.resid = x; g.ldr = C;
+          if (!last) { g.out_bf16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }
+          L.gemm(g, last ? CS_EPI_RESID_F32 : CS_EPI_RESID_F32_LN);  // the final LayerNorm reads the fp32 stream
+        }
+        continue;
+      }
       L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, u, s), "ln1"); L.end();
       L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.bqkv, r1, 3 * C), CS_EPI_BIAS_BF16);
-      {
-        CsAttnParams a{};
-        a.Q = r1; a.K = r1 + C; a.V = r1 + 2 * C; a.O = u;
-        a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
-        a.q_bs = a.k_bs = a.v_bs = (long long)p.T * 3 * C; a.o_bs = (long long)p.T * C;
-        a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = LOG2E / std::sqrt((float)enc_dh); a.lse = nullptr;
-        L.attn(a, enc_dh, ic);
-      }
+      a.O = u;
+      L.attn(a, enc_dh, ic);
       {
         CsGemmParams g = gp(u, C, E.Wo, C, Mc, C, C, E.bo, x, C);
         g.resid = x; g.ldr = C;
@@ -698,10 +760,13 @@ int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, do
 // ---------------------------------------------------------------------------------------------------------
 int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
                const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np, int gw, int P, int act,
-               float powp, cs_stream stream) {
+               float powp, uint16_t* out_bf16, float* stats_out, int stats_sp, const float* ln_part, int ln_sp, const float* col_s,
+               float ln_eps, cs_stream stream) {
   CsGemmParams g = gp(A, lda, W, ldw, M, N, K, bias, out, ldc);
+  g.out_bf16 = out_bf16; g.stats_out = stats_out; g.stats_sp = stats_sp; g.ln_part = ln_part; g.ln_sp = ln_sp; g.col_s = col_s;
+  g.ln_eps = ln_eps;
   g.resid = resid; g.ldr = ldr; g.pos = pos; g.Np = Np; g.gw = gw; g.P = P; g.act = act; g.powp = powp;
-  if (epi < 0 || epi > CS_EPI_HEAD_SCORE) return fail(CS_ERR_BAD_ARG, "gemm: unknown epilogue %d", epi);
+  if (epi < 0 || epi > CS_EPI_RESID_F32_LN) return fail(CS_ERR_BAD_ARG, "gemm: unknown epilogue %d", epi);
   if (const char* e = cs_gemm_check(&g, epi)) return fail(CS_ERR_BAD_ARG, "%s", e);
   HIPCHK(cs_gemm_launch(&g, epi, (hipStream_t)stream));
   return 0;
@@ -755,9 +820,17 @@ int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, fl
   return 0;
 }
 
-int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, cs_stream stream) {
+int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
+                    cs_stream stream) {
   if (!w || !out || rows <= 0 || K <= 0 || ldo < K) return fail(CS_ERR_BAD_ARG, "pack_bf16: bad arguments");
-  HIPCHK(cs_pack_bf16_launch(w, rows, K, out, ldo, row_scale, (hipStream_t)stream));
+  HIPCHK(cs_pack_bf16_launch(w, rows, K, out, ldo, row_scale, col_scale, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_ln_fold_consts(const uint16_t* w_packed, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
+                         float* s_out, float* c_out, cs_stream stream) {
+  if (!w_packed || !w || !beta || !s_out || !c_out || N <= 0 || K <= 0 || ldp < K) return fail(CS_ERR_BAD_ARG, "ln_fold_consts: bad arguments");
+  HIPCHK(cs_ln_fold_consts_launch(w_packed, ldp, w, beta, bias, N, K, s_out, c_out, (hipStream_t)stream));
   return 0;
 }
 

@@ -46,6 +46,12 @@ enum CsEpilogue {
   CS_EPI_RESID_F32 = 4,        // out_f32[m][n] = (resid? resid[m][n]:0) + (scale? scale[n]:1)*(acc+bias[n])
   CS_EPI_PATCH_F32 = 5,        // out_f32[(m + m/Np + 1)][n] = acc + bias[n] + pos[(m%Np+1)][n]
   CS_EPI_HEAD_SCORE = 6,       // score[b][P*i+py][P*j+px] = act(acc + bias[n]), m=b*Np+i*gw+j, n=py*P+px
+  // LayerNorm folded into the consuming projection (no separate LN pass over the fp32 residual stream):
+  //   LN(x) W^T + b = rstd[m] * (bf16(x) W'^T - mu[m] * s[n]) + c[n],  W' = W*gamma (per input column), s[n] = sum_k W'[n][k],
+  //   c[n] = b[n] + sum_k beta[k] W[n][k];  mu / rstd come from per-row partial sums the PRODUCING epilogue wrote.
+  CS_EPI_LN_BF16 = 7,          // out_bf16 = rstd*(acc - mu*s) + c
+  CS_EPI_LN_GELU_BF16 = 8,     // ... then GELU
+  CS_EPI_RESID_F32_LN = 9,     // CS_EPI_RESID_F32 + bf16 copy of the new rows + their partial (sum, sum of squares)
 };
 
 struct CsGemmParams {
@@ -66,10 +72,16 @@ struct CsGemmParams {
   int P;              // patch size (head)
   int act;            // 0 sigmoid, 1 tanh
   float powp;         // 1 -> identity
+  // LayerNorm fold (see CS_EPI_LN_*): producer side (RESID_F32_LN, PATCH_F32) ...
+  bf16_t* out_bf16;    // [rows][ldc] bf16 copy of the fp32 rows written (the next GEMM's A operand), or null
+  float* stats_out;    // [rows][stats_sp][2] partial (sum, sumsq) per row: slot = column_tile*4 + wave, or null
+  int stats_sp;
+  // ... consumer side (LN_BF16, LN_GELU_BF16); `bias` carries c[n]
+  const float* ln_part;  // [M][ln_sp][2] partial sums of the A rows (fp32 values before bf16 rounding)
+  int ln_sp;             // 4, 8 or 16
+  const float* col_s;    // [N] s[n]
+  float ln_eps;
   int ablate;         // debug timing builds only (CS_ABLATE); 0 in the product
-  int stagger_ticks;  // start delay (100 MHz ticks) of every other resident block; 0 = none
-  int stagger_mode;   // 0: second half of the slots, 1: odd slots
-  int tall;           // 1: 256-row tiles (8 waves, 1 block/CU) where M is large; 0: 128-row tiles (2 blocks/CU)
 };
 
 struct CsAttnParams {

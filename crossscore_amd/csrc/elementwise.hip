@@ -157,12 +157,25 @@ __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __rest
   }
 }
 
-// CLS rows of the residual stream: x[img*T][c] = cls[c] + pos[0][c]  (HF:108-112)
-__global__ void cls_rows_kernel(float* x, int I, int T, int C, const float* cls, const float* pos) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= I * C) return;
-  const int img = i / C, c = i - img * C;
-  x[(size_t)img * T * C + c] = cls[c] + pos[c];
+// CLS rows of the residual stream: x[img*T][c] = cls[c] + pos[0][c]  (HF:108-112).  One wave per image.  With the LayerNorm
+// fold the row also gets its bf16 copy and its (sum, sumsq) in partial slot 0 (the other slots are zeroed).
+__global__ __launch_bounds__(64) void cls_rows_kernel(float* x, int I, int T, int C, const float* cls, const float* pos, bf16_t* xb,
+                                                      float* stats, int sp) {
+  const int img = blockIdx.x, lane = threadIdx.x;
+  const size_t row = (size_t)img * T;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = cls[c] + pos[c];
+    x[row * C + c] = v;
+    if (xb) xb[row * C + c] = f2bf(v);
+    s1 += v;
+    s2 += v * v;
+  }
+  if (stats) {
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    for (int k = lane; k < 2 * sp; k += 64) stats[row * sp * 2 + k] = k == 0 ? s1 : (k == 1 ? s2 : 0.f);
+  }
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -229,13 +242,32 @@ __global__ void pe_bilinear_kernel(const float* __restrict__ pe, int ph, int pw,
 // fp32 -> bf16 weight packing (K-contiguous rows; optional zero padding of K to ldo; optional per-output-row scale:
 // LayerScale lambda folded into the projection, HF modeling_dinov2.py:277-278, so the GEMM epilogue has no scale operand)
 __global__ void pack_bf16_kernel(const float* __restrict__ w, int rows, int K, bf16_t* __restrict__ out, int ldo,
-                                 const float* __restrict__ row_scale) {
+                                 const float* __restrict__ row_scale, const float* __restrict__ col_scale) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)rows * ldo) return;
   const int k = (int)(i % ldo);
   const long long rr = i / ldo;
-  const float sc = row_scale ? row_scale[rr] : 1.0f;
+  const float sc = (row_scale ? row_scale[rr] : 1.0f) * ((col_scale && k < K) ? col_scale[k] : 1.0f);
   out[i] = k < K ? f2bf(w[rr * K + k] * sc) : (bf16_t)0;
+}
+
+// LayerNorm fold constants of one projection (see CS_EPI_LN_* in cs_common.h), one wave per output row n:
+//   s[n] = sum_k float(Wp[n][k])            over the PACKED bf16 weights W' = W*gamma (what the MFMA really multiplies)
+//   c[n] = bias[n] + sum_k beta[k] W[n][k]   in fp32 from the original weights
+__global__ __launch_bounds__(256) void ln_fold_consts_kernel(const bf16_t* __restrict__ wp, int ldp, const float* __restrict__ w,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias, int N,
+                                                             int K, float* __restrict__ s_out, float* __restrict__ c_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s = 0.f, c = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    s += bf2f(wp[(size_t)n * ldp + k]);
+    c += beta[k] * w[(size_t)n * K + k];
+  }
+  s = wave_sum(s);
+  c = wave_sum(c);
+  if (lane == 0) { s_out[n] = s; c_out[n] = c + (bias ? bias[n] : 0.f); }
 }
 
 __global__ void vec_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
@@ -317,8 +349,15 @@ hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int
   return hipGetLastError();
 }
 
-hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, hipStream_t st) {
-  hipLaunchKernelGGL(cls_rows_kernel, dim3((I * C + 255) / 256), dim3(256), 0, st, x, I, T, C, cls, pos);
+hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, bf16_t* xb, float* stats, int sp,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(cls_rows_kernel, dim3(I), dim3(64), 0, st, x, I, T, C, cls, pos, xb, stats, sp);
+  return hipGetLastError();
+}
+
+hipError_t cs_ln_fold_consts_launch(const bf16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
+                                    float* s_out, float* c_out, hipStream_t st) {
+  hipLaunchKernelGGL(ln_fold_consts_kernel, dim3((N + 3) / 4), dim3(256), 0, st, wp, ldp, w, beta, bias, N, K, s_out, c_out);
   return hipGetLastError();
 }
 
@@ -334,9 +373,11 @@ hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh,
   return hipGetLastError();
 }
 
-hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, const float* row_scale, hipStream_t st) {
+hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, const float* row_scale, const float* col_scale,
+                               hipStream_t st) {
   const long long total = (long long)rows * ldo;
-  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, rows, K, out, ldo, row_scale);
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, rows, K, out, ldo, row_scale,
+                     col_scale);
   return hipGetLastError();
 }
 

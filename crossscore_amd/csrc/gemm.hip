@@ -41,7 +41,7 @@ template <int NSUB> struct GemmCfg {
   static constexpr int WN = 16 * NSUB;                    // wave tile columns
   static constexpr int PROW_F = WN * 4 + 16;              // patch row (fp32), padded: conflict-free b128 writes
   static constexpr int PROW_H = WN * 2 + 16;              // patch row (bf16)
-  static constexpr int PATCH = 16 * PROW_F;               // one 16-row patch per wave
+  static constexpr int PATCH = 16 * PROW_F + (NSUB == 2 ? 512 : 0);  // one 16-row patch per wave (+ room for the LN stash)
   static constexpr int LDS = RING + 4 * PATCH;            // 73.3 / 57.2 KiB -> two blocks per CU
 };
 
@@ -104,15 +104,56 @@ __device__ __forceinline__ void patch_read16(unsigned addr, unsigned stride, f32
   }
 }
 
+// LN-folded consumer step: (mu, rstd) of the lane's row (8 bytes) from the wave's stash
+__device__ __forceinline__ u32x2_t patch_read8(unsigned addr) {
+  u32x2_t r;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
+  return r;
+}
+
+// (sum, sum of squares) of one lane's 4 values, reduced over the LPR lanes that hold a row.  One helper with explicit fma order
+// for the full-tile and the ragged path: with -ffp-contract the compiler would otherwise fuse the two copies differently, and
+// a row's LayerNorm statistics (hence every later bf16 rounding) would depend on which tile the row fell into.
+// The total lands in the LAST lane of the row (lane % LPR == LPR-1).  LPR == 16 is one DPP row: four v_add with row_shr
+// (no LDS crossbar traffic, which ds_bpermute-based shuffles would put into every epilogue step).
+template <int SHR>
+__device__ __forceinline__ float dpp_row_shr_add(float v) {
+  // row_shr:SHR = 0x110 + SHR; bound_ctrl: lanes shifted in from outside the row read 0
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + SHR, 0xf, 0xf, true);
+  return v + __int_as_float(moved);
+}
+template <int LPR>
+__device__ __forceinline__ void row_partial(f32x4_t v, bool on, float& a, float& b) {
+  a = on ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+  b = on ? fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))) : 0.f;
+  if constexpr (LPR == 16) {
+    a = dpp_row_shr_add<1>(a); b = dpp_row_shr_add<1>(b);
+    a = dpp_row_shr_add<2>(a); b = dpp_row_shr_add<2>(b);
+    a = dpp_row_shr_add<4>(a); b = dpp_row_shr_add<4>(b);
+    a = dpp_row_shr_add<8>(a); b = dpp_row_shr_add<8>(b);
+  } else {  // 8 lanes per row (128-wide tiles): xor butterfly, then hand the total to the row's last lane like the DPP form
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+      a += __shfl_xor(a, o, 64);
+      b += __shfl_xor(b, o, 64);
+    }
+  }
+}
+
 template <int EPI> struct EpiTraits {
+  static constexpr bool kLN = EPI == CS_EPI_LN_BF16 || EPI == CS_EPI_LN_GELU_BF16;           // LayerNorm-folded consumer
   static constexpr bool kHalf = EPI == CS_EPI_BIAS_BF16 || EPI == CS_EPI_BIAS_GELU_BF16 || EPI == CS_EPI_BIAS_RELU_BF16 ||
-                                EPI == CS_EPI_BIAS_LEAKY_BF16;
+                                EPI == CS_EPI_BIAS_LEAKY_BF16 || kLN;
+  static constexpr bool kResid = EPI == CS_EPI_RESID_F32 || EPI == CS_EPI_RESID_F32_LN;
+  static constexpr bool kLnOut = EPI == CS_EPI_RESID_F32_LN || EPI == CS_EPI_PATCH_F32;      // may emit bf16 copy + row partials
 };
 
 // NSUB = 16-column sub-tiles per wave; block tile = 128 x (64*NSUB); 4 waves side by side in N, wave tile 128 x 16*NSUB.
-template <int EPI, int NSUB>
+// SPL = float4 loads per row of LayerNorm partial sums (LN-folded consumers only: ln_sp / 2).
+template <int EPI, int NSUB, int SPL>
 __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   using Cfg = GemmCfg<NSUB>;
+  constexpr bool kLN = EpiTraits<EPI>::kLN, kResid = EpiTraits<EPI>::kResid, kLnOut = EpiTraits<EPI>::kLnOut;
   constexpr int BN = Cfg::BN, NS = Cfg::NS, D = Cfg::D, LPS = Cfg::LPS, STAGE_BYTES = Cfg::STAGE_BYTES;
   static_assert(D == 2, "the vmcnt bookkeeping below tracks exactly two iterations of epilogue traffic");
   constexpr bool kHalf = EpiTraits<EPI>::kHalf;
@@ -122,8 +163,15 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   constexpr int RPI = 64 / LPR;                                            // rows per ds_read / global access
   constexpr int NRD = 16 / RPI;                                            // accesses per 16-row step: 2/1 (bf16), 4/2 (fp32)
   constexpr int PROW = kHalf ? Cfg::PROW_H : Cfg::PROW_F;
-  // vector-memory instructions one full-tile epilogue step issues (stores, + as many addend loads for RESID / PATCH)
-  constexpr int VE = kHalf ? NRD : 2 * NRD;
+  // vector-memory instructions one full-tile epilogue step issues: stores (+ the row partials of an LN-folded consumer);
+  // stores + as many addend loads for RESID / PATCH (+ bf16 copy + row partials when those are emitted)
+  constexpr int VE = kHalf ? NRD : (kLnOut ? 4 * NRD : 2 * NRD);
+  // LN-folded consumer: behind the bf16 patch rows each wave keeps s[n], c[n] of the tile's columns and (mu, rstd) of the
+  // tile's 128 rows, filled once per tile, so the epilogue steps issue no vector-memory loads (a load consumed inside a
+  // step would wait for every older LDS-DMA: the queue retires in order)
+  constexpr int STASH = 16 * Cfg::PROW_H;
+  constexpr int MRST = STASH + 2 * Cfg::WN * 4;
+  static_assert(!kLN || MRST + 128 * 8 <= Cfg::PATCH, "stash does not fit the patch");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -210,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   const unsigned pw_addr = patch_lds + (lane & 15) * PROW + (lane >> 4) * (kHalf ? 8 : 16);
   const int rrow = lane / LPR, rch = lane % LPR;
   const unsigned pr_addr = patch_lds + rrow * PROW + (rch < CPR ? rch : CPR - 1) * 16;
+  const unsigned stash_addr = patch_lds + STASH + (lane >> 4) * 16;  // + j*64 (s), + WN*4 + j*64 (c)
 
   f32x4_t acc[8][NSUB], prv[8][NSUB];
   bool have_prev = false, prev_full = false;
@@ -250,12 +299,24 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
       return -1;
     } else {
       // 1) activation in the accumulator layout, then into the patch
+      float ln_mu = 0.f, ln_rs = 1.f;
+      if constexpr (kLN) {  // LayerNorm statistics of this lane's row (stashed at the tile switch)
+        const u32x2_t mr = patch_read8(patch_lds + MRST + (I * 16 + (lane & 15)) * 8);
+        ln_mu = __uint_as_float(mr[0]);
+        ln_rs = __uint_as_float(mr[1]);
+      }
 #pragma unroll
       for (int j = 0; j < NSUB; ++j) {
         float v[4] = {prv[I][j][0], prv[I][j][1], prv[I][j][2], prv[I][j][3]};
+        if constexpr (kLN) {
+          f32x4_t sc[2];
+          patch_read16<2>(stash_addr + j * 64, Cfg::WN * 4, sc);  // s then c of these 4 columns
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(fmaf(-ln_mu, sc[0][r], v[r]), ln_rs, sc[1][r]);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if constexpr (EPI == CS_EPI_BIAS_GELU_BF16) v[r] = gelu_erf(v[r]);
+          if constexpr (EPI == CS_EPI_BIAS_GELU_BF16 || EPI == CS_EPI_LN_GELU_BF16) v[r] = gelu_erf(v[r]);
           if constexpr (EPI == CS_EPI_BIAS_RELU_BF16) v[r] = fmaxf(v[r], 0.f);
           if constexpr (EPI == CS_EPI_BIAS_LEAKY_BF16) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
         }
@@ -270,10 +331,13 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
       patch_read16<NRD>(pr_addr, RPI * PROW, seg);
       const int mrow0 = pm0 + I * 16 + rrow;
       const int n = ncol0 + rch * (kHalf ? 8 : 4);
-      if (prev_full && (EPI != CS_EPI_RESID_F32 || p.resid)) {
+      [[maybe_unused]] const int st_slot = (pn0 / BN) * 4 + wn;
+      [[maybe_unused]] const bool ln_out = kLnOut && p.out_bf16 && p.stats_out;
+      if (prev_full && (!kResid || p.resid) && (!kLnOut || EPI == CS_EPI_PATCH_F32 || ln_out) &&
+          (EPI != CS_EPI_PATCH_F32 || ln_out)) {
         // every row and column of the tile exists: no row tests, a fixed number (VE) of memory instructions
         if (rch < CPR) {
-          if constexpr (EPI == CS_EPI_RESID_F32) {
+          if constexpr (kResid) {
 #pragma unroll
             for (int q = 0; q < NRD; ++q)
               seg[q] += *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)(mrow0 + q * RPI) * p.ldr + n);
@@ -289,30 +353,57 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
             const int m = mrow0 + q * RPI;
             if constexpr (kHalf) {
               *reinterpret_cast<f32x4_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n) = seg[q];
-            } else if constexpr (EPI == CS_EPI_RESID_F32) {
-              *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = seg[q];
-            } else {  // CS_EPI_PATCH_F32: token row m of image img lands at row m + img + 1 (CLS rows interleaved)
-              *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)(m + m / p.Np + 1) * p.ldc + n) = seg[q];
+            } else {
+              // CS_EPI_PATCH_F32: token row m of image img lands at row m + img + 1 (CLS rows interleaved)
+              const size_t row = EPI == CS_EPI_PATCH_F32 ? (size_t)(m + m / p.Np + 1) : (size_t)m;
+              *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + row * p.ldc + n) = seg[q];
+              if constexpr (kLnOut)
+                *reinterpret_cast<u32x2_t*>(p.out_bf16 + row * p.ldc + n) =
+                    u32x2_t{pack_bf16x2(seg[q][0], seg[q][1]), pack_bf16x2(seg[q][2], seg[q][3])};
             }
+          }
+        }
+        if constexpr (kLnOut) {  // per-row partial (sum, sumsq) of this wave's columns; reduction over the LPR lanes of a row
+#pragma unroll
+          for (int q = 0; q < NRD; ++q) {
+            float a, b;
+            row_partial<LPR>(seg[q], rch < CPR, a, b);
+            const int m = mrow0 + q * RPI;
+            const size_t row = EPI == CS_EPI_PATCH_F32 ? (size_t)(m + m / p.Np + 1) : (size_t)m;
+            if (rch == LPR - 1) *reinterpret_cast<float2*>(p.stats_out + (row * p.stats_sp + st_slot) * 2) = make_float2(a, b);
           }
         }
         return VE;
       }
-      // ragged tile (or no residual operand): per-row tests, data-dependent instruction count
+      // ragged tile (or no residual / LN outputs): per-row tests, data-dependent instruction count
       const bool col_ok = rch < CPR && n < p.N;
 #pragma unroll
       for (int q = 0; q < NRD; ++q) {
         const int m = mrow0 + q * RPI;
-        if (col_ok && m < p.M) {
+        const bool ok = col_ok && m < p.M;
+        [[maybe_unused]] size_t row = (size_t)m;
+        if (ok) {
           if constexpr (kHalf) {
             *reinterpret_cast<f32x4_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n) = seg[q];
-          } else if constexpr (EPI == CS_EPI_RESID_F32) {
-            if (p.resid) seg[q] += *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m * p.ldr + n);
-            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = seg[q];
           } else {
-            seg[q] += *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)(m % p.Np + 1) * p.ldc + n);
-            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)(m + m / p.Np + 1) * p.ldc + n) = seg[q];
+            if constexpr (kResid) {
+              if (p.resid) seg[q] += *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m * p.ldr + n);
+            } else {
+              seg[q] += *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)(m % p.Np + 1) * p.ldc + n);
+              row = (size_t)(m + m / p.Np + 1);
+            }
+            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + row * p.ldc + n) = seg[q];
+            if constexpr (kLnOut)
+              if (p.out_bf16)
+                *reinterpret_cast<u32x2_t*>(p.out_bf16 + row * p.ldc + n) =
+                    u32x2_t{pack_bf16x2(seg[q][0], seg[q][1]), pack_bf16x2(seg[q][2], seg[q][3])};
           }
+        }
+        if constexpr (kLnOut) {
+          float a, b;
+          row_partial<LPR>(seg[q], ok, a, b);
+          if (EPI == CS_EPI_PATCH_F32 && m < p.M) row = (size_t)(m + m / p.Np + 1);
+          if (p.stats_out && rch == LPR - 1 && m < p.M) *reinterpret_cast<float2*>(p.stats_out + (row * p.stats_sp + st_slot) * 2) = make_float2(a, b);
         }
       }
       return -1;
@@ -347,14 +438,16 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-      // W fragments + three A fragments up front, then one A-fragment read per MFMA group, two groups ahead of its use
-      __builtin_amdgcn_sched_group_barrier(0x100, NSUB + 3, 0);
+      // W fragments + LOOK A fragments up front, then one A-fragment read per MFMA group, LOOK-1 groups ahead of its use
+      // (the LN-folded consumers are at the 256-register limit: one fragment less in flight avoids spills)
+      constexpr int LOOK = (kLN && NSUB == 3) ? 2 : 3;
+      __builtin_amdgcn_sched_group_barrier(0x100, NSUB + LOOK, 0);
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < 8 - LOOK; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, NSUB, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 3 * NSUB, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, LOOK * NSUB, 0);
     }
     int ve = 0;
     if constexpr (STEP >= 0) {
@@ -373,11 +466,11 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
       const int n = min(cn0 + wn * Cfg::WN + j * 16 + (lane >> 4) * 4, p.N - 4);
-      const f32x4_t b4 = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const f32x4_t b4 = (p.bias && !kLN) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i][j] = b4;
     }
-    if (p.bias) ve1 = -1;  // the bias loads joined the queue and are consumed at once: the next wait drains it
+    if (p.bias && !kLN) ve1 = -1;  // the bias loads joined the queue and are consumed at once: the next wait drains it
     int kt = 0;
     // the first 8 slices carry the previous tile's 8 epilogue steps
 #define CS_SLICE_WITH_STEP(E)                                                              \
@@ -395,6 +488,37 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
     have_prev = true;
     pm0 = cm0; pn0 = cn0;
     prev_full = (cm0 + BM <= p.M) && (cn0 + BN <= p.N);
+    if constexpr (kLN) {  // s[n], c[n] of the finished tile's columns and (mu, rstd) of its rows -> wave-private stash
+      {
+        const float invc = 1.0f / (float)p.K;
+        float mr4[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // lane l owns rows 2l, 2l+1 of the tile; partial sums come from the producing epilogue
+          const int mrow = min(cm0 + 2 * lane + h, p.M - 1);
+          const f32x4_t* pp = reinterpret_cast<const f32x4_t*>(p.ln_part + (size_t)mrow * (2 * SPL) * 2);
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int q = 0; q < SPL; ++q) {
+            const f32x4_t t4 = pp[q];
+            s1 += t4[0] + t4[2];
+            s2 += t4[1] + t4[3];
+          }
+          const float mu = s1 * invc;
+          mr4[2 * h] = mu;
+          mr4[2 * h + 1] = 1.0f / sqrtf(fmaxf(s2 * invc - mu * mu, 0.f) + p.ln_eps);
+        }
+        patch_write16(patch_lds + MRST + lane * 16, f32x4_t{mr4[0], mr4[1], mr4[2], mr4[3]});
+      }
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+          const int n = min(cn0 + wn * Cfg::WN + j * 16 + (lane >> 4) * 4, p.N - 4);
+          patch_write16(stash_addr + j * 64, *reinterpret_cast<const f32x4_t*>(p.col_s + n));
+          patch_write16(stash_addr + Cfg::WN * 4 + j * 64, *reinterpret_cast<const f32x4_t*>(p.bias + n));
+        }
+      }
+      ve1 = -1;  // those loads are consumed at once: the next wait drains the queue
+    }
   }
   if (have_prev) {  // flush the last tile
     (void)epi_step(std::integral_constant<int, 0>{}); (void)epi_step(std::integral_constant<int, 1>{});
@@ -406,13 +530,13 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
 
 int g_num_cus = 0;
 
-template <int EPI, int NSUB>
+template <int EPI, int NSUB, int SPL>
 hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   constexpr int BN = 64 * NSUB;
   constexpr int LDS = GemmCfg<NSUB>::LDS;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm_kernel<EPI, NSUB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm_kernel<EPI, NSUB, SPL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
@@ -432,20 +556,39 @@ hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   const int need = ((tiles_m + 7) / 8) * tiles_n * 8;
   if (grid > need) grid = need;
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((cs_gemm_kernel<EPI, NSUB>), dim3(grid), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((cs_gemm_kernel<EPI, NSUB, SPL>), dim3(grid), dim3(256), LDS, stream, p);
   return hipGetLastError();
 }
 
 template <int EPI>
 hipError_t launch(const CsGemmParams& p, hipStream_t stream) {
   // column tile: 192 where it divides N (every N of the path is a multiple of 384, 128 or the 196-wide head), else 128
-  if (p.N % 192 == 0) return launch_n<EPI, 3>(p, stream);
-  return launch_n<EPI, 2>(p, stream);
+  if constexpr (EpiTraits<EPI>::kLN) {
+    if (p.N % 192 == 0) {
+      if (p.ln_sp == 4) return launch_n<EPI, 3, 2>(p, stream);
+      if (p.ln_sp == 8) return launch_n<EPI, 3, 4>(p, stream);
+      return launch_n<EPI, 3, 8>(p, stream);
+    }
+    if (p.ln_sp == 4) return launch_n<EPI, 2, 2>(p, stream);
+    if (p.ln_sp == 8) return launch_n<EPI, 2, 4>(p, stream);
+    return launch_n<EPI, 2, 8>(p, stream);
+  } else {
+    if (p.N % 192 == 0) return launch_n<EPI, 3, 0>(p, stream);
+    return launch_n<EPI, 2, 0>(p, stream);
+  }
 }
 
 }  // namespace
 
+// column tile the launcher picks for N (the LayerNorm partial-sum slots of a producer are 4 per column tile)
+extern "C" int cs_gemm_column_tiles(int N) { return N % 192 == 0 ? N / 192 : (N + 127) / 128; }
+
+namespace {
+
+}  // namespace
+
 // Host-side shape contract (checked here so a bad call fails loudly instead of faulting on the GPU).
+extern "C" int cs_gemm_column_tiles(int N);
 extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
   if (p->M <= 0 || p->N <= 0 || p->K <= 0) return "gemm: empty shape";
   if (p->K % 64) return "gemm: K must be a multiple of 64";
@@ -455,7 +598,13 @@ extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
   if (p->lda < p->K || p->ldw < p->K) return "gemm: lda/ldw smaller than K";
   if (!p->A || !p->W || !p->out) return "gemm: null operand";
   if (p->scale) return "gemm: a per-column scale is folded into the packed weights (cs_op_pack_bf16 row_scale), it is not an epilogue operand";
-  if (epi == CS_EPI_RESID_F32 && p->resid && p->ldr % 4) return "gemm: ldr must be a multiple of 4";
+  if ((epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN) && p->resid && p->ldr % 4) return "gemm: ldr must be a multiple of 4";
+  if (epi == CS_EPI_RESID_F32_LN && (!p->out_bf16 || !p->stats_out)) return "gemm: RESID_F32_LN needs out_bf16 and stats_out";
+  if ((epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32) && p->stats_out && p->stats_sp != 4 * cs_gemm_column_tiles(p->N))
+    return "gemm: stats_sp must be 4 x the number of column tiles";
+  if ((epi == CS_EPI_LN_BF16 || epi == CS_EPI_LN_GELU_BF16) &&
+      (!p->ln_part || !p->col_s || !p->bias || (p->ln_sp != 4 && p->ln_sp != 8 && p->ln_sp != 16) || p->N % 8 || p->ldc % 8))
+    return "gemm: LayerNorm-folded epilogue needs ln_part, col_s, bias (= c), ln_sp in {4,8,16}";
   if (epi == CS_EPI_PATCH_F32 && (!p->pos || p->Np <= 0 || p->M % p->Np)) return "gemm: bad patch epilogue params";
   if (epi == CS_EPI_HEAD_SCORE && (p->Np <= 0 || p->gw <= 0 || p->Np % p->gw || p->M % p->Np || p->N != p->P * p->P))
     return "gemm: bad head epilogue params";
@@ -477,6 +626,9 @@ extern "C" hipError_t cs_gemm_launch(const CsGemmParams* p0, int epi, hipStream_
     case CS_EPI_RESID_F32: return launch<CS_EPI_RESID_F32>(*p, stream);
     case CS_EPI_PATCH_F32: return launch<CS_EPI_PATCH_F32>(*p, stream);
     case CS_EPI_HEAD_SCORE: return launch<CS_EPI_HEAD_SCORE>(*p, stream);
+    case CS_EPI_LN_BF16: return launch<CS_EPI_LN_BF16>(*p, stream);
+    case CS_EPI_LN_GELU_BF16: return launch<CS_EPI_LN_GELU_BF16>(*p, stream);
+    case CS_EPI_RESID_F32_LN: return launch<CS_EPI_RESID_F32_LN>(*p, stream);
   }
   return hipErrorInvalidValue;
 }

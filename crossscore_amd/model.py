@@ -100,6 +100,7 @@ class CrossScoreNet(torch.nn.Module):
         self._dirty = True
         self.enc_chunk_images = 0  # 0 = library default
         self.lanes = 0             # 0 = library default (2 concurrent lanes); 1 = serial
+        self.ln_fold = 0           # 1 = fold the encoder LayerNorms into the QKV / fc1 GEMM epilogues (opt-in; slower so far)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
     # -- weights ----------------------------------------------------------------------------------------------
@@ -130,7 +131,8 @@ class CrossScoreNet(torch.nn.Module):
         cc = _lib.CsConfig(hidden=a.hidden, enc_layers=a.enc_layers, enc_heads=a.enc_heads, mlp_ratio=a.mlp_ratio, patch=a.patch,
                            pos_grid=a.pos_grid, pe_h=a.pe_h, pe_w=a.pe_w, dec_layers=a.dec_layers, dec_heads=a.dec_heads,
                            do_self_attn=int(bool(m.decoder_do_self_attn)), do_short_cut=int(bool(m.decoder_do_short_cut)),
-                           act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), lanes=int(self.lanes))
+                           act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold),
+                           lanes=int(self.lanes))
         with torch.cuda.device(device):
             h = lib.cs_create(C.byref(cc))
             if not h:

@@ -50,6 +50,8 @@ typedef struct cs_config {
   int act;           /* 0 sigmoid (metric.min == 0), 1 tanh (metric.min == -1), model/regression_layer.py:31-38 */
   float pow_p;       /* exponent after the activation; 1 = identity, model/regression_layer.py:40-62 */
   int enc_chunk_images; /* images per encoder pass (0 = library default) */
+  int ln_fold;       /* 1: encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass; opt-in, measured
+                      * slower on MI355X); 0: separate LayerNorm kernels (default) */
   int lanes;         /* internal streams that run independent image chunks / batch groups concurrently: 0 = default (2), 1 = serial, up to 4 */
 } cs_config;
 
@@ -97,7 +99,10 @@ int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, do
 /* out = epilogue(bias + A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. bf16 = raw uint16. */
 int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
                const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np,
-               int gw, int P, int act, float powp, cs_stream stream);
+               int gw, int P, int act, float powp,
+               /* LayerNorm fold (CsEpilogue 7-9): producer outputs, then consumer inputs; NULL / 0 when unused */
+               uint16_t* out_bf16, float* stats_out, int stats_sp, const float* ln_part, int ln_sp, const float* col_s,
+               float ln_eps, cs_stream stream);
 /* softmax(QK^T/sqrt(dh))V for `batch` x `heads`; strides in elements; lse may be NULL. */
 int cs_op_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* V, uint16_t* O, int ldq, int ldk, int ldv,
                     int ldo, long long q_bs, long long k_bs, long long v_bs, long long o_bs, int batch, int heads,
@@ -110,8 +115,15 @@ int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const floa
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream);
 int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream);
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
-/* fp32 [rows][K] -> bf16 [rows][ldo] (zero padded); row_scale (rows) may be NULL: LayerScale folded into a projection */
-int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, cs_stream stream);
+/* fp32 [rows][K] -> bf16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
+ * rows of a projection, LayerNorm gamma into its columns */
+int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
+                    cs_stream stream);
+/* LayerNorm fold constants of a projection: s[n] = sum_k packed W'[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] */
+int cs_op_ln_fold_consts(const uint16_t* w_packed, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
+                         float* s_out, float* c_out, cs_stream stream);
+/* number of column tiles the GEMM launcher uses for N output columns (LayerNorm partial-sum slots per row = 4 x this) */
+int cs_gemm_column_tiles(int N);
 
 #ifdef __cplusplus
 }

@@ -15,18 +15,20 @@ def _stream():
 
 
 def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_BF16, resid=None, out=None, pos=None, Np=0, gw=0, P=0, act=0, powp=1.0,
-         K=None, ldc=None):
+         K=None, ldc=None, out_bf16=None, stats_out=None, ln_part=None, col_s=None, ln_eps=1e-6):
     """A:(M,lda) bf16, W:(N,ldw) bf16 -> out (allocated here unless given)."""
     lib = _lib.load()
     M, lda = A.shape
     N, ldw = W.shape
     K = K or lda
     if out is None:
-        dt = torch.bfloat16 if epi <= _lib.EPI_BIAS_LEAKY_BF16 else torch.float32
+        dt = torch.bfloat16 if (epi <= _lib.EPI_BIAS_LEAKY_BF16 or epi in (_lib.EPI_LN_BF16, _lib.EPI_LN_GELU_BF16)) else torch.float32
         out = torch.zeros((M, N), dtype=dt, device=A.device)
     ldc = ldc or out.shape[-1]
     rc = lib.cs_op_gemm(_p(A), lda, _p(W), ldw, M, N, K, _p(bias), _p(resid), resid.shape[-1] if resid is not None else 0,
-                        _p(out), ldc, epi, _p(pos), Np, gw, P, act, powp, _stream())
+                        _p(out), ldc, epi, _p(pos), Np, gw, P, act, powp, _p(out_bf16), _p(stats_out),
+                        stats_out.shape[1] if stats_out is not None else 0, _p(ln_part), ln_part.shape[1] if ln_part is not None else 0,
+                        _p(col_s), ln_eps, _stream())
     _lib.check(rc)
     return out
 
@@ -88,10 +90,23 @@ def pe_bilinear(pe, gh, gw):
     return out
 
 
-def pack_bf16(w, ldo=None, row_scale=None):
+def pack_bf16(w, ldo=None, row_scale=None, col_scale=None):
     lib = _lib.load()
     rows, K = w.shape
     ldo = ldo or K
     out = torch.zeros((rows, ldo), dtype=torch.bfloat16, device=w.device)
-    _lib.check(lib.cs_op_pack_bf16(_p(w), rows, K, _p(out), ldo, _p(row_scale), _stream()))
+    _lib.check(lib.cs_op_pack_bf16(_p(w), rows, K, _p(out), ldo, _p(row_scale), _p(col_scale), _stream()))
     return out
+
+
+def ln_fold_consts(w_packed, w, beta, bias):
+    lib = _lib.load()
+    N, K = w.shape
+    s = torch.zeros(N, device=w.device)
+    c = torch.zeros(N, device=w.device)
+    _lib.check(lib.cs_op_ln_fold_consts(_p(w_packed), w_packed.shape[1], _p(w), _p(beta), _p(bias), N, K, _p(s), _p(c), _stream()))
+    return s, c
+
+
+def column_tiles(N):
+    return _lib.load().cs_gemm_column_tiles(N)

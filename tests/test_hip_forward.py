@@ -161,6 +161,25 @@ def test_reference_token_cache_is_bit_identical():
     assert torch.equal(cached["attn_weights_map_ref_cross"], full["attn_weights_map_ref_cross"])
 
 
+def test_layernorm_fold_matches_separate_layernorm_path():
+    """ln_fold=1 (LayerNorm applied inside the consuming GEMM epilogue) and the default separate-LayerNorm path are two
+    roundings of the same fp32 math: both within tolerance of the oracle; the fold must not be a silent no-op."""
+    net, arch, sd = _net("facebook/dinov2-small", 1)
+    q, r = synth.make_inputs(1, 2, 518, 518, 1)
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    plain = net(tq, tr, False, 0, False)["score_map_ref_cross"].clone()
+    net.ln_fold = 1
+    net._mark_dirty()
+    folded = net(tq, tr, False, 0, False)["score_map_ref_cross"].clone()
+    ref = _oracle(arch, sd, q, r)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    mae_f, _ = _compare(folded, ref)
+    mae_p, _ = _compare(plain, ref)
+    print(f"ln_fold MAE={mae_f:.2e}  separate-LN MAE={mae_p:.2e}  fold-vs-plain MAE={float((folded - plain).abs().mean()):.2e}")
+    assert mae_f < MAE_TOL and mae_p < MAE_TOL
+    assert not torch.equal(folded, plain)
+
+
 def test_bad_inputs_raise():
     net, arch, sd = _net(TINY, 2)
     q = torch.zeros(1, 3, 70, 70, device="cuda")

@@ -93,6 +93,73 @@ def test_gemm_resid_f32(M, with_scale, with_resid):
     assert (out - ref).abs().max() < 2e-4  # fp32 out; only accumulation order differs
 
 
+def _row_partials(x, sp):
+    """(sum, sumsq) of each row of x over the column ranges the producing epilogue's (column tile, wave) pairs own."""
+    M, Cc = x.shape
+    tiles = sp // 4
+    bn = Cc // tiles if Cc % 192 == 0 else 128
+    wn = bn // 4
+    out = torch.zeros((M, sp, 2), device=x.device)
+    for t in range(tiles):
+        for w in range(4):
+            c0 = t * bn + w * wn
+            seg = x[:, c0:min(c0 + wn, Cc)]
+            out[:, t * 4 + w, 0] = seg.sum(1)
+            out[:, t * 4 + w, 1] = (seg * seg).sum(1)
+    return out
+
+
+@pytest.mark.parametrize("M,Cc,N,epi", [(700, 384, 1152, _lib.EPI_LN_BF16), (1370, 384, 1536, _lib.EPI_LN_GELU_BF16),
+                                        (300, 128, 384, _lib.EPI_LN_BF16), (257, 768, 768, _lib.EPI_LN_GELU_BF16)])
+def test_gemm_layernorm_folded_consumer(M, Cc, N, epi):
+    """LN(x) W^T + b computed as rstd*(bf16(x) W'^T - mu*s) + c from the producer's per-row partial sums
+    (HF modeling_dinov2.py:365,373 LayerNorm -> query/key/value / fc1)."""
+    g = _rng(M + N)
+    x = _t(2.0 * g.standard_normal((M, Cc), dtype=np.float32) + 0.7)           # non-zero row means
+    gam = _t(1 + 0.2 * g.standard_normal((Cc,), dtype=np.float32))
+    bet = _t(0.1 * g.standard_normal((Cc,), dtype=np.float32))
+    Wf = _t(g.standard_normal((N, Cc), dtype=np.float32) / math.sqrt(Cc))
+    b = _t(0.1 * g.standard_normal((N,), dtype=np.float32))
+    sp = 4 * hh.column_tiles(Cc)
+    Wp = hh.pack_bf16(Wf, col_scale=gam)
+    assert torch.equal(Wp, _bf(Wf * gam[None, :]))
+    s, c = hh.ln_fold_consts(Wp, Wf, bet, b)
+    assert (s - Wp.float().sum(1)).abs().max() < 1e-4 and (c - (b + Wf @ bet)).abs().max() < 1e-4
+    part = _row_partials(x, sp)
+    out = hh.gemm(_bf(x), Wp, c, epi, ln_part=part, col_s=s, ln_eps=1e-6)
+    ref = orc.layer_norm(x.cpu(), gam.cpu(), bet.cpu(), 1e-6).to(DEV) @ Wf.t() + b
+    if epi == _lib.EPI_LN_GELU_BF16:
+        ref = orc.gelu_erf(ref.cpu()).to(DEV)
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs()
+    # bf16 rounding of x and of gamma*W (operands) + bf16 output: a few 1e-2 worst case on |ref| ~ 2, 3e-3 on average
+    assert err.max() < 6e-2 and err.mean() < 5e-3, (float(err.max()), float(err.mean()))
+
+
+@pytest.mark.parametrize("M,Cc", [(700, 384), (128, 384), (300, 128), (1370, 768)])
+def test_gemm_resid_producer_emits_bf16_rows_and_partials(M, Cc):
+    """RESID_F32_LN: x += A Wo^T + b, plus the bf16 copy of the new rows and their per-(tile, wave) partial sums."""
+    K = 256
+    g = _rng(M * 3 + Cc)
+    A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))
+    W = _bf(_t(g.standard_normal((Cc, K), dtype=np.float32) / math.sqrt(K)))
+    b = _t(g.standard_normal((Cc,), dtype=np.float32))
+    r = _t(g.standard_normal((M, Cc), dtype=np.float32))
+    sp = 4 * hh.column_tiles(Cc)
+    xb = torch.zeros((M, Cc), dtype=torch.bfloat16, device=DEV)
+    st = torch.full((M, sp, 2), 777.0, device=DEV)
+    out = r.clone()
+    hh.gemm(A, W, b, _lib.EPI_RESID_F32_LN, resid=out, out=out, out_bf16=xb, stats_out=st)
+    ref = A.float() @ W.float().t() + b + r
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max() < 2e-4
+    assert torch.equal(xb, _bf(out))
+    want = _row_partials(out, sp)
+    assert (st - want).abs().max() < 2e-3 * (1 + want.abs().max())  # fp32 sums in a different order
+    mu = st[:, :, 0].sum(1) / Cc
+    assert (mu - out.mean(1)).abs().max() < 1e-5
+
+
 def test_gemm_patch_epilogue_and_im2col():
     """im2col + patch GEMM == conv patchify + cls/pos placement (HF:97-149), rows m -> img*T + 1 + p."""
     I, H, W, P, Cc = 3, 75, 90, 14, 128

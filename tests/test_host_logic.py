@@ -118,7 +118,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # cs_create validates on the host before touching the device
     cc = _lib.CsConfig(hidden=100, enc_layers=1, enc_heads=1, mlp_ratio=4, patch=14, pos_grid=5, pe_h=40, pe_w=40, dec_layers=2,
-                       dec_heads=8, do_self_attn=1, do_short_cut=1, act=0, pow_p=1.0, enc_chunk_images=0, lanes=0)
+                       dec_heads=8, do_self_attn=1, do_short_cut=1, act=0, pow_p=1.0, enc_chunk_images=0, ln_fold=0, lanes=0)
     assert not lib.cs_create(ctypes.byref(cc))
     assert b"hidden" in lib.cs_last_error()
 

@@ -1,0 +1,15 @@
+import sys, time, torch, os
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+from crossscore_amd import synth
+from crossscore_amd.config import model_config
+from crossscore_amd.model import CrossScoreNet
+net = CrossScoreNet(model_config()); net.load_numpy_state_dict(synth.make_state_dict(net.arch, 1)); net = net.cuda()
+q, r = synth.make_inputs(8, 5, 518, 518, 1); tq = torch.from_numpy(q).cuda(); tr = torch.from_numpy(r).cuda()
+for rep in range(2):
+    for fold, lanes, chunk in ((1, 2, 0), (0, 2, 0), (1, 1, 48), (0, 1, 48)):
+        net.ln_fold = fold; net.lanes = lanes; net.enc_chunk_images = chunk; net._mark_dirty()
+        for _ in range(3): net(tq, tr, False, 0, False)
+        torch.cuda.synchronize(); t = time.time()
+        for _ in range(10): net(tq, tr, False, 0, False)
+        torch.cuda.synchronize(); dt = (time.time() - t) / 10
+        print(f"ln_fold={fold} lanes={lanes} chunk={chunk}: {dt*1e3:.2f} ms -> {8/dt:.1f} q/s", flush=True)
