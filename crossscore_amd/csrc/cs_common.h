@@ -21,8 +21,12 @@ __device__ __forceinline__ bf16_t f2bf(float x) {
   return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+// two values in one v_cvt_pk_bf16_f32 (same round-to-nearest-even as f2bf)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 // wave64 butterfly reductions

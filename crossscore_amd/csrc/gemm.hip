@@ -22,6 +22,7 @@
 #include "cs_common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -42,36 +43,65 @@ template <int NSUB> struct GemmCfg {
   static constexpr int PROW_F = WN * 4 + 16;              // patch row (fp32), padded: conflict-free b128 writes
   static constexpr int PROW_H = WN * 2 + 16;              // patch row (bf16)
   static constexpr int PATCH = 16 * PROW_F + (NSUB == 2 ? 512 : 0);  // one 16-row patch per wave (+ room for the LN stash)
-  static constexpr int LDS = RING + 4 * PATCH;            // 73.3 / 57.2 KiB -> two blocks per CU
+  static constexpr int BIAS_MAX = 1536;                   // the bias vector lives in LDS when N <= BIAS_MAX (every N of the path)
+  static constexpr int BIAS_OFF = RING + 4 * PATCH;
+  static constexpr int LDS = BIAS_OFF + BIAS_MAX * 4;     // 79.3 / 65.2 KiB -> two blocks per CU
 };
 
 #define CS_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 #ifdef CS_ABLATE  // timing-only debug builds (tools/gemm_ablate.py): bit0 no epilogue, bit1 no MFMA, bit2 no LDS-DMA
 #define CS_ABL(bit) (p.ablate & (bit))
+// per-wave phase clocks (issue time, s_memtime): 0 vmcnt wait, 1 barrier, 2 prefetch + LDS-DMA issue, 3 LDS reads + MFMA,
+// 4 epilogue step, 5 everything between slices (tile switch, hand-over, loop control), 6 slices, 7 total
+__device__ long long* g_cs_dbg = nullptr;
+#define CS_T(k) do { const long long t_ = clock64(); dbg_acc[k] += t_ - dbg_last; dbg_last = t_; } while (0)
 #else
 #define CS_ABL(bit) 0
+#define CS_T(k) do { } while (0)
 #endif
 
 // GELU(x) = x * Phi(x) with the exact (erf) Phi of HF ACT2FN["gelu"] (HF modeling_dinov2.py:293-297) approximated by
-// Phi(x) ~ 0.5 + x * P(x^2), x clamped to +-4.2 and Phi clamped to [0,1]; P is a degree-7 minimax fit of the GELU error:
+// Phi(x) ~ 0.5 + x * P(x^2), x clamped to +-4.2; P is a degree-7 minimax fit of the GELU error:
 // max |GELU_fit - GELU_erf| = 6.7e-5 (2.1e-4 as evaluated in fp32 Horner form, near |x| = 4 where y ~ x; a bf16 half-ulp is
 // 2e-3 at |y| = 1 and 8e-3 at 4).  12 plain VALU ops, no
 // transcendentals: the fc1 epilogue was spending more issue slots on erf (v_exp + v_rcp) than its K loop on MFMAs
 // (PMC: SQ_ACTIVE_INST_VALU 51 % vs MFMA pipe busy 26 % with the Abramowitz-Stegun erf).
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float xc = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f);
-  const float t = xc * xc;
-  float q = -9.6129670387e-10f;
-  q = q * t + 8.3297297734e-08f;
-  q = q * t - 3.1398569575e-06f;
-  q = q * t + 6.8266010957e-05f;
-  q = q * t - 9.6075936689e-04f;
-  q = q * t + 9.3374518106e-03f;
-  q = q * t - 6.5599355124e-02f;
-  q = q * t + 3.9850871469e-01f;
-  const float phi = __builtin_amdgcn_fmed3f(xc * q + 0.5f, 0.0f, 1.0f);
-  return x * phi;
+// Four values per call as two packed-fp32 Horner chains (v_pk_fma_f32) issued alternately from one asm block: a lone chain pays
+// a dependent-issue bubble on every packed fma, and the compiler's scheduler serialises the chains again whatever the source
+// order.  The fitted Phi stays inside [-1.2e-6, 1 + 1.2e-6] on the clamped range, so it is not clamped again.
+__device__ __forceinline__ unsigned long long gelu_c(float c) { return (unsigned long long)__float_as_uint(c); }
+__device__ __forceinline__ void gelu_erf4(float (&v)[4]) {
+  const f32x2_t xa = {v[0], v[1]}, xb = {v[2], v[3]};
+  const f32x2_t ca = {__builtin_amdgcn_fmed3f(v[0], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(v[1], -4.2f, 4.2f)};
+  const f32x2_t cb = {__builtin_amdgcn_fmed3f(v[2], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(v[3], -4.2f, 4.2f)};
+  const f32x2_t ta = ca * ca, tb = cb * cb;
+  const f32x2_t c1 = {8.3297297734e-08f, 8.3297297734e-08f};
+  f32x2_t qa, qb;
+  // q = c0*t + c1, then q = q*t + c_k: the scalar operand is a register pair whose low half is broadcast (op_sel_hi 0)
+  // (leading / trailing s_nop: the packed-fma result hazard against the compiler's own neighbouring instructions)
+  asm("s_nop 0\n\t"
+      "v_pk_fma_f32 %0, %2, %4, %5 op_sel_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %1, %3, %4, %5 op_sel_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %6 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %6 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %7 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %7 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %8 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %8 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %9 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %9 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %10 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %10 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %11 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %11 op_sel_hi:[1,1,0]\n\t"
+      "s_nop 0"
+      : "=&v"(qa), "=&v"(qb)
+      : "v"(ta), "v"(tb), "s"(gelu_c(-9.6129670387e-10f)), "v"(c1), "s"(gelu_c(-3.1398569575e-06f)), "s"(gelu_c(6.8266010957e-05f)),
+        "s"(gelu_c(-9.6075936689e-04f)), "s"(gelu_c(9.3374518106e-03f)), "s"(gelu_c(-6.5599355124e-02f)), "s"(gelu_c(3.9850871469e-01f)));
+  const f32x2_t ya = xa * __builtin_elementwise_fma(ca, qa, f32x2_t{0.5f, 0.5f});
+  const f32x2_t yb = xb * __builtin_elementwise_fma(cb, qb, f32x2_t{0.5f, 0.5f});
+  v[0] = ya[0]; v[1] = ya[1]; v[2] = yb[0]; v[3] = yb[1];
 }
 
 // RegressionLayer activation (regression_layer.py:26-62); kept out of line so the unrolled head epilogue does not spill
@@ -82,25 +112,26 @@ __device__ __noinline__ float head_activation(float v, int act, float powp) {
 }
 
 // ---- wave-private LDS patch access by inline asm (the compiler must not treat it as aliasing the LDS-DMA ring) ----
+// (constant byte offsets go into the instruction's offset field: one address register per access group)
+template <int OFF = 0>
 __device__ __forceinline__ void patch_write16(unsigned addr, f32x4_t v) {
-  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+template <int OFF = 0>
 __device__ __forceinline__ void patch_write8(unsigned addr, u32x2_t v) {
-  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
-template <int N>
-__device__ __forceinline__ void patch_read16(unsigned addr, unsigned stride, f32x4_t (&r)[N]) {
+template <int N, int STRIDE>
+__device__ __forceinline__ void patch_read16(unsigned addr, f32x4_t (&r)[N]) {
   static_assert(N == 1 || N == 2 || N == 4, "patch_read16");
   if constexpr (N == 1) {
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0]) : "v"(addr) : "memory");
   } else if constexpr (N == 2) {
-    const unsigned a1 = addr + stride;
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r[0]), "=&v"(r[1]) : "v"(addr), "v"(a1) : "memory");
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]) : "v"(addr), "n"(STRIDE) : "memory");
   } else {
-    const unsigned a1 = addr + stride, a2 = addr + 2 * stride, a3 = addr + 3 * stride;
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(addr), "v"(a1), "v"(a2), "v"(a3) : "memory");
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(addr), "n"(STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE) : "memory");
   }
 }
 
@@ -110,6 +141,13 @@ __device__ __forceinline__ u32x2_t patch_read8(unsigned addr) {
   asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
   return r;
 }
+
+// Residual prefetch (PIPE kernels): 16 bytes per lane at sbase + voff, issued by inline asm so that the compiler neither
+// counts it nor waits for it; the kernel's own counted s_waitcnt covers it (see k_slice), and rb_touch() orders the uses.
+__device__ __forceinline__ void gload16(f32x4_t& r, unsigned voff, const float* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void rb_touch(f32x4_t& r) { asm volatile("" : "+v"(r)); }
 
 // (sum, sum of squares) of one lane's 4 values, reduced over the LPR lanes that hold a row.  One helper with explicit fma order
 // for the full-tile and the ragged path: with -ffp-contract the compiler would otherwise fuse the two copies differently, and
@@ -140,6 +178,11 @@ __device__ __forceinline__ void row_partial(f32x4_t v, bool on, float& a, float&
   }
 }
 
+template <int... Js, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F&& f) {
+  (f(std::integral_constant<int, Js>{}), ...);
+}
+
 template <int EPI> struct EpiTraits {
   static constexpr bool kLN = EPI == CS_EPI_LN_BF16 || EPI == CS_EPI_LN_GELU_BF16;           // LayerNorm-folded consumer
   static constexpr bool kHalf = EPI == CS_EPI_BIAS_BF16 || EPI == CS_EPI_BIAS_GELU_BF16 || EPI == CS_EPI_BIAS_RELU_BF16 ||
@@ -150,8 +193,12 @@ template <int EPI> struct EpiTraits {
 
 // NSUB = 16-column sub-tiles per wave; block tile = 128 x (64*NSUB); 4 waves side by side in N, wave tile 128 x 16*NSUB.
 // SPL = float4 loads per row of LayerNorm partial sums (LN-folded consumers only: ln_sp / 2).
-template <int EPI, int NSUB, int SPL>
+// PIPE (RESID_F32 with a residual, K >= 9 slices): the residual is prefetched in the accumulator layout a slice or more ahead of
+// its epilogue step and added in registers, so no step consumes a load it has just issued (that would wait for every older
+// LDS-DMA: the vector-memory queue retires in order, and the K=384/1536 residual GEMMs were spending a third of their time there).
+template <int EPI, int NSUB, int SPL, bool PIPE>
 __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
+  static_assert(!PIPE || EPI == CS_EPI_RESID_F32, "PIPE is the RESID_F32 residual prefetch");
   using Cfg = GemmCfg<NSUB>;
   constexpr bool kLN = EpiTraits<EPI>::kLN, kResid = EpiTraits<EPI>::kResid, kLnOut = EpiTraits<EPI>::kLnOut;
   constexpr int BN = Cfg::BN, NS = Cfg::NS, D = Cfg::D, LPS = Cfg::LPS, STAGE_BYTES = Cfg::STAGE_BYTES;
@@ -165,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   constexpr int PROW = kHalf ? Cfg::PROW_H : Cfg::PROW_F;
   // vector-memory instructions one full-tile epilogue step issues: stores (+ the row partials of an LN-folded consumer);
   // stores + as many addend loads for RESID / PATCH (+ bf16 copy + row partials when those are emitted)
-  constexpr int VE = kHalf ? NRD : (kLnOut ? 4 * NRD : 2 * NRD);
+  constexpr int VE = kHalf ? NRD : (kLnOut ? 4 * NRD : (PIPE ? NRD : 2 * NRD));
   // LN-folded consumer: behind the bf16 patch rows each wave keeps s[n], c[n] of the tile's columns and (mu, rstd) of the
   // tile's 128 rows, filled once per tile, so the epilogue steps issue no vector-memory loads (a load consumed inside a
   // step would wait for every older LDS-DMA: the queue retires in order)
@@ -181,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   const int tiles_m = (p.M + BM - 1) / BM;
   const int wn = wv;
   const int nk = p.K / BK;
+  if constexpr (PIPE) __builtin_assume(nk >= 9);
 
   // ---- persistent tile walk, XCD aware: blocks b, b+8, .. share an XCD (round-robin dispatch); XCD x owns the A row
   //      panels tm == x (mod 8) and its blocks walk that list n-fastest, so concurrent blocks of one L2 share A. ----
@@ -199,30 +247,58 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   //      fetches source chunk (i&3) ^ 2*((row>>2)&1), and ds_read_b128 applies the same XOR: conflict free. ----
   const int srow = lane >> 2;
   const int gchunk = (lane & 3) ^ (((srow >> 2) & 1) << 1);
-  int offA[2], offW[NSUB];
+  unsigned offA[2], offW[NSUB];  // byte offsets (the shape check keeps M*lda and N*ldw below 2^31 elements)
   auto set_tile = [&](int m0, int n0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int ga = m0 + (j * 4 + wv) * 16 + srow;  // A tile: 8 groups of 16 rows, 2 per wave
       ga = ga < p.M ? ga : p.M - 1;
-      offA[j] = ga * p.lda + gchunk * 8;
+      offA[j] = (unsigned)(ga * p.lda + gchunk * 8) * 2u;
+#ifdef CS_ABLATE
+      if (CS_ABL(8)) {  // timing experiment: 8 lanes fetch one whole 128-byte line (the data is meaningless)
+        ga = min(m0 + (j * 4 + wv) * 8 + (lane >> 3), p.M - 1);
+        offA[j] = (unsigned)(ga * p.lda + (lane & 7) * 8) * 2u;
+      }
+#endif
     }
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
       int gw = n0 + (j * 4 + wv) * 16 + srow;  // W tile: 4*NSUB groups of 16 rows, NSUB per wave
       gw = gw < p.N ? gw : p.N - 1;
-      offW[j] = gw * p.ldw + gchunk * 8;
+      offW[j] = (unsigned)(gw * p.ldw + gchunk * 8) * 2u;
+#ifdef CS_ABLATE
+      if (CS_ABL(8)) {
+        gw = min(n0 + (j * 4 + wv) * 8 + (lane >> 3), p.N - 1);
+        offW[j] = (unsigned)(gw * p.ldw + (lane & 7) * 8) * 2u;
+      }
+#endif
     }
   };
   auto stage = [&](int ring, int kt) {
     char* base = smem + ring * STAGE_BYTES;
+#ifdef CS_ABLATE
+    if (CS_ABL(8)) kt &= ~1;  // 64-element aligned: stays inside the row
+#endif
+    // uniform base (this slice's K offset) + 32-bit lane offset: the scalar-base addressing form, no per-instruction VALU
+    const char* sA = reinterpret_cast<const char*>(p.A + kt * BK);
+    const char* sW = reinterpret_cast<const char*>(p.W + kt * BK);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.A + offA[j] + kt * BK), CS_LDS_PTR(base + (j * 4 + wv) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(sA + offA[j]), CS_LDS_PTR(base + (j * 4 + wv) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < NSUB; ++j)
-      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.W + offW[j] + kt * BK), CS_LDS_PTR(base + A_BYTES + (j * 4 + wv) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(sW + offW[j]), CS_LDS_PTR(base + A_BYTES + (j * 4 + wv) * 1024), 16, 0, 0);
   };
+
+  // ---- bias vector -> LDS once per block (read back by inline-asm ds_read at each tile start: a global load there would be
+  //      consumed at once and drain the LDS-DMA queue once per tile) ----
+  const unsigned bias_lds = (unsigned)(size_t)CS_LDS_PTR(smem + Cfg::BIAS_OFF);
+  const bool bias_in_lds = p.bias && !kLN && p.N <= Cfg::BIAS_MAX;
+  if (bias_in_lds) {
+    for (int i = tid * 4; i < p.N; i += 1024) patch_write16(bias_lds + i * 4, *reinterpret_cast<const f32x4_t*>(p.bias + i));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 
   // load cursor (runs D slices ahead of the compute cursor, across tile boundaries)
   int issued = 0, l_idx = slot, l_kt = 0, l_ring = 0;
@@ -260,16 +336,48 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   const unsigned pr_addr = patch_lds + rrow * PROW + (rch < CPR ? rch : CPR - 1) * 16;
   const unsigned stash_addr = patch_lds + STASH + (lane >> 4) * 16;  // + j*64 (s), + WN*4 + j*64 (c)
 
+#ifdef CS_ABLATE
+  long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long dbg_last = clock64();
+  const long long dbg_t0 = dbg_last;
+#endif
   f32x4_t acc[8][NSUB], prv[8][NSUB];
   bool have_prev = false, prev_full = false;
-  int pm0 = 0, pn0 = 0;
+  int pm0 = 0, pn0 = 0, cm0 = 0, cn0 = 0;
   int it = 0, c_ring = 0;
-  int ve1 = 0, ve2 = 0;  // vector-memory ops the epilogue steps of the last / second-to-last iteration issued (-1: unknown)
+  // stores the epilogue steps of the last / second-to-last slice issued (-1: unknown count), and whether the last slice began
+  // with residual prefetches (PIPE): the inputs of the counted wait at the top of k_slice
+  int st1 = 0, st2 = 0;
+  bool rl1 = false, last_dma = false;
+  // PIPE: residual prefetch registers of epilogue step t (accumulator layout); live from the slice that loads them to the next
+  // slice's start, so they reuse registers of `prv` sub-tiles whose step has already run
+  [[maybe_unused]] f32x4_t rb[8][NSUB];
+  [[maybe_unused]] const unsigned lane_roff = PIPE ? (unsigned)(((lane & 15) * p.ldr + (lane >> 4) * 4) * 4) : 0u;
+  [[maybe_unused]] auto rload = [&](int m0, int n0, auto T_) {
+    constexpr int T = decltype(T_)::value;
+    const int r0 = min(m0 + T * 16, p.M - 16);  // clamps only on ragged tiles, whose prefetch is not used
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+      const int c0 = min(n0 + wn * Cfg::WN + j * 16, p.N - 16);
+      gload16(rb[T][j], lane_roff, p.resid + (size_t)r0 * p.ldr + c0);
+    }
+  };
+  [[maybe_unused]] auto radd = [&](auto T_) {
+    constexpr int T = decltype(T_)::value;
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) rb_touch(rb[T][j]);
+    if (prev_full) {
+#pragma unroll
+      for (int j = 0; j < NSUB; ++j) prv[T][j] += rb[T][j];
+    }
+  };
 
   // ---- one epilogue step: 16-row sub-tile I of the previous tile; returns the number of vector-memory instructions it
   //      issued when that is known at compile time (full tiles), else -1 ----
-  auto epi_step = [&](auto I_) -> int {
+  auto epi_step = [&](auto I_, auto FLUSH_) -> int {
     constexpr int I = decltype(I_)::value;
+    // PIPE: the residual of a full tile is already in prv, except for steps 3..7 of a block's last tile (flushed after the loop)
+    constexpr bool kLoadResid = kResid && (!PIPE || (decltype(FLUSH_)::value && I >= 3));
     if (CS_ABL(1)) {
       if (prv[I][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = prv[I][NSUB - 1][3];  // keep prv live
       return -1;
@@ -305,30 +413,32 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
         ln_mu = __uint_as_float(mr[0]);
         ln_rs = __uint_as_float(mr[1]);
       }
-#pragma unroll
-      for (int j = 0; j < NSUB; ++j) {
+      static_for(std::make_integer_sequence<int, NSUB>{}, [&](auto J_) {
+        constexpr int j = decltype(J_)::value;
         float v[4] = {prv[I][j][0], prv[I][j][1], prv[I][j][2], prv[I][j][3]};
         if constexpr (kLN) {
           f32x4_t sc[2];
-          patch_read16<2>(stash_addr + j * 64, Cfg::WN * 4, sc);  // s then c of these 4 columns
+          patch_read16<2, Cfg::WN * 4>(stash_addr + j * 64, sc);  // s then c of these 4 columns
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaf(fmaf(-ln_mu, sc[0][r], v[r]), ln_rs, sc[1][r]);
         }
+        if constexpr (EPI == CS_EPI_BIAS_GELU_BF16 || EPI == CS_EPI_LN_GELU_BF16) {
+          gelu_erf4(v);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if constexpr (EPI == CS_EPI_BIAS_GELU_BF16 || EPI == CS_EPI_LN_GELU_BF16) v[r] = gelu_erf(v[r]);
           if constexpr (EPI == CS_EPI_BIAS_RELU_BF16) v[r] = fmaxf(v[r], 0.f);
           if constexpr (EPI == CS_EPI_BIAS_LEAKY_BF16) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
         }
         if constexpr (kHalf) {
-          patch_write8(pw_addr + j * 32, u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])});
+          patch_write8<j * 32>(pw_addr, u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])});
         } else {
-          patch_write16(pw_addr + j * 64, f32x4_t{v[0], v[1], v[2], v[3]});
+          patch_write16<j * 64>(pw_addr, f32x4_t{v[0], v[1], v[2], v[3]});
         }
-      }
+      });
       // 2) whole row segments out of the patch
       f32x4_t seg[NRD];
-      patch_read16<NRD>(pr_addr, RPI * PROW, seg);
+      patch_read16<NRD, RPI * PROW>(pr_addr, seg);
       const int mrow0 = pm0 + I * 16 + rrow;
       const int n = ncol0 + rch * (kHalf ? 8 : 4);
       [[maybe_unused]] const int st_slot = (pn0 / BN) * 4 + wn;
@@ -337,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
           (EPI != CS_EPI_PATCH_F32 || ln_out)) {
         // every row and column of the tile exists: no row tests, a fixed number (VE) of memory instructions
         if (rch < CPR) {
-          if constexpr (kResid) {
+          if constexpr (kLoadResid) {
 #pragma unroll
             for (int q = 0; q < NRD; ++q)
               seg[q] += *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)(mrow0 + q * RPI) * p.ldr + n);
@@ -373,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
             if (rch == LPR - 1) *reinterpret_cast<float2*>(p.stats_out + (row * p.stats_sp + st_slot) * 2) = make_float2(a, b);
           }
         }
-        return VE;
+        return kLoadResid != (kResid && !PIPE) ? -1 : VE;
       }
       // ragged tile (or no residual / LN outputs): per-row tests, data-dependent instruction count
       const bool col_ok = rch < CPR && n < p.N;
@@ -415,17 +525,44 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
     constexpr int STEP = decltype(STEP_)::value;
     // Slice `it` must have landed.  The vector-memory queue retires in order; younger than slice `it`'s LDS-DMA are the D-1
     // later slices and whatever the epilogue steps of the last D iterations issued, so exactly that many may stay in flight.
+    // Order inside a slice: [residual prefetches (PIPE)] [LDS-DMA of slice it+D] [stores of the epilogue step].  If the last
+    // slice began with prefetches they must have landed too: they are older than its LDS-DMA, so only that and its stores stay.
+    CS_T(5);
     const int ahead = min(total - 1 - it, D - 1);
-    const int young = ve1 + ve2;
-    if (ahead < D - 1 || ve1 < 0 || ve2 < 0) CS_VMCNT(0);
+    const int young = (st1 < 0 || (!rl1 && st2 < 0)) ? -1 : (rl1 ? st1 : st1 + st2);
+    if (ahead < D - 1 || young < 0) CS_VMCNT(0);
     else if (young == 0) CS_VMCNT(LPS);
     else if (young == VE) CS_VMCNT(LPS + VE);
     else if (young == 2 * VE) CS_VMCNT(LPS + 2 * VE);
     else CS_VMCNT(0);
+    CS_T(0);
     __builtin_amdgcn_s_barrier();  // every wave's part of slice `it` landed; everyone has left ring slot (it-1)%NS
     asm volatile("" ::: "memory");
+    CS_T(1);
+    bool rl = false;
+    if constexpr (PIPE) {
+      // step t's residual: loaded in slice t-2, added at the top of slice t-1 (steps 0..2: loaded in the tile's last slice,
+      // added at the hand-over), so that no prefetch register is live while all of prv still is
+      if constexpr (STEP >= 2 && STEP <= 6) {
+        if (have_prev) radd(std::integral_constant<int, (STEP >= 2 && STEP <= 6) ? STEP + 1 : 0>{});
+      }
+      if constexpr (STEP >= 1 && STEP <= 5) {
+        rload(pm0, pn0, std::integral_constant<int, (STEP >= 1 && STEP <= 5) ? STEP + 2 : 0>{});
+        rl = true;
+      }
+      if constexpr (STEP == -2) {
+        rload(cm0, cn0, std::integral_constant<int, 0>{});
+        rload(cm0, cn0, std::integral_constant<int, 1>{});
+        rload(cm0, cn0, std::integral_constant<int, 2>{});
+        rl = true;
+      }
+    }
+    if (!CS_ABL(16)) {
+    last_dma = issued < total;
     if (issued < total && !CS_ABL(4)) issue_one();  // refill the slot just vacated
     else if (issued < total) ++issued;
+    }
+    CS_T(2);
     if (!CS_ABL(2)) {
       const char* sa = smem + c_ring * STAGE_BYTES + frow * 64 + coff;
       const char* sw = smem + c_ring * STAGE_BYTES + A_BYTES + (wn * 16 * NSUB + frow) * 64 + coff;
@@ -440,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
         for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
       // W fragments + LOOK A fragments up front, then one A-fragment read per MFMA group, LOOK-1 groups ahead of its use
       // (the LN-folded consumers are at the 256-register limit: one fragment less in flight avoids spills)
-      constexpr int LOOK = (kLN && NSUB == 3) ? 2 : 3;
+      constexpr int LOOK = ((kLN || PIPE) && NSUB == 3) ? 2 : 3;
       __builtin_amdgcn_sched_group_barrier(0x100, NSUB + LOOK, 0);
 #pragma unroll
       for (int i = 0; i < 8 - LOOK; ++i) {
@@ -449,37 +586,52 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
       }
       __builtin_amdgcn_sched_group_barrier(0x008, LOOK * NSUB, 0);
     }
+    CS_T(3);
+    if (CS_ABL(16)) {  // experiment: refill after the MFMA section
+    last_dma = issued < total;
+    if (issued < total && !CS_ABL(4)) issue_one();
+    else if (issued < total) ++issued;
+    }
     int ve = 0;
     if constexpr (STEP >= 0) {
-      if (have_prev) ve = epi_step(std::integral_constant<int, (STEP >= 0 ? STEP : 0)>{});
+      if (have_prev) ve = epi_step(std::integral_constant<int, (STEP >= 0 ? STEP : 0)>{}, std::false_type{});
     }
-    ve2 = ve1;
-    ve1 = ve;
+    CS_T(4);
+    st2 = st1;
+    st1 = __builtin_amdgcn_readfirstlane(ve);
+    rl1 = rl;
     ++it;
     c_ring = c_ring + 1 == NS ? 0 : c_ring + 1;
   };
 
   for (int idx = slot; idx < ntile_x; idx += slots) {
-    int cm0, cn0;
     tile_of(idx, cm0, cn0);
     // accumulators start at the bias of their columns
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
       const int n = min(cn0 + wn * Cfg::WN + j * 16 + (lane >> 4) * 4, p.N - 4);
-      const f32x4_t b4 = (p.bias && !kLN) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      f32x4_t b4[1] = {f32x4_t{0.f, 0.f, 0.f, 0.f}};
+      if (bias_in_lds) patch_read16<1, 0>(bias_lds + n * 4, b4);
+      else if (p.bias && !kLN) b4[0] = *reinterpret_cast<const f32x4_t*>(p.bias + n);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i][j] = b4;
+      for (int i = 0; i < 8; ++i) acc[i][j] = b4[0];
     }
-    if (p.bias && !kLN) ve1 = -1;  // the bias loads joined the queue and are consumed at once: the next wait drains it
+    if (p.bias && !kLN && !bias_in_lds) st1 = -1;  // global bias loads are consumed at once: the next wait drains the queue
     int kt = 0;
     // the first 8 slices carry the previous tile's 8 epilogue steps
 #define CS_SLICE_WITH_STEP(E)                                                              \
     if (kt < nk) { k_slice(std::integral_constant<int, E>{}); ++kt; }                     \
-    else if (have_prev) { (void)epi_step(std::integral_constant<int, E>{}); ve1 = -1; }
+    else if (have_prev) { (void)epi_step(std::integral_constant<int, E>{}, std::false_type{}); st1 = -1; }
     CS_SLICE_WITH_STEP(0) CS_SLICE_WITH_STEP(1) CS_SLICE_WITH_STEP(2) CS_SLICE_WITH_STEP(3)
     CS_SLICE_WITH_STEP(4) CS_SLICE_WITH_STEP(5) CS_SLICE_WITH_STEP(6) CS_SLICE_WITH_STEP(7)
 #undef CS_SLICE_WITH_STEP
-    for (; kt < nk; ++kt) k_slice(std::integral_constant<int, -1>{});
+    if constexpr (PIPE) {  // nk >= 9 (launcher): the last slice prefetches the residual of this tile's steps 0..2
+      for (; kt < nk - 1; ++kt) k_slice(std::integral_constant<int, -1>{});
+      k_slice(std::integral_constant<int, -2>{});
+      ++kt;
+    } else {
+      for (; kt < nk; ++kt) k_slice(std::integral_constant<int, -1>{});
+    }
     // hand the finished tile to the deferred epilogue
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -488,6 +640,14 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
     have_prev = true;
     pm0 = cm0; pn0 = cn0;
     prev_full = (cm0 + BM <= p.M) && (cn0 + BN <= p.N);
+    if constexpr (PIPE) {
+      // the three prefetches are older than the last slice's LDS-DMA (if it issued one): wait for exactly those
+      if (last_dma) CS_VMCNT(LPS);
+      else CS_VMCNT(0);
+      radd(std::integral_constant<int, 0>{});
+      radd(std::integral_constant<int, 1>{});
+      radd(std::integral_constant<int, 2>{});
+    }
     if constexpr (kLN) {  // s[n], c[n] of the finished tile's columns and (mu, rstd) of its rows -> wave-private stash
       {
         const float invc = 1.0f / (float)p.K;
@@ -517,26 +677,34 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
           patch_write16(stash_addr + Cfg::WN * 4 + j * 64, *reinterpret_cast<const f32x4_t*>(p.bias + n));
         }
       }
-      ve1 = -1;  // those loads are consumed at once: the next wait drains the queue
+      st1 = -1;  // those loads are consumed at once: the next wait drains the queue
     }
   }
   if (have_prev) {  // flush the last tile
-    (void)epi_step(std::integral_constant<int, 0>{}); (void)epi_step(std::integral_constant<int, 1>{});
-    (void)epi_step(std::integral_constant<int, 2>{}); (void)epi_step(std::integral_constant<int, 3>{});
-    (void)epi_step(std::integral_constant<int, 4>{}); (void)epi_step(std::integral_constant<int, 5>{});
-    (void)epi_step(std::integral_constant<int, 6>{}); (void)epi_step(std::integral_constant<int, 7>{});
+    (void)epi_step(std::integral_constant<int, 0>{}, std::true_type{}); (void)epi_step(std::integral_constant<int, 1>{}, std::true_type{});
+    (void)epi_step(std::integral_constant<int, 2>{}, std::true_type{}); (void)epi_step(std::integral_constant<int, 3>{}, std::true_type{});
+    (void)epi_step(std::integral_constant<int, 4>{}, std::true_type{}); (void)epi_step(std::integral_constant<int, 5>{}, std::true_type{});
+    (void)epi_step(std::integral_constant<int, 6>{}, std::true_type{}); (void)epi_step(std::integral_constant<int, 7>{}, std::true_type{});
   }
+#ifdef CS_ABLATE
+  if (g_cs_dbg && lane == 0) {
+    long long* d = g_cs_dbg + ((size_t)blockIdx.x * 4 + wv) * 8;
+    for (int k = 0; k < 6; ++k) d[k] = dbg_acc[k];
+    d[6] = it;
+    d[7] = clock64() - dbg_t0;
+  }
+#endif
 }
 
 int g_num_cus = 0;
 
-template <int EPI, int NSUB, int SPL>
+template <int EPI, int NSUB, int SPL, bool PIPE = false>
 hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   constexpr int BN = 64 * NSUB;
   constexpr int LDS = GemmCfg<NSUB>::LDS;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm_kernel<EPI, NSUB, SPL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm_kernel<EPI, NSUB, SPL, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
@@ -556,7 +724,7 @@ hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   const int need = ((tiles_m + 7) / 8) * tiles_n * 8;
   if (grid > need) grid = need;
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((cs_gemm_kernel<EPI, NSUB, SPL>), dim3(grid), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((cs_gemm_kernel<EPI, NSUB, SPL, PIPE>), dim3(grid), dim3(256), LDS, stream, p);
   return hipGetLastError();
 }
 
@@ -573,6 +741,13 @@ hipError_t launch(const CsGemmParams& p, hipStream_t stream) {
     if (p.ln_sp == 8) return launch_n<EPI, 2, 4>(p, stream);
     return launch_n<EPI, 2, 8>(p, stream);
   } else {
+    if constexpr (EPI == CS_EPI_RESID_F32) {
+      // residual prefetch pipeline: needs a residual, >= 9 K slices (the 8 step-carrying slices + a last one) and 32-bit offsets
+      if (p.resid && p.K / BK >= 9 && p.M >= 16 && p.N >= 16 && (long long)p.M * p.ldr * 4 < (1ll << 31)) {
+        if (p.N % 192 == 0) return launch_n<EPI, 3, 0, true>(p, stream);
+        return launch_n<EPI, 2, 0, true>(p, stream);
+      }
+    }
     if (p.N % 192 == 0) return launch_n<EPI, 3, 0>(p, stream);
     return launch_n<EPI, 2, 0>(p, stream);
   }
@@ -611,6 +786,10 @@ extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
   if ((long long)p->M * p->lda >= (1ll << 31) || (long long)p->N * p->ldw >= (1ll << 31)) return "gemm: operand too large for 32-bit offsets";
   return nullptr;
 }
+
+#ifdef CS_ABLATE
+extern "C" int cs_gemm_dbg_set(long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cs_dbg), &buf, sizeof(buf)); }
+#endif
 
 extern "C" hipError_t cs_gemm_launch(const CsGemmParams* p0, int epi, hipStream_t stream) {
   CsGemmParams pp = *p0;
