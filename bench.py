@@ -148,6 +148,10 @@ def main():
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--cached-refs", action="store_true", help="also time the reference-token cache mode (separate metric)")
     ap.add_argument("--eager", action="store_true", help="also time the plain-PyTorch (eager, GPU) restatement: fp32 and bf16 autocast")
+    ap.add_argument("--lanes", type=int, default=0, help="internal streams of the forward (0 = library default, 2); 1 makes every "
+                    "kernel run alone, which is how the per-kernel table below is measured")
+    ap.add_argument("--chunk", type=int, default=0, help="encoder chunk in images (0 = library default); the per-kernel table uses "
+                    "one chunk for the whole batch")
     args = ap.parse_args()
 
     rank, local_rank, world = parallel.init_from_env()
@@ -165,6 +169,10 @@ def main():
     sd = synth.make_state_dict(arch, seed)  # every rank builds the same replica from the seed (no broadcast needed)
     net.load_numpy_state_dict(sd)
     net = net.to(dev)
+    if args.lanes > 0:
+        net.lanes = args.lanes
+    if args.chunk > 0:
+        net.enc_chunk_images = args.chunk
     lo = rank * B  # weak scaling: rank r scores global items [r*B, (r+1)*B)
     q, r = synth.make_inputs_shard(lo, lo + B, N, H, W, seed)
     tq, tr = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)  # inputs resident in HBM before timing
@@ -186,12 +194,21 @@ def main():
     # ---- per-kernel HIP-event timing (separate pass so the events do not perturb the timed region) ----
     result = None
     if rank == 0:
+        # every kernel alone on the GPU: one lane, the whole batch as one encoder chunk (the timed region above overlaps two lanes,
+        # where a kernel's wall duration also contains its neighbour's work); `bench.py --lanes 1 --chunk <images>` under rocprofv3
+        # reproduces exactly these launches (profiles/)
+        saved = (net.lanes, net.enc_chunk_images)
+        net.lanes, net.enc_chunk_images = 1, B * (1 + N)
+        net._mark_dirty()
+        net(tq, tr, False, 0, False)  # rebuilds the handle with the new lane / chunk settings
         net.profile_enable(True)
         prof_steps = 3
         for _ in range(prof_steps):
             net(tq, tr, False, 0, False)
         rows = kernel_table(net)
         net.profile_enable(False)
+        net.lanes, net.enc_chunk_images = saved
+        net._mark_dirty()
         for rrow in rows:
             rrow["launches_per_step"] = rrow["launches"] // prof_steps
         dom = max((x for x in rows if x["tflops"]), key=lambda x: x["total_ms"])
@@ -209,6 +226,7 @@ def main():
                            "frac": value * flops_q / 1e12 / world / PEAK_BF16_TFLOPS},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom["kernel"]),
+                         "measured": "HIP events around each launch on its stream, kernel alone on the GPU (1 lane, whole batch per chunk)",
                          "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
                          "flop_per_launch": dom["flops"] / dom["launches"]},
             "kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in x.items() if k != "flops"} for x in rows],
