@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrossscore_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "preprocess.hip"]
 
 
 def _hipcc() -> str:

@@ -38,6 +38,8 @@ hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
+hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int oh,
+                                int ow, const float* mean, const float* stdv, float* out, float* scratch, hipStream_t stream);
 }
 
 namespace {
@@ -805,6 +807,19 @@ int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const floa
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream) {
   if (!x || !out || I <= 0 || P <= 0 || H < P || W < P || Kp % 8 || Kp < 3 * P * P) return fail(CS_ERR_BAD_ARG, "im2col: bad arguments");
   HIPCHK(cs_im2col_launch(x, nullptr, 0, 0, out, I, H, W, P, Kp, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_preprocess_u8(const uint8_t* img, int in_h, int in_w, int in_row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int out_h,
+                        int out_w, const float* mean3, const float* std3, float* out, float* scratch, cs_stream stream) {
+  if (!img || !out || !mean3 || !std3 || in_h <= 0 || in_w <= 0 || in_row_bytes < 3 * in_w || rs_h <= 0 || rs_w <= 0 || out_h <= 0 ||
+      out_w <= 0 || crop_y < 0 || crop_x < 0 || crop_y + out_h > rs_h || crop_x + out_w > rs_w)
+    return fail(CS_ERR_BAD_ARG, "preprocess_u8: bad sizes (the crop window must lie inside the resized image)");
+  if ((rs_h != in_h || rs_w != in_w) && !scratch) return fail(CS_ERR_BAD_ARG, "preprocess_u8: a resize needs in_h*rs_w*3 floats of scratch");
+  for (int c = 0; c < 3; ++c)
+    if (!(std3[c] > 0.f)) return fail(CS_ERR_BAD_ARG, "preprocess_u8: std must be positive");
+  HIPCHK(cs_preprocess_launch(img, in_h, in_w, in_row_bytes, rs_h, rs_w, crop_y, crop_x, out_h, out_w, mean3, std3, out, scratch,
+                              (hipStream_t)stream));
   return 0;
 }
 

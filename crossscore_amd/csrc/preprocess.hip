@@ -1,0 +1,184 @@
+// Input stage of the predict path on the GPU: uint8 HWC image -> the fp32, ImageNet-normalised CHW tensor that
+// cs_forward consumes.  Replaces the reference's CPU transforms
+//   image_read: np.float32(img) / 255.0                                           utils/io/images.py:14-29
+//   T.Resize(short side, BILINEAR, antialias=True) on the float CHW tensor        task/predict.py:87-93, nvs_dataset.py:218-225
+//   deterministic (top-left) crop / integer-patch crop                            dataloading/transformation/crop.py:8-25, nvs_dataset.py:227-241
+//   T.Normalize(mean, std)                                                        task/predict.py:68-74
+// in that order, with the same fp32 operations: (u8 / 255) -> separable antialiased triangle filter, width pass then height pass
+// (ATen UpSampleKernel.cpp, _compute_indices_min_size_weights_aa + separable_upsample_generic_Nd_kernel_impl) -> (v - mean) / std.
+// Divisions are IEEE (hipcc's default correctly-rounded fp32 divide), so without a resize the result is bit-identical to the
+// reference's tensor.  HBM-bound byte work: one thread per output pixel, coalesced along x; H2D traffic drops 4x (uint8 in).
+#include "cs_common.h"
+#include <math.h>
+#include <vector>
+
+namespace {
+
+// ---- per-axis filter tables (host): for output index i the taps start at xmin[i], xsize[i] of them, weights w[i][0..xsize) ----
+struct AxisTable {
+  int in = 0, out = 0, taps = 0;
+  std::vector<int> xmin, xsize;
+  std::vector<float> w;  // [out][taps], zero padded
+};
+
+float tri(float x) {  // HelperInterpLinear::aa_filter
+  x = fabsf(x);
+  return x < 1.0f ? 1.0f - x : 0.0f;
+}
+
+void build_axis(int in, int out, AxisTable& t) {
+  t.in = in;
+  t.out = out;
+  const float scale = (float)in / (float)out;  // area_pixel_compute_scale, align_corners = False, no explicit scale factor
+  const float support = scale >= 1.0f ? scale : 1.0f;  // interp_size / 2 = 1 for the linear filter
+  t.taps = (int)ceilf(support) * 2 + 1;
+  t.xmin.assign(out, 0);
+  t.xsize.assign(out, 0);
+  t.w.assign((size_t)out * t.taps, 0.f);
+  const float invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+  for (int i = 0; i < out; ++i) {
+    const float center = (float)((double)scale * ((double)i + 0.5));
+    long long lo = (long long)((double)center - (double)support + 0.5);
+    if (lo < 0) lo = 0;
+    long long hi = (long long)((double)center + (double)support + 0.5);
+    if (hi > in) hi = in;
+    const int n = (int)(hi - lo);
+    float total = 0.f;
+    float* wr = &t.w[(size_t)i * t.taps];
+    for (int j = 0; j < n && j < t.taps; ++j) {
+      const float wv = tri((float)(((double)j + (double)lo - (double)center + 0.5) * (double)invscale));
+      wr[j] = wv;
+      total += wv;
+    }
+    if (total != 0.f)
+      for (int j = 0; j < n && j < t.taps; ++j) wr[j] /= total;
+    t.xmin[i] = (int)lo;
+    t.xsize[i] = n < t.taps ? n : t.taps;
+  }
+}
+
+// device copy of the two tables of the last (in_h, in_w, rs_h, rs_w); grown on demand, reused while the sizes repeat
+struct TableCache {
+  int in_h = 0, in_w = 0, rs_h = 0, rs_w = 0;
+  AxisTable tx, ty;
+  int* d_int = nullptr;    // xmin[rs_w] xsize[rs_w] ymin[rs_h] ysize[rs_h]
+  float* d_w = nullptr;    // wx[rs_w][taps_x] wy[rs_h][taps_y]
+  size_t cap_int = 0, cap_w = 0;
+  std::vector<int> h_int;
+  std::vector<float> h_w;
+} g_tab;
+
+__global__ void u8_norm_kernel(const uint8_t* __restrict__ img, int row_bytes, int crop_y, int crop_x, int oh, int ow,
+                               float m0, float m1, float m2, float s0, float s1, float s2, float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= ow) return;
+  const uint8_t* px = img + (size_t)(y + crop_y) * row_bytes + (size_t)(x + crop_x) * 3;
+  const size_t plane = (size_t)oh * ow, o = (size_t)y * ow + x;
+  out[o] = ((float)px[0] / 255.0f - m0) / s0;
+  out[plane + o] = ((float)px[1] / 255.0f - m1) / s1;
+  out[2 * plane + o] = ((float)px[2] / 255.0f - m2) / s2;
+}
+
+// width pass: tmp[y][x'][c] = sum_j wx[x'][j] * (u8[y][xmin[x'] + j][c] / 255)
+__global__ void u8_resize_w_kernel(const uint8_t* __restrict__ img, int row_bytes, int in_h, int rs_w, int taps,
+                                   const int* __restrict__ xmin, const int* __restrict__ xsize, const float* __restrict__ wx,
+                                   float* __restrict__ tmp) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= rs_w) return;
+  const uint8_t* row = img + (size_t)y * row_bytes + (size_t)xmin[x] * 3;
+  const float* w = wx + (size_t)x * taps;
+  const int n = xsize[x];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const float wj = w[j];
+    const float v0 = (float)row[3 * j] / 255.0f, v1 = (float)row[3 * j + 1] / 255.0f, v2 = (float)row[3 * j + 2] / 255.0f;
+    if (j == 0) { a0 = v0 * wj; a1 = v1 * wj; a2 = v2 * wj; }
+    else { a0 += v0 * wj; a1 += v1 * wj; a2 += v2 * wj; }
+  }
+  float* o = tmp + ((size_t)y * rs_w + x) * 3;
+  o[0] = a0; o[1] = a1; o[2] = a2;
+}
+
+// height pass + crop + normalise + HWC -> CHW
+__global__ void resize_h_norm_kernel(const float* __restrict__ tmp, int rs_w, int taps, const int* __restrict__ ymin,
+                                     const int* __restrict__ ysize, const float* __restrict__ wy, int crop_y, int crop_x, int oh,
+                                     int ow, float m0, float m1, float m2, float s0, float s1, float s2, float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= ow) return;
+  const int ry = y + crop_y, rx = x + crop_x;
+  const float* w = wy + (size_t)ry * taps;
+  const int n = ysize[ry];
+  const float* col = tmp + ((size_t)ymin[ry] * rs_w + rx) * 3;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const float wj = w[j];
+    const float* p = col + (size_t)j * rs_w * 3;
+    if (j == 0) { a0 = p[0] * wj; a1 = p[1] * wj; a2 = p[2] * wj; }
+    else { a0 += p[0] * wj; a1 += p[1] * wj; a2 += p[2] * wj; }
+  }
+  const size_t plane = (size_t)oh * ow, o = (size_t)y * ow + x;
+  out[o] = (a0 - m0) / s0;
+  out[plane + o] = (a1 - m1) / s1;
+  out[2 * plane + o] = (a2 - m2) / s2;
+}
+
+}  // namespace
+
+// Returns hipSuccess or the failing HIP error.  `scratch` holds in_h * rs_w * 3 floats when a resize is requested.
+extern "C" hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y,
+                                           int crop_x, int oh, int ow, const float* mean, const float* stdv, float* out,
+                                           float* scratch, hipStream_t stream) {
+  const dim3 blk(256);
+  if (rs_h == in_h && rs_w == in_w) {
+    hipLaunchKernelGGL(u8_norm_kernel, dim3((ow + 255) / 256, oh), blk, 0, stream, img, row_bytes, crop_y, crop_x, oh, ow, mean[0],
+                       mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
+    return hipGetLastError();
+  }
+  TableCache& T = g_tab;
+  if (T.in_h != in_h || T.in_w != in_w || T.rs_h != rs_h || T.rs_w != rs_w) {
+    // the previous tables may still be read by kernels in flight on another stream: finish them before overwriting
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    build_axis(in_w, rs_w, T.tx);
+    build_axis(in_h, rs_h, T.ty);
+    const size_t n_int = 2 * (size_t)rs_w + 2 * (size_t)rs_h;
+    const size_t n_w = (size_t)rs_w * T.tx.taps + (size_t)rs_h * T.ty.taps;
+    if (n_int > T.cap_int) {
+      if (T.d_int) (void)hipFree(T.d_int);
+      if ((e = hipMalloc(&T.d_int, n_int * sizeof(int))) != hipSuccess) return e;
+      T.cap_int = n_int;
+    }
+    if (n_w > T.cap_w) {
+      if (T.d_w) (void)hipFree(T.d_w);
+      if ((e = hipMalloc(&T.d_w, n_w * sizeof(float))) != hipSuccess) return e;
+      T.cap_w = n_w;
+    }
+    T.h_int.clear();
+    T.h_int.insert(T.h_int.end(), T.tx.xmin.begin(), T.tx.xmin.end());
+    T.h_int.insert(T.h_int.end(), T.tx.xsize.begin(), T.tx.xsize.end());
+    T.h_int.insert(T.h_int.end(), T.ty.xmin.begin(), T.ty.xmin.end());
+    T.h_int.insert(T.h_int.end(), T.ty.xsize.begin(), T.ty.xsize.end());
+    T.h_w.clear();
+    T.h_w.insert(T.h_w.end(), T.tx.w.begin(), T.tx.w.end());
+    T.h_w.insert(T.h_w.end(), T.ty.w.begin(), T.ty.w.end());
+    if ((e = hipMemcpy(T.d_int, T.h_int.data(), n_int * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(T.d_w, T.h_w.data(), n_w * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    T.in_h = in_h; T.in_w = in_w; T.rs_h = rs_h; T.rs_w = rs_w;
+  }
+  const int* xmin = T.d_int;
+  const int* xsize = T.d_int + rs_w;
+  const int* ymin = T.d_int + 2 * rs_w;
+  const int* ysize = ymin + rs_h;
+  const float* wx = T.d_w;
+  const float* wy = T.d_w + (size_t)rs_w * T.tx.taps;
+  hipLaunchKernelGGL(u8_resize_w_kernel, dim3((rs_w + 255) / 256, in_h), blk, 0, stream, img, row_bytes, in_h, rs_w, T.tx.taps, xmin,
+                     xsize, wx, scratch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(resize_h_norm_kernel, dim3((ow + 255) / 256, oh), blk, 0, stream, scratch, rs_w, T.ty.taps, ymin, ysize, wy, crop_y,
+                     crop_x, oh, ow, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
+  return hipGetLastError();
+}

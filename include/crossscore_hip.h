@@ -113,6 +113,14 @@ int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int l
 int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
                     uint16_t* out_bf16, cs_stream stream);
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream);
+/* Input stage: device uint8 HWC image (3 channels, rows in_row_bytes apart) -> fp32 CHW [3][out_h][out_w], the
+ * tensor cs_forward consumes.  Same operations, in the same order, as the reference's CPU transforms: x/255 (utils/io/images.py:14-29),
+ * antialiased bilinear resize to (rs_h, rs_w) (T.Resize, task/predict.py:87-93; skipped when equal to the input size), crop window
+ * (crop_y, crop_x, out_h, out_w) of the resized image (dataloading/transformation/crop.py:8-25, nvs_dataset.py:227-241), then
+ * (v - mean) / std (T.Normalize, task/predict.py:68-74).  mean3 / std3 are HOST pointers; scratch (device, in_h*rs_w*3 floats) is
+ * needed only when resizing.  Filter tables of the last size pair are cached in the library (not thread-safe, like the handle). */
+int cs_op_preprocess_u8(const uint8_t* img, int in_h, int in_w, int in_row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int out_h,
+                        int out_w, const float* mean3, const float* std3, float* out, float* scratch, cs_stream stream);
 int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream);
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
 /* fp32 [rows][K] -> bf16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the

@@ -12,7 +12,7 @@ o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 for ns in (2, 3, 4, 5):
     out = f"/tmp/libcs_ns{ns}.so"
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCS_ABLATE", f"-DCS_NS_OVERRIDE={ns}",
-                           "-Wno-unused-value", "-o", out] + [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "attention.hip", "elementwise.hip")])
+                           "-Wno-unused-value", "-o", out] + [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "preprocess.hip")])
     _lib._lib = None; _lib.LIB_PATH = out
     line = [f"NS={ns} (128x128 tiles, {2*(ns-1)*16} KB in flight per CU):"]
     for ab, nm in ((0, "full"), (3, "dma-only"), (1, "no-epilogue")):

@@ -6,7 +6,7 @@ sys.path.insert(0, REPO)
 src = os.path.join(REPO, "crossscore_amd", "csrc")
 out = "/tmp/libcs_ablate.so"
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCS_ABLATE", "-Wno-unused-value",
-                       "-o", out] + [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "attention.hip", "elementwise.hip")])
+                       "-o", out] + [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "preprocess.hip")])
 from crossscore_amd import _lib
 _lib.LIB_PATH = out
 sys.path.insert(0, os.path.join(REPO, "tests"))
