@@ -48,6 +48,8 @@ SYMBOLS = {
     "cs_op_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cs_op_pos_bicubic": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pe_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cs_op_score_to_gray16": (_i, [_vp, C.c_longlong, _i, _vp, _vp]),
+    "cs_op_score_to_rgb": (_i, [_vp, C.c_longlong, C.c_float, C.c_float, _vp, _vp, _vp]),
     "cs_op_preprocess_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _vp]),
     "cs_op_pack_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "cs_op_ln_fold_consts": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -38,6 +38,8 @@ hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
+hipError_t cs_score_gray16_launch(const float* score, size_t n, int signed_range, uint16_t* out, hipStream_t stream);
+hipError_t cs_score_rgb_launch(const float* score, size_t n, float vmin, float vmax, const uint8_t* lut, uint8_t* out, hipStream_t stream);
 hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int oh,
                                 int ow, const float* mean, const float* stdv, float* out, float* scratch, hipStream_t stream);
 }
@@ -820,6 +822,18 @@ int cs_op_preprocess_u8(const uint8_t* img, int in_h, int in_w, int in_row_bytes
     if (!(std3[c] > 0.f)) return fail(CS_ERR_BAD_ARG, "preprocess_u8: std must be positive");
   HIPCHK(cs_preprocess_launch(img, in_h, in_w, in_row_bytes, rs_h, rs_w, crop_y, crop_x, out_h, out_w, mean3, std3, out, scratch,
                               (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_score_to_gray16(const float* score, long long n, int signed_range, uint16_t* out, cs_stream stream) {
+  if (!score || !out || n <= 0 || (signed_range != 0 && signed_range != 1)) return fail(CS_ERR_BAD_ARG, "score_to_gray16: bad arguments");
+  HIPCHK(cs_score_gray16_launch(score, (size_t)n, signed_range, out, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_score_to_rgb(const float* score, long long n, float vmin, float vmax, const uint8_t* lut256x3, uint8_t* out, cs_stream stream) {
+  if (!score || !out || !lut256x3 || n <= 0 || !(vmax > vmin)) return fail(CS_ERR_BAD_ARG, "score_to_rgb: bad arguments");
+  HIPCHK(cs_score_rgb_launch(score, (size_t)n, vmin, vmax, lut256x3, out, (hipStream_t)stream));
   return 0;
 }
 

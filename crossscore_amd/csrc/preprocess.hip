@@ -1,4 +1,4 @@
-// Input stage of the predict path on the GPU: uint8 HWC image -> the fp32, ImageNet-normalised CHW tensor that
+// Input stage and output stage (8f-2, end of file) of the predict path on the GPU.  Input: uint8 HWC image -> the fp32, ImageNet-normalised CHW tensor that
 // cs_forward consumes.  Replaces the reference's CPU transforms
 //   image_read: np.float32(img) / 255.0                                           utils/io/images.py:14-29
 //   T.Resize(short side, BILINEAR, antialias=True) on the float CHW tensor        task/predict.py:87-93, nvs_dataset.py:218-225
@@ -125,7 +125,48 @@ __global__ void resize_h_norm_kernel(const float* __restrict__ tmp, int rs_w, in
   out[2 * plane + o] = (a2 - m2) / s2;
 }
 
+// ---- output stage: score map -> the integer images the reference's writers store ----
+// gray: metric_map_write (utils/io/images.py:49-63): m*65535 for the [0,1] intrinsic range, (m+1)*32767 for [-1,1], truncated
+// (numpy astype(int32)), stored as 16-bit PNG samples.  Same fp32 operations -> identical integers.
+__global__ void score_gray16_kernel(const float* __restrict__ score, size_t n, int signed_range, uint16_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float m = score[i];
+  const float v = signed_range ? (m + 1.0f) * 32767.0f : m * 65535.0f;
+  const int q = (int)v;  // truncation toward zero, like astype(int32)
+  out[i] = (uint16_t)(q < 0 ? 0 : (q > 65535 ? 65535 : q));
+}
+
+// rgb: gray2rgb (utils/misc/image.py:37-52) = matplotlib Normalize(vmin, vmax) in fp32, colormap lookup with N = 256 entries
+// (index = trunc(x*256), x == 1 -> 255, below 0 -> first, above -> last entry), u8() truncation folded into the 256x3 byte table.
+__global__ void score_rgb_kernel(const float* __restrict__ score, size_t n, float vmin, float vmax, const uint8_t* __restrict__ lut,
+                                 uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = score[i] - vmin;
+  x = x / (vmax - vmin);
+  x = x * 256.0f;
+  int idx;
+  if (x == 256.0f) idx = 255;
+  else if (!(x >= 0.0f)) idx = 0;      // under (and NaN -> the "bad" colour is not reproduced: first entry)
+  else if (x >= 256.0f) idx = 255;     // over
+  else idx = (int)x;
+  out[3 * i] = lut[3 * idx];
+  out[3 * i + 1] = lut[3 * idx + 1];
+  out[3 * i + 2] = lut[3 * idx + 2];
+}
+
 }  // namespace
+
+extern "C" hipError_t cs_score_gray16_launch(const float* score, size_t n, int signed_range, uint16_t* out, hipStream_t stream) {
+  hipLaunchKernelGGL(score_gray16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, score, n, signed_range, out);
+  return hipGetLastError();
+}
+extern "C" hipError_t cs_score_rgb_launch(const float* score, size_t n, float vmin, float vmax, const uint8_t* lut, uint8_t* out,
+                                          hipStream_t stream) {
+  hipLaunchKernelGGL(score_rgb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, score, n, vmin, vmax, lut, out);
+  return hipGetLastError();
+}
 
 // Returns hipSuccess or the failing HIP error.  `scratch` holds in_h * rs_w * 3 floats when a resize is requested.
 extern "C" hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y,

@@ -1,0 +1,160 @@
+"""Predict-time data side of the drop-in: which files form a (query, N references) item, and the GPU input stage.
+
+Mirrors, for the predict path only:
+  SimpleReference.get_paths            dataloading/dataset/simple_reference.py:42-84   sorted listdir of query_dir / reference_dir
+  NeighbourSelector + SamplerRandom    dataloading/dataset/nvs_dataset.py:14-84, utils/neighbour/sampler.py:15-38
+  load_content / resize_all / crops / T.Normalize   nvs_dataset.py:218-279,429-470, task/predict.py:68-93
+The pixel work (x/255, antialiased resize, crop, normalise) runs on the GPU through cs_op_preprocess_u8 straight from the decoded
+uint8 image; only PNG/JPEG decoding stays on the host (PIL, as in utils/io/images.py:26-29).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synth import IMAGENET_MEAN_STD
+
+EMPTY = "empty_image"  # placeholder path the reference pads short reference lists with (sampler.py:22-27)
+
+
+def resized_output_size(h: int, w: int, short: int) -> Tuple[int, int]:
+    """torchvision T.Resize(int): the short side becomes `short`, the long side int(short * long / short_side)."""
+    if h <= w:
+        return short, int(short * w / h)
+    return int(short * h / w), short
+
+
+def list_paths(query_dir: str, reference_dir: str) -> Tuple[List[str], List[str]]:
+    """simple_reference.py:53-58: every entry of the two directories, sorted by name."""
+    query_dir, reference_dir = os.path.expanduser(query_dir), os.path.expanduser(reference_dir)
+    q = [os.path.join(query_dir, p) for p in sorted(os.listdir(query_dir))]
+    r = [os.path.join(reference_dir, p) for p in sorted(os.listdir(reference_dir))]
+    return q, r
+
+
+def sample_references(ref_list: Sequence[str], n_sample: int, deterministic: bool, rng=np.random) -> List[str]:
+    """SamplerRandom.sample (utils/neighbour/sampler.py:19-38): first N when deterministic, else N without replacement from the
+    global numpy RNG; a short list is padded with "empty_image" placeholders and permuted."""
+    ref_list = list(ref_list)
+    if n_sample > len(ref_list):
+        result = ref_list + [EMPTY] * (n_sample - len(ref_list))
+        return rng.permutation(result).tolist()
+    if deterministic:
+        return ref_list[:n_sample]
+    return rng.choice(ref_list, n_sample, replace=False).tolist()
+
+
+def read_image_u8(path: str) -> np.ndarray:
+    """Decoded uint8 HWC RGB image (utils/io/images.py:26-29 keeps whatever channel count PIL returns; the model needs 3)."""
+    from PIL import Image
+
+    img = np.array(Image.open(path))
+    if img.ndim == 2:
+        img = np.repeat(img[:, :, None], 3, axis=2)
+    if img.shape[2] == 4:
+        img = img[:, :, :3]
+    if img.dtype != np.uint8 or img.shape[2] != 3:
+        raise ValueError(f"{path}: expected an 8-bit RGB image, got {img.dtype} {img.shape}")
+    return np.ascontiguousarray(img)
+
+
+class InputStage:
+    """uint8 HWC images -> the normalised fp32 batch tensors CrossScoreNet.forward takes, on `device`."""
+
+    def __init__(self, device: torch.device, resize_short_side: int = 518, crop_size: Optional[int] = None, integer_patches: bool = False,
+                 patch: int = 14, mean_std: Sequence[float] = IMAGENET_MEAN_STD):
+        self.device = device
+        self.resize_short_side = int(resize_short_side)
+        self.crop_size = crop_size
+        self.integer_patches = integer_patches
+        self.patch = patch
+        self._mean = (C.c_float * 3)(*mean_std[:3])
+        self._std = (C.c_float * 3)(*mean_std[3:])
+        self._scratch: Optional[torch.Tensor] = None
+        ms = torch.tensor(list(mean_std), dtype=torch.float32)
+        self.zero_image_value = ((torch.zeros(3) - ms[:3]) / ms[3:]).to(device)  # a black pixel after T.Normalize
+
+    def geometry(self, h: int, w: int):
+        """(resized (h, w), crop (y, x, h, w)) for an input of h x w: resize_all, then the deterministic crop (crop.py:19-22: i = j = 0)
+        or the integer-patch crop (nvs_dataset.py:227-241)."""
+        rs = resized_output_size(h, w, self.resize_short_side) if self.resize_short_side > 0 else (h, w)
+        oh, ow = rs
+        if self.crop_size is not None:
+            oh = ow = int(self.crop_size)
+            if oh > rs[0] or ow > rs[1]:
+                raise ValueError(f"crop {oh}x{ow} larger than the resized image {rs[0]}x{rs[1]}")
+        elif self.integer_patches:
+            oh, ow = rs[0] - rs[0] % self.patch, rs[1] - rs[1] % self.patch
+        return rs, (0, 0, oh, ow)
+
+    def __call__(self, img_u8: np.ndarray, out: torch.Tensor) -> None:
+        """Writes the processed image into `out` ((3, oh, ow) fp32 slice on the device)."""
+        lib = _lib.load()
+        h, w, _ = img_u8.shape
+        rs, crop = self.geometry(h, w)
+        if tuple(out.shape) != (3, crop[2], crop[3]) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError(f"output slice must be contiguous fp32 (3,{crop[2]},{crop[3]}), got {tuple(out.shape)}")
+        d_img = torch.from_numpy(img_u8).to(self.device, non_blocking=False)
+        scratch = None
+        if rs != (h, w):
+            need = h * rs[1] * 3
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.empty((need,), dtype=torch.float32, device=self.device)
+            scratch = C.c_void_p(self._scratch.data_ptr())
+        _lib.check(lib.cs_op_preprocess_u8(C.c_void_p(d_img.data_ptr()), h, w, w * 3, rs[0], rs[1], crop[0], crop[1], crop[2], crop[3],
+                                           self._mean, self._std, C.c_void_p(out.data_ptr()), scratch,
+                                           C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        # d_img may be released once the stream has consumed it
+        d_img.record_stream(torch.cuda.current_stream(self.device))
+
+
+class SimpleReferenceItems:
+    """Index -> file paths of one item, like NeighbourSelector.__getitem__ for the single-scene layout of SimpleReference."""
+
+    def __init__(self, query_dir: str, reference_dir: str, neighbour_config) -> None:
+        if neighbour_config["strategy"] != "random":
+            raise NotImplementedError(f"neighbour strategy {neighbour_config['strategy']} (sampler.py:60-66 only knows 'random')")
+        self.query_paths, self.reference_paths = list_paths(query_dir, reference_dir)
+        self.n_cross = int(neighbour_config["cross"])
+        self.deterministic = bool(neighbour_config["deterministic"])
+
+    def __len__(self) -> int:
+        return len(self.query_paths)
+
+    def __getitem__(self, idx: int) -> Dict[str, object]:
+        refs = sample_references(self.reference_paths, self.n_cross, self.deterministic) if self.n_cross > 0 else []
+        return {"query/img": self.query_paths[idx], "query/score_map": EMPTY, "reference/cross/imgs": refs}
+
+
+def load_batch(items: List[Dict[str, object]], stage: InputStage, zero_reference: bool = False) -> Dict[str, object]:
+    """One batch dict with the keys `_core_step` reads (task/core.py:265-272) plus `item_paths` in the collated layout the
+    writers expect (default_collate turns the per-item list of N reference paths into N lists of B paths)."""
+    B = len(items)
+    q_imgs = [read_image_u8(it["query/img"]) for it in items]
+    geo = {stage.geometry(*im.shape[:2])[1][2:] for im in q_imgs}
+    if len(geo) != 1:
+        raise ValueError(f"query images of one batch must share the processed size, got {sorted(geo)}")
+    oh, ow = next(iter(geo))
+    N = len(items[0]["reference/cross/imgs"])
+    query = torch.empty((B, 3, oh, ow), dtype=torch.float32, device=stage.device)
+    refs = torch.empty((B, N, 3, oh, ow), dtype=torch.float32, device=stage.device)
+    for b, (it, qi) in enumerate(zip(items, q_imgs)):
+        stage(qi, query[b])
+        for n, p in enumerate(it["reference/cross/imgs"]):
+            if p == EMPTY or zero_reference:
+                # nvs_dataset.py:459-470: placeholders and zero_reference are all-zero images BEFORE T.Normalize -> (0 - mean) / std
+                refs[b, n] = stage.zero_image_value[:, None, None]
+                continue
+            ri = read_image_u8(p)
+            if stage.geometry(*ri.shape[:2])[1][2:] != (oh, ow):
+                raise ValueError(f"{p}: processed size differs from the query's {oh}x{ow}")
+            stage(ri, refs[b, n])
+    item_paths = {"query/img": [it["query/img"] for it in items], "query/score_map": [it["query/score_map"] for it in items],
+                  "reference/cross/imgs": [[it["reference/cross/imgs"][n] for it in items] for n in range(N)]}
+    return {"query/img": query, "reference/cross/imgs": refs, "item_paths": item_paths}

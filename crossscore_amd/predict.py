@@ -1,0 +1,125 @@
+"""`task/predict.py`-compatible driver for the MI355X path.
+
+    python -m crossscore_amd.predict trainer.ckpt_path_to_load=ckpt/CrossScore-v1.0.0.ckpt \\
+        data.dataset.query_dir=<dir> data.dataset.reference_dir=<dir> [any a.b=c override of config/default_predict.yaml]
+
+Same key tree and defaults as the reference's Hydra config (crossscore_amd/config/), same output tree:
+  out_dir naming                        task/predict.py:47-65
+  dataset / sampling / transforms       task/predict.py:67-108 -> crossscore_amd/data.py (GPU input stage)
+  model + checkpoint                    task/predict.py:120-141, task/core.py:173 -> crossscore_amd/model.py (state_dict keys "model.*")
+  per-batch writers, end-of-run CSV     task/core.py:214-225,419-441,483-484 -> crossscore_amd/writers.py
+What is not reproduced: Lightning's Trainer (one process per GPU is launched with torchrun instead of DDPStrategy; ranks take
+contiguous shards of the query list), DataLoader worker processes (so with `neighbour_config.deterministic=False` the random
+reference choice follows numpy's global RNG seeded with `lightning.seed` in this process, not Lightning's per-worker seeds), and the
+composite matplotlib "vis" figure.
+"""
+from __future__ import annotations
+
+import random
+import sys
+import time
+from datetime import datetime
+from pathlib import Path
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import parallel, synth
+from .config import load_config
+from .data import InputStage, SimpleReferenceItems, load_batch
+from .model import CrossScoreNet, load_lightning_checkpoint
+from .writers import BatchWriter, ScoreSummariser
+
+
+def resolve_out_dir(cfg, now: Optional[str] = None) -> str:
+    """task/predict.py:47-65."""
+    now = now or datetime.now().strftime("%Y%m%d_%H%M%S.%f")
+    if cfg.trainer.ckpt_path_to_load is None:
+        log_dir, test_dir_name = Path("log") / now, "predict_empty_ckpt"
+    else:
+        log_dir, test_dir_name = Path(cfg.trainer.ckpt_path_to_load).parents[1], "predict"
+    log_dir = log_dir / test_dir_name
+    log_dir.mkdir(parents=True, exist_ok=True)
+    out_dir = cfg.logger.predict.out_dir
+    if out_dir is None:
+        out_dir = f"{log_dir}/{now}"
+    if cfg.alias != "":
+        out_dir += f"_{cfg.alias}"
+    return out_dir
+
+
+def seed_everything(seed: int) -> None:
+    """lightning.seed_everything (task/predict.py:23): python, numpy and torch global generators."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Optional[str] = None) -> Dict[str, object]:
+    """Runs the predict loop; returns {"out_dir", "files", "rows", "query_images_per_sec"}."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("crossscore_amd.predict needs a GPU: the scoring path has no CPU fallback")
+    seed_everything(int(cfg.lightning.seed))
+    rank, local_rank, world = parallel.init_from_env()
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+    cfg.logger.predict.out_dir = resolve_out_dir(cfg, now)
+    Path(cfg.logger.predict.out_dir).mkdir(parents=True, exist_ok=True)
+
+    if cfg.this_main.crop_mode not in (None, "dataset_default"):
+        raise ValueError(f"crop_mode {cfg.this_main.crop_mode} not supported (task/predict.py:76-86 knows null and dataset_default)")
+    stage = InputStage(device, resize_short_side=int(cfg.this_main.resize_short_side),
+                       crop_size=int(cfg.data.transforms.crop_size) if cfg.this_main.crop_mode == "dataset_default" else None)
+    items = SimpleReferenceItems(cfg.data.dataset.query_dir, cfg.data.dataset.reference_dir, cfg.data.neighbour_config)
+
+    net = CrossScoreNet(cfg)
+    if state_dict is None:
+        if cfg.trainer.ckpt_path_to_load is not None:
+            state_dict = load_lightning_checkpoint(cfg.trainer.ckpt_path_to_load)
+        else:  # the reference would start from the hub's DINOv2 weights + a random decoder; there is no hub here
+            print("[crossscore_amd.predict] no checkpoint: seeded synthetic weights (scores are meaningless)", file=sys.stderr)
+            state_dict = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(net.arch, int(cfg.lightning.seed)).items()}
+    net.load_state_dict(state_dict, strict=True)
+    net = net.to(device)
+
+    writer = BatchWriter(cfg, "predict", net.img_mean_std, device) if cfg.logger.predict.write.flag.batch else None
+    summariser = ScoreSummariser(cfg.model.predict.metric.type, cfg.model.predict.metric.min, cfg.logger.predict.out_dir)
+
+    lo, hi = parallel.shard_bounds(len(items), world, rank)
+    bs = int(cfg.data.loader.validation.batch_size)
+    files, n_done, t_model = [], 0, 0.0
+    for batch_idx, start in enumerate(range(lo, hi, bs)):
+        batch = load_batch([items[i] for i in range(start, min(start + bs, hi))], stage, bool(cfg.data.dataset.zero_reference))
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        out = net(query_img=batch["query/img"], ref_cross_imgs=batch["reference/cross/imgs"], need_attn_weights=bool(cfg.model.need_attn_weights),
+                  need_attn_weights_head_id=int(cfg.model.need_attn_weights_head_id), norm_img=False)
+        torch.cuda.synchronize(device)
+        t_model += time.perf_counter() - t0
+        n_done += batch["query/img"].shape[0]
+        summariser.update(batch, out)
+        if writer is not None:
+            files += writer.write_out(batch, out, local_rank, batch_idx)
+    files += summariser.summarise()
+    parallel.barrier()
+    return {"out_dir": cfg.logger.predict.out_dir, "files": files, "rows": summariser.rows,
+            "query_images_per_sec": n_done / t_model if t_model > 0 else 0.0}
+
+
+def main(argv: Optional[Iterable[str]] = None) -> int:
+    overrides = list(sys.argv[1:] if argv is None else argv)
+    cfg = load_config("default_predict", overrides)
+    if cfg.data.dataset.query_dir is None or cfg.data.dataset.reference_dir is None:
+        print("usage: python -m crossscore_amd.predict data.dataset.query_dir=<dir> data.dataset.reference_dir=<dir> "
+              "[trainer.ckpt_path_to_load=<ckpt>] [a.b=c ...]", file=sys.stderr)
+        return 2
+    with torch.no_grad():
+        res = predict(cfg)
+    print(f"[crossscore_amd.predict] {len(res['rows'])} query images, {res['query_images_per_sec']:.1f} query-images/s in the model, "
+          f"outputs under {res['out_dir']}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -121,6 +121,12 @@ int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int 
  * needed only when resizing.  Filter tables of the last size pair are cached in the library (not thread-safe, like the handle). */
 int cs_op_preprocess_u8(const uint8_t* img, int in_h, int in_w, int in_row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int out_h,
                         int out_w, const float* mean3, const float* std3, float* out, float* scratch, cs_stream stream);
+/* Output stage: score map -> the integer images the reference's writers store (PNG compression stays on the host).
+ * gray16: metric_map_write, utils/io/images.py:49-63 (signed_range 1: (m+1)*32767 for the SSIM intrinsic range, 0: m*65535), truncated.
+ * rgb: gray2rgb, utils/misc/image.py:37-52 (Normalize(vmin,vmax), 256-entry colormap, u8 truncation); lut256x3 = the colormap's byte
+ * table on the device (matplotlib "turbo" in the reference). */
+int cs_op_score_to_gray16(const float* score, long long n, int signed_range, uint16_t* out, cs_stream stream);
+int cs_op_score_to_rgb(const float* score, long long n, float vmin, float vmax, const uint8_t* lut256x3, uint8_t* out, cs_stream stream);
 int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream);
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
 /* fp32 [rows][K] -> bf16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
