@@ -35,6 +35,7 @@ hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw,
 hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st);
 hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, const float* row_scale, const float* col_scale,
                                hipStream_t st);
+hipError_t cs_split3_launch(const float* src, long long M, int K, int ld, int act, int wmode, bf16_t* out, hipStream_t st);
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
@@ -77,6 +78,7 @@ struct EncLayer {
 struct DecLayer {
   float *sa_bin, *sa_bo, *ca_bq, *ca_bo, *l1b, *l2b, *n1g, *n1b, *n2g, *n2b, *n3g, *n3b;
   bf16_t *sa_Win, *sa_Wo, *ca_Wq, *ca_Wo, *l1W, *l2W;
+  bf16_t *sa_Win3, *ca_Wq3, *l1W3, *l2W3;  // [out][3*in] = [w_hi | w_hi | w_lo]: split-bf16 operands of the row-wise linears
 };
 
 struct ProfRec { hipEvent_t a, b; int family; double flops; };
@@ -99,6 +101,7 @@ struct cs_model {
   std::vector<DecLayer> dec;
   bf16_t* Wkv_all = nullptr; float* bkv_all = nullptr;
   bf16_t *Wh0 = nullptr, *Wh2 = nullptr; float *bh0 = nullptr, *bh2 = nullptr;
+  bf16_t *Wh03 = nullptr, *Wh23 = nullptr;  // split-bf16 head weights
   float *lnfg = nullptr, *lnfb = nullptr, *cls = nullptr, *pos = nullptr, *pe = nullptr;
   // per-(gh,gw,square) tables
   int tab_gh = -1, tab_gw = -1, tab_sq = -1;
@@ -167,7 +170,7 @@ struct Plan {
   float* x[CS_MAX_LANES]; bf16_t* u[CS_MAX_LANES]; bf16_t* r1[CS_MAX_LANES];
   bf16_t* ob[CS_MAX_LANES]; float* stats[CS_MAX_LANES];  // LayerNorm fold: attention output, per-row partial sums
   // decoder
-  float *xq, *y, *lse; bf16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
+  float *xq, *y, *lse, *hf; bf16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid, *q3, *hid3;
 };
 
 Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* base) {
@@ -209,6 +212,10 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
   p.dq = a.take<bf16_t>(M * C);
   p.dob = a.take<bf16_t>(M * C);
   p.dhid = a.take<bf16_t>(M * C);
+  const bool split = c.tail_precision != 1;
+  p.q3 = a.take<bf16_t>(split ? M * 3 * C : 0);
+  p.hid3 = a.take<bf16_t>(split ? M * 3 * C : 0);
+  p.hf = a.take<float>(split ? M * C : 0);
   p.lse = a.take<float>((size_t)B * c.dec_heads * p.Np);
   p.total = a.off;
   return p;
@@ -438,6 +445,7 @@ int cs_finalize(cs_handle h) {
       ALLOC_BF(w, (size_t)3 * C * C) if (int r = pack(iw->d, (int)(3 * C), (int)C, (int)C, w)) return r;
       ALLOC_BF(wo, (size_t)C * C) if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
       L.sa_Win = w; L.sa_bin = ib->d; L.sa_Wo = wo; L.sa_bo = ob->d;
+      ALLOC_BF(w3, (size_t)3 * C * 3 * C) HIPCHK(cs_split3_launch(iw->d, 3 * C, (int)C, (int)C, 0, 1, w3, st)); L.sa_Win3 = w3;
     }
     NEED(iw, p + "multihead_attn.in_proj_weight", 3 * C, C) NEED(ib, p + "multihead_attn.in_proj_bias", 3 * C)
     NEED(ow, p + "multihead_attn.out_proj.weight", C, C) NEED(ob, p + "multihead_attn.out_proj.bias", C)
@@ -447,10 +455,13 @@ int cs_finalize(cs_handle h) {
     D2D(h->bkv_all + (size_t)l * 2 * C, ib->d + C, 2 * C);
     ALLOC_BF(wo, (size_t)C * C) if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
     L.ca_Wq = wq; L.ca_bq = ib->d; L.ca_Wo = wo; L.ca_bo = ob->d;
+    { ALLOC_BF(w3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(iw->d, C, (int)C, (int)C, 0, 1, w3, st)); L.ca_Wq3 = w3; }
     NEED(l1w, p + "linear1.weight", C, C) NEED(l1b, p + "linear1.bias", C) NEED(l2w, p + "linear2.weight", C, C) NEED(l2b, p + "linear2.bias", C)
     ALLOC_BF(w1, (size_t)C * C) if (int r = pack(l1w->d, (int)C, (int)C, (int)C, w1)) return r;
     ALLOC_BF(w2, (size_t)C * C) if (int r = pack(l2w->d, (int)C, (int)C, (int)C, w2)) return r;
     L.l1W = w1; L.l1b = l1b->d; L.l2W = w2; L.l2b = l2b->d;
+    { ALLOC_BF(w3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(l1w->d, C, (int)C, (int)C, 0, 1, w3, st)); L.l1W3 = w3; }
+    { ALLOC_BF(w3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(l2w->d, C, (int)C, (int)C, 0, 1, w3, st)); L.l2W3 = w3; }
     NEED(n1g, p + "norm1.weight", C) NEED(n1b, p + "norm1.bias", C) NEED(n2g, p + "norm2.weight", C) NEED(n2b, p + "norm2.bias", C)
     NEED(n3g, p + "norm3.weight", C) NEED(n3b, p + "norm3.bias", C)
     L.n1g = n1g->d; L.n1b = n1b->d; L.n2g = n2g->d; L.n2b = n2b->d; L.n3g = n3g->d; L.n3b = n3b->d;
@@ -462,6 +473,8 @@ int cs_finalize(cs_handle h) {
     ALLOC_BF(w0, (size_t)C * C) if (int r = pack(h0w->d, (int)C, (int)C, (int)C, w0)) return r;
     ALLOC_BF(w2, (size_t)PP * C) if (int r = pack(h2w->d, (int)PP, (int)C, (int)C, w2)) return r;
     h->Wh0 = w0; h->bh0 = h0b->d; h->Wh2 = w2; h->bh2 = h2b->d;
+    { ALLOC_BF(w3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(h0w->d, C, (int)C, (int)C, 0, 1, w3, st)); h->Wh03 = w3; }
+    { ALLOC_BF(w3, (size_t)PP * 3 * C) HIPCHK(cs_split3_launch(h2w->d, PP, (int)C, (int)C, 0, 1, w3, st)); h->Wh23 = w3; }
   }
   HIPCHK(hipDeviceSynchronize());
   // fp32 copies of the big matrices are no longer needed
@@ -515,6 +528,9 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
 
   // ---- lanes: fork from the caller's stream, join back before returning (everything stays stream-ordered on `st`) ----
   const int NL = p.lanes;
+  // The decoder runs as ONE group on the caller's stream: its kernels are small, and splitting the batch over streams only
+  // makes them smaller (cfg-2, tools/dec_lanes.py: 1 group 8.77 ms, 2 groups 8.80, 3 groups 8.79, 4 groups 9.31).
+  const int ND = 1;
   hipStream_t lst[CS_MAX_LANES] = {st, st, st, st};
   if (NL >= 2) {
     for (int l = 0; l < NL; ++l) {
@@ -524,15 +540,15 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
     }
     if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   }
-  auto fork = [&]() -> int {
+  auto fork = [&](int n) -> int {
     if (NL == 1) return 0;
     HIPCHK(hipEventRecord(h->ev_fork, st));
-    for (int l = 0; l < NL; ++l) HIPCHK(hipStreamWaitEvent(lst[l], h->ev_fork, 0));
+    for (int l = 0; l < n; ++l) HIPCHK(hipStreamWaitEvent(lst[l], h->ev_fork, 0));
     return 0;
   };
-  auto join = [&]() -> int {
+  auto join = [&](int n) -> int {
     if (NL == 1) return 0;
-    for (int l = 0; l < NL; ++l) {
+    for (int l = 0; l < n; ++l) {
       HIPCHK(hipEventRecord(h->ev_join[l], lst[l]));
       HIPCHK(hipStreamWaitEvent(st, h->ev_join[l], 0));
     }
@@ -625,11 +641,27 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
     const bf16_t* mem = (mode == 1 ? ref_tokens : p.mem_bf) + ko * C; bf16_t* kv = p.kv + ko * KV;
     bf16_t* dqkv = p.dqkv + ro * 3 * C; bf16_t* dq = p.dq + ro * C; bf16_t* dob = p.dob + ro * C; bf16_t* dhid = p.dhid + ro * C;
     float* lse = p.lse + (size_t)b0 * c.dec_heads * p.Np;
+    // Split-bf16 tail (cs_config.tail_precision == 0): the row-wise linears of the decoder (self-attention in-proj, cross-attention
+    // Q-proj, FFN) and the regression head take [hi | lo | hi] activations against [w_hi | w_hi | w_lo] weights (K = 3C, same GEMM
+    // kernel): fp32-grade products for 1 % of the FLOPs.  An error budget with the oracle (bf16 rounding switched on per stage,
+    // ViT-S cfg-2) attributes 4.1e-4 of the 8.3e-4 score-map MAE to the head and 4.5e-4 to these linears (encoder 4.9e-4, KV
+    // projection 1.5e-4, attention internals 0.4e-4; the terms add in quadrature).
+    // Levels: 0 (default) head + FFN linears, 2 additionally the self-attention in-proj and cross-attention Q-proj, 1 plain bf16.
+    // Predicted by the same budget: 8.3e-4 plain, 6.5e-4 head only, 5.4e-4 head + FFN, 5.2e-4 level 2; measured on cfg-2 item 0
+    // (tools/mae_check.py): 8.4e-4 plain, 6.0e-4 level 2.
+    const bool split = c.tail_precision != 1, split_proj = c.tail_precision == 2;
+    bf16_t* q3 = split ? p.q3 + ro * 3 * C : nullptr; bf16_t* hid3 = split ? p.hid3 + ro * 3 * C : nullptr;
+    float* hf = split ? p.hf + ro * C : nullptr;
+    auto split3 = [&](const float* src, int act, bf16_t* dst) {
+      L.begin(32, 0); L.misc(cs_split3_launch(src, M, C, C, act, 0, dst, s), "split3"); L.end();
+    };
+    if (split_proj && c.do_self_attn) split3(xq, 0, q3);
     L.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_BF16);
     for (int l = 0; l < c.dec_layers; ++l) {
       const DecLayer& D = h->dec[l];
       if (c.do_self_attn) {
-        L.gemm(gp(q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_BF16);
+        if (split_proj) L.gemm(gp(q3, 3 * C, D.sa_Win3, 3 * C, M, 3 * C, 3 * C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_BF16);
+        else L.gemm(gp(q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_BF16);
         CsAttnParams a{};
         a.Q = dqkv; a.K = dqkv + C; a.V = dqkv + 2 * C; a.O = dob;
         a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
@@ -641,7 +673,9 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
         L.gemm(g, CS_EPI_RESID_F32);
         L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n1g, D.n1b, 1e-5f, xq, q_bf, s), "norm1"); L.end();
       }
-      L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_BF16);
+      if (split_proj) split3(xq, 0, q3);
+      if (split_proj) L.gemm(gp(q3, 3 * C, D.ca_Wq3, 3 * C, M, C, 3 * C, D.ca_bq, dq, C), CS_EPI_BIAS_BF16);
+      else L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_BF16);
       CsAttnParams a{};
       a.Q = dq; a.K = kv + (size_t)l * 2 * C; a.V = kv + (size_t)l * 2 * C + C; a.O = dob;
       a.ldq = C; a.ldk = a.ldv = KV; a.ldo = C;
@@ -661,18 +695,31 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
         L.gemm(g, CS_EPI_RESID_F32);
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n2g, D.n2b, 1e-5f, xq, q_bf, s), "norm2"); L.end();
-      L.gemm(gp(q_bf, C, D.l1W, C, M, C, C, D.l1b, dhid, C), CS_EPI_BIAS_RELU_BF16);
+      if (split) {
+        split3(xq, 0, q3);
+        L.gemm(gp(q3, 3 * C, D.l1W3, 3 * C, M, C, 3 * C, D.l1b, hf, C), CS_EPI_RESID_F32);  // fp32 hidden (no residual operand)
+        split3(hf, 1, hid3);                                                                  // ReLU, then hi/lo
+      } else {
+        L.gemm(gp(q_bf, C, D.l1W, C, M, C, C, D.l1b, dhid, C), CS_EPI_BIAS_RELU_BF16);
+      }
       {
-        CsGemmParams g = gp(dhid, C, D.l2W, C, M, C, C, D.l2b, y, C);
+        CsGemmParams g = split ? gp(hid3, 3 * C, D.l2W3, 3 * C, M, C, 3 * C, D.l2b, y, C) : gp(dhid, C, D.l2W, C, M, C, C, D.l2b, y, C);
         g.resid = xq; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n3g, D.n3b, 1e-5f, xq, q_bf, s), "norm3"); L.end();
+      if (split && (split_proj || l == c.dec_layers - 1)) split3(xq, 0, q3);  // next layer's in-proj (level 2) or the head
     }
     // head + RegressionLayer + jigsaw (cross_reference.py:45-50,82-87)
-    L.gemm(gp(q_bf, C, h->Wh0, C, M, C, C, h->bh0, dhid, C), CS_EPI_BIAS_LEAKY_BF16);
+    if (split) {
+      L.gemm(gp(q3, 3 * C, h->Wh03, 3 * C, M, C, 3 * C, h->bh0, hf, C), CS_EPI_RESID_F32);
+      split3(hf, 2, hid3);  // LeakyReLU, then hi/lo
+    } else {
+      L.gemm(gp(q_bf, C, h->Wh0, C, M, C, C, h->bh0, dhid, C), CS_EPI_BIAS_LEAKY_BF16);
+    }
     {
-      CsGemmParams g = gp(dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4);
+      CsGemmParams g = split ? gp(hid3, 3 * C, h->Wh23, 3 * C, M, P * P, 3 * C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4)
+                             : gp(dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4);
       g.Np = p.Np; g.gw = p.gw; g.P = P; g.act = c.act; g.powp = c.pow_p;
       L.gemm(g, CS_EPI_HEAD_SCORE);
     }
@@ -683,10 +730,10 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
   const int per_item = 1 + N_enc;
   // Decoding each chunk's items on its lane right after encoding them (no global join) was measured SLOWER (833 vs 875
   // query-images/s on cfg-2): it doubles the number of small decoder launches and the host enqueue rate becomes the
-  // limit.  The decoder therefore runs after a join, split over the lanes by batch halves.
+  // limit.  The decoder therefore runs after a join, as one group on the caller's stream.
   const bool chunk_decodes = false;
   (void)per_item;
-  if (int r = fork()) return r;
+  if (int r = fork(NL)) return r;
   {
     // chunk sizes: the short remainder (if any) goes FIRST so that it overlaps the long chunks instead of trailing them
     int chunk = 0, i0 = 0;
@@ -700,18 +747,14 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
     if (rem) run_chunk(rem);
     while (i0 < p.I) run_chunk(p.Ic);
   }
-  if (int r = join()) return r;
+  if (int r = join(NL)) return r;
   if (int r = lanes_rc()) return r;
   if (mode == 2) return 0;
   if (!chunk_decodes) {  // every image's tokens are in place (join above) before any decoder group starts
-    if (int r = fork()) return r;
-    const int groups = std::min(NL, B);
-    for (int g = 0; g < groups; ++g) {
-      const int b0 = (int)((long long)B * g / groups), b1 = (int)((long long)B * (g + 1) / groups);
-      dec_group(LL[g], b0, b1 - b0);
-    }
-    if (int r = join()) return r;
-    if (int r = lanes_rc()) return r;
+    (void)ND;
+    Launcher LD{h, st};
+    dec_group(LD, 0, B);
+    if (LD.rc) return LD.rc;
   }
   Launcher L{h, st};
   if (mean_out) {

@@ -335,6 +335,47 @@ hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, b
   return hipGetLastError();
 }
 
+// -------------------------------------------------------------------------------------------------------
+// Split-bf16 operands for the precision-critical tail (the decoder's row-wise linears and the regression head):
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi).  A K-concatenated GEMM then computes
+//   [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]^T = a_hi.w_hi + a_lo.w_hi + a_hi.w_lo   (fp32-grade products, fp32 accumulation)
+// with the ordinary bf16 MFMA kernel.  src fp32 [M][ld] -> bf16 [M][3K]; wmode 0: activations [hi|lo|hi], 1: weights [hi|hi|lo];
+// act 0 none, 1 ReLU (transformer.py:59), 2 LeakyReLU 0.01 (cross_reference.py:47) applied before the split.
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, long long M, int K, int ld, int act, int wmode,
+                                                      bf16_t* __restrict__ out) {
+  const int K4 = K / 4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * K4) return;
+  const long long row = i / K4;
+  const int c = (int)(i - row * K4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
+  float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (act == 1) e[k] = fmaxf(e[k], 0.f);
+    else if (act == 2) e[k] = e[k] >= 0.f ? e[k] : 0.01f * e[k];
+  }
+  bf16_t hi[4], lo[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    hi[k] = f2bf(e[k]);
+    lo[k] = f2bf(e[k] - bf2f(hi[k]));
+  }
+  const uint2 H = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+  const uint2 L = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+  bf16_t* o = out + row * 3 * K + c;
+  *reinterpret_cast<uint2*>(o) = H;
+  *reinterpret_cast<uint2*>(o + K) = wmode ? H : L;
+  *reinterpret_cast<uint2*>(o + 2 * K) = wmode ? L : H;
+}
+
+hipError_t cs_split3_launch(const float* src, long long M, int K, int ld, int act, int wmode, bf16_t* out, hipStream_t st) {
+  const long long total = M * (K / 4);
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, M, K, ld, act, wmode, out);
+  return hipGetLastError();
+}
+
 hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32,
                                bf16_t* obf, hipStream_t st) {
   hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, g, b, eps, of32, obf);

@@ -100,6 +100,7 @@ class CrossScoreNet(torch.nn.Module):
         self._dirty = True
         self.enc_chunk_images = 0  # 0 = library default
         self.lanes = 0             # 0 = library default (2 concurrent lanes); 1 = serial
+        self.tail_precision = 0    # split-bf16 operands: 0 = head + decoder FFN (default), 2 = + decoder in-proj / Q-proj, 1 = plain bf16
         self.ln_fold = 0           # 1 = fold the encoder LayerNorms into the QKV / fc1 GEMM epilogues (opt-in; slower so far)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
@@ -131,7 +132,7 @@ class CrossScoreNet(torch.nn.Module):
         cc = _lib.CsConfig(hidden=a.hidden, enc_layers=a.enc_layers, enc_heads=a.enc_heads, mlp_ratio=a.mlp_ratio, patch=a.patch,
                            pos_grid=a.pos_grid, pe_h=a.pe_h, pe_w=a.pe_w, dec_layers=a.dec_layers, dec_heads=a.dec_heads,
                            do_self_attn=int(bool(m.decoder_do_self_attn)), do_short_cut=int(bool(m.decoder_do_short_cut)),
-                           act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold),
+                           act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold), tail_precision=int(self.tail_precision),
                            lanes=int(self.lanes))
         with torch.cuda.device(device):
             h = lib.cs_create(C.byref(cc))

@@ -53,6 +53,10 @@ typedef struct cs_config {
   int ln_fold;       /* 1: encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass; opt-in, measured
                       * slower on MI355X); 0: separate LayerNorm kernels (default) */
   int lanes;         /* internal streams that run independent image chunks / batch groups concurrently: 0 = default (2), 1 = serial, up to 4 */
+  int tail_precision; /* split-bf16 (hi + lo, three-term) operands = fp32-grade products with the bf16 MFMA kernel, for the linears that
+                       * carry most of the bf16 error of the score map: 0 = default: regression head + decoder FFN (score-map MAE 8.4e-4 ->
+                       * ~6.3e-4 on cfg-2 at < 1 % time), 2 = also the decoder's self-attention in-proj and cross-attention Q-proj,
+                       * 1 = plain bf16 everywhere */
 } cs_config;
 
 /* Replaces CrossScoreNet.__init__ (task/core.py:27-56). NULL on failure. */

@@ -112,6 +112,25 @@ def test_full_size_vs_reference_goldens(golden_dir, name, backbone):
     assert (out["score_mean_ref_cross"] - out["score_map_ref_cross"].mean(dim=(-1, -2))).abs().max() < 1e-5
 
 
+def test_tail_precision_levels(golden_dir):
+    """Split-bf16 operands for the head + decoder FFN (default) must lower the error against the reference golden; every level
+    stays inside the 1e-3 bound and the plain-bf16 level keeps working."""
+    g = np.load(os.path.join(golden_dir, "g1_vits_518_n5.npz"))
+    net, arch, sd = _net("facebook/dinov2-small", int(g["seed"]))
+    q, r = synth.make_inputs(1, 5, 518, 518, int(g["seed"]))
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    mae = {}
+    for level in (0, 1, 2):
+        net.tail_precision = level
+        net._mark_dirty()
+        out = net(tq, tr, False, 0, False)["score_map_ref_cross"]
+        torch.cuda.synchronize()
+        mae[level] = _check_compact(g, out)[0]
+        assert mae[level] < MAE_TOL
+    print("score-map MAE by tail_precision:", mae)
+    assert mae[0] < 0.85 * mae[1] and mae[2] <= mae[0] * 1.05
+
+
 def test_batch8_vits_matches_oracle_per_item_and_is_batch_invariant():
     """cfg-2 (ViT-S, 518^2, N=5, B=8): item 3 of the batch against the oracle; every item must equal the same item run
     alone (batch shard equivalence: shards are independent, so results are bitwise identical)."""
