@@ -741,14 +741,30 @@ hipError_t launch(const CsGemmParams& p, hipStream_t stream) {
     if (p.ln_sp == 8) return launch_n<EPI, 2, 4>(p, stream);
     return launch_n<EPI, 2, 8>(p, stream);
   } else {
+#ifdef CS_ABLATE
+    if (const char* e = getenv("CS_GEMM_NSUB")) {  // timing experiment: force the 128-wide column tile
+      if (atoi(e) == 2 && p.N % 128 == 0) {
+        if constexpr (EPI == CS_EPI_RESID_F32) {
+          if (p.resid && p.K / BK >= 9) return launch_n<EPI, 2, 0, true>(p, stream);
+        }
+        return launch_n<EPI, 2, 0>(p, stream);
+      }
+    }
+#endif
+    // Narrow outputs (N <= 384: out-proj, fc2, the decoder's C x C linears) take the 128-wide tile: 1.5x as many tiles, so
+    // the persistent grid is fuller and its last round shorter (out-proj / fc2 at 12 images: 258 tiles of 192 columns leave
+    // half the block slots empty; measured -21 % at 16440 rows, -14 % at 32880, -2..-12 % at 65760).  The LayerNorm-stat
+    // producers keep the 192-wide tile (their partial-sum slots are sized by cs_gemm_column_tiles).
+    constexpr bool kNarrowOk = EPI != CS_EPI_PATCH_F32 && EPI != CS_EPI_RESID_F32_LN;
+    const bool wide = p.N % 192 == 0 && !(kNarrowOk && p.N % 128 == 0 && p.N <= 384);
     if constexpr (EPI == CS_EPI_RESID_F32) {
       // residual prefetch pipeline: needs a residual, >= 9 K slices (the 8 step-carrying slices + a last one) and 32-bit offsets
       if (p.resid && p.K / BK >= 9 && p.M >= 16 && p.N >= 16 && (long long)p.M * p.ldr * 4 < (1ll << 31)) {
-        if (p.N % 192 == 0) return launch_n<EPI, 3, 0, true>(p, stream);
+        if (wide) return launch_n<EPI, 3, 0, true>(p, stream);
         return launch_n<EPI, 2, 0, true>(p, stream);
       }
     }
-    if (p.N % 192 == 0) return launch_n<EPI, 3, 0>(p, stream);
+    if (wide) return launch_n<EPI, 3, 0>(p, stream);
     return launch_n<EPI, 2, 0>(p, stream);
   }
 }

@@ -27,7 +27,8 @@ for sn, (M, N, K, epi) in shapes.items():
     resid = torch.randn(M, N, device=dev) if epi == _lib.EPI_RESID_F32 else None
     o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.bfloat16)
     line = [f"{sn:8s} M={M} N={N} K={K}:"]
-    for tall in (0,):
+    for tall in [int(x) for x in os.environ.get("CS_ABL_NSUB", "3").split(",")]:
+        os.environ["CS_GEMM_NSUB"] = str(tall)
         for ab, nm in [(m, names.get(m & 7, "?") + ("+line128" if m & 8 else "")) for m in modes]:
             os.environ["CS_GEMM_ABLATE"] = str(ab)
             for _ in range(3):
