@@ -25,6 +25,7 @@ from crossscore_amd.model import CrossScoreNet  # noqa: E402
 from crossscore_amd import parallel  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0      # HBM3E peak, same table
 GEMM_EPI = ["BIAS_BF16", "BIAS_GELU_BF16", "BIAS_RELU_BF16", "BIAS_LEAKY_BF16", "RESID_F32", "PATCH_F32", "HEAD_SCORE",
             "LN_BF16", "LN_GELU_BF16", "RESID_F32_LN"]
 WORKLOADS = {
@@ -53,8 +54,32 @@ def kernel_table(net):
         if n == 0:
             continue
         name = (f"cs_gemm_kernel<{GEMM_EPI[fam]}>" if fam < 10 else f"cs_attn_kernel<{(fam - 16) * 16}>" if fam < 32 else "layernorm/im2col/other")
-        rows.append(dict(kernel=name, launches=n, total_ms=ms, avg_us=1e3 * ms / n, tflops=(fl / ms / 1e9) if fl else None, flops=fl))
+        by = net.profile_read_bytes(fam)
+        rows.append(dict(kernel=name, launches=n, total_ms=ms, avg_us=1e3 * ms / n, tflops=(fl / ms / 1e9) if fl else None, flops=fl,
+                         gbytes_per_s=(by / ms / 1e6) if by else None, flop_per_byte=(fl / by) if by else None, bytes=by))
     return rows
+
+
+def roofline_of(dom):
+    """Roofline entry of the dominant kernel family.  Its bound follows from its arithmetic intensity (algorithmic FLOPs over
+    algorithmic HBM bytes per launch, both recorded by the library next to the HIP-event timings) against the ridge point
+    peak_flops / peak_bandwidth = 312.5 FLOP/B: below it the kernel is HBM-bound and `achieved` is algorithmic bytes over the
+    launch duration, above it MFMA-bound and `achieved` is algorithmic FLOPs over the duration.  The other view is kept too."""
+    ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    ai = dom["flop_per_byte"]
+    hbm = ai is not None and ai < ridge
+    r = {"bound": "hbm" if hbm else "mfma", "kernel": dom["kernel"],
+         "achieved": dom["gbytes_per_s"] if hbm else dom["tflops"], "peak": PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS,
+         "unit": "GB/s" if hbm else "TFLOP/s"}
+    r["frac"] = r["achieved"] / r["peak"]
+    r.update({"traffic": pmc_traffic(dom["kernel"]),
+              "measured": "HIP events around each launch on its stream, kernel alone on the GPU (1 lane, whole batch per chunk)",
+              "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
+              "flop_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+              "flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+              "mfma_view": {"achieved_tflops": dom["tflops"], "frac_of_peak": dom["tflops"] / PEAK_BF16_TFLOPS,
+                            "frac_of_attainable": dom["tflops"] / min(PEAK_BF16_TFLOPS, ai * PEAK_HBM_GBS / 1e3) if ai else None}})
+    return r
 
 
 def pmc_traffic(kernel_name):
@@ -224,12 +249,8 @@ def main():
                        "gflop_per_query": flops_q / 1e9, "parallelism": f"batch-shard x{world} (replicas, no data-path collective)"},
             "whole_path": {"achieved_tflops": value * flops_q / 1e12 / world, "peak_tflops": PEAK_BF16_TFLOPS,
                            "frac": value * flops_q / 1e12 / world / PEAK_BF16_TFLOPS},
-            "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom["kernel"]),
-                         "measured": "HIP events around each launch on its stream, kernel alone on the GPU (1 lane, whole batch per chunk)",
-                         "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
-                         "flop_per_launch": dom["flops"] / dom["launches"]},
-            "kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in x.items() if k != "flops"} for x in rows],
+            "roofline": roofline_of(dom),
+            "kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in x.items() if k not in ("flops", "bytes")} for x in rows],
         }
         if args.kernels:
             for x in rows:

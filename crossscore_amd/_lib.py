@@ -40,6 +40,7 @@ SYMBOLS = {
     "cs_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "cs_profile_enable": (_i, [_vp, _i]),
     "cs_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "cs_profile_read_bytes": (_i, [_vp, _i, C.POINTER(C.c_double)]),
     "cs_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _f,
                         _vp, _vp, _i, _vp, _i, _vp, _f, _vp]),
     "cs_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp]),

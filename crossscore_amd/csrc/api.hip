@@ -81,7 +81,7 @@ struct DecLayer {
   bf16_t *sa_Win3, *ca_Wq3, *l1W3, *l2W3;  // [out][3*in] = [w_hi | w_hi | w_lo]: split-bf16 operands of the row-wise linears
 };
 
-struct ProfRec { hipEvent_t a, b; int family; double flops; };
+struct ProfRec { hipEvent_t a, b; int family; double flops; double bytes; };
 constexpr int CS_MAX_LANES = 4;
 
 }  // namespace
@@ -224,9 +224,9 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
 // launch helpers that record profiling events when enabled
 struct Launcher {
   cs_model* m; hipStream_t st; int rc = 0;
-  void begin(int family, double flops) {
+  void begin(int family, double flops, double bytes = 0) {
     if (!m->prof) return;
-    ProfRec r{}; r.family = family; r.flops = flops;
+    ProfRec r{}; r.family = family; r.flops = flops; r.bytes = bytes;
     hipEventCreate(&r.a); hipEventCreate(&r.b);
     hipEventRecord(r.a, st);
     m->recs.push_back(r);
@@ -235,7 +235,13 @@ struct Launcher {
   bool gemm(CsGemmParams g, int epi, double k_real = 0) {
     if (rc) return false;
     if (const char* e = cs_gemm_check(&g, epi)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
-    begin(epi, 2.0 * g.M * g.N * (k_real > 0 ? k_real : g.K));
+    // algorithmic HBM bytes of one launch: A and W once (bf16), bias, the output once, the residual / position addend once
+    const double mn = (double)g.M * g.N;
+    const bool f32out = epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32 || epi == CS_EPI_HEAD_SCORE;
+    double bytes = 2.0 * g.M * g.K + 2.0 * g.N * g.K + 4.0 * g.N + mn * (f32out ? 4.0 : 2.0);
+    if ((epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN) && g.resid) bytes += 4.0 * mn;
+    if (epi == CS_EPI_PATCH_F32) bytes += 4.0 * g.Np * g.N;
+    begin(epi, 2.0 * g.M * g.N * (k_real > 0 ? k_real : g.K), bytes);
     hipError_t e = cs_gemm_launch(&g, epi, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "gemm launch: %s", hipGetErrorString(e)); return false; }
@@ -244,7 +250,8 @@ struct Launcher {
   bool attn(CsAttnParams a, int dh, int batch) {
     if (rc) return false;
     if (const char* e = cs_attn_check(&a, dh, batch)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
-    begin(16 + dh / 16, 4.0 * batch * a.heads * (double)a.Lq * a.Lk * dh);
+    // Q and O once, K and V once per (batch, head): 2 bytes each
+    begin(16 + dh / 16, 4.0 * batch * a.heads * (double)a.Lq * a.Lk * dh, 2.0 * batch * a.heads * dh * (2.0 * a.Lq + 2.0 * a.Lk));
     hipError_t e = cs_attn_launch(&a, dh, batch, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "attention launch: %s", hipGetErrorString(e)); return false; }
@@ -783,6 +790,15 @@ int cs_profile_enable(cs_handle h, int on) {
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   h->recs.clear();
   h->prof = on != 0;
+  return 0;
+}
+
+int cs_profile_read_bytes(cs_handle h, int family, double* bytes) {
+  if (!h || !bytes) return fail(CS_ERR_BAD_ARG, "null argument");
+  double b = 0;
+  for (auto& r : h->recs)
+    if (r.family == family) b += r.bytes;
+  *bytes = b;
   return 0;
 }
 

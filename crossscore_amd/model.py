@@ -261,6 +261,11 @@ class CrossScoreNet(torch.nn.Module):
         _lib.check(_lib.load().cs_profile_read(self._handle, family, C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
 
+    def profile_read_bytes(self, family: int) -> float:
+        b = C.c_double()
+        _lib.check(_lib.load().cs_profile_read_bytes(self._handle, family, C.byref(b)))
+        return b.value
+
 
 def load_lightning_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     """`state_dict` of a CrossScore Lightning checkpoint with the "model." prefix removed

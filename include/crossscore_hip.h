@@ -98,6 +98,8 @@ size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
  * (LayerNorm, im2col, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */
 int cs_profile_enable(cs_handle h, int on);
 int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, double* flops);
+/* algorithmic HBM bytes (operands and results once each) of the recorded launches of one family */
+int cs_profile_read_bytes(cs_handle h, int family, double* bytes);
 
 /* ---- single-op entry points (used by the parity tests; same kernels the forward launches) ------------- */
 /* out = epilogue(bias + A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. bf16 = raw uint16. */
