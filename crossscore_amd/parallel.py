@@ -36,7 +36,12 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            # bind this process to its GPU before the first collective (RCCL picks the current device for barrier / all_reduce)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 

@@ -1,0 +1,151 @@
+/* C ABI of libcrossscore_hip.so -- the MI355X (gfx950) CrossScore inference hot path.
+ *
+ * The reference (ActiveVisionLab/CrossScore) is pure Python and has no native interface; the boundary this
+ * library sits behind is the model call
+ *     CrossScoreNet.forward(query_img, ref_cross_imgs, need_attn_weights, need_attn_weights_head_id, norm_img)
+ *         -> {"score_map_ref_cross", "attn_weights_map_ref_cross"}            (task/core.py:58-117)
+ * made from CrossScoreLightningModule._core_step (task/core.py:265-272).  Each entry point below names the
+ * reference code it replaces.  Plain pointers and sizes only: no torch / Python types cross this line.
+ *
+ * Ownership: the caller (PyTorch) owns every input / output / weight-source buffer; the library owns only its
+ * packed bf16 weights and its workspace.  Threading: a handle is not thread-safe; one handle per process per
+ * GPU.  All work is enqueued on the caller's hipStream_t; no entry point synchronises the device except
+ * cs_finalize, cs_profile_* and cs_destroy.  Every function returning int returns 0 on success; on failure
+ * cs_last_error() describes it (CS_ERR_* below) and nothing was launched on the bad-argument paths.
+ */
+#ifndef CROSSSCORE_HIP_H
+#define CROSSSCORE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cs_model* cs_handle;
+typedef void* cs_stream; /* hipStream_t */
+
+enum {
+  CS_OK = 0,
+  CS_ERR_BAD_ARG = 1,     /* shape / config the reference would also reject (ValueError / assert) */
+  CS_ERR_UNSUPPORTED = 2, /* legal for the reference, not built here (e.g. head dim outside {16,48,64,96}) */
+  CS_ERR_STATE = 3,       /* wrong call order (forward before finalize, missing weight) */
+  CS_ERR_HIP = 4          /* HIP runtime error; message carries hipGetErrorString */
+};
+
+/* Architecture + the model.* config keys the forward consumes (config/model/model.yaml:1-32). */
+typedef struct cs_config {
+  int hidden;        /* C: Dinov2Config.hidden_size (384 small / 768 base), task/core.py:39 */
+  int enc_layers;    /* Dinov2Config.num_hidden_layers */
+  int enc_heads;     /* Dinov2Config.num_attention_heads (head dim must be 64 or 16) */
+  int mlp_ratio;     /* 4 */
+  int patch;         /* model.patch_size = 14 */
+  int pos_grid;      /* sqrt(#position_embeddings - 1) = 37 */
+  int pe_h, pe_w;    /* model.pos_enc.multi_view.{h,w} = 40,40 (bilinear, align_corners=True) */
+  int dec_layers;    /* 2, model/cross_reference.py:38 */
+  int dec_heads;     /* 8, model/cross_reference.py:31 */
+  int do_self_attn;  /* model.decoder_do_self_attn */
+  int do_short_cut;  /* model.decoder_do_short_cut */
+  int act;           /* 0 sigmoid (metric.min == 0), 1 tanh (metric.min == -1), model/regression_layer.py:31-38 */
+  float pow_p;       /* exponent after the activation; 1 = identity, model/regression_layer.py:40-62 */
+  int enc_chunk_images; /* images per encoder pass (0 = library default) */
+  int ln_fold;       /* 1: encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass; opt-in, measured
+                      * slower on MI355X); 0: separate LayerNorm kernels (default) */
+  int lanes;         /* internal streams that run independent image chunks / batch groups concurrently: 0 = default (2), 1 = serial, up to 4 */
+  int tail_precision; /* split-bf16 (hi + lo, three-term) operands = fp32-grade products with the bf16 MFMA kernel, for the linears that
+                       * carry most of the bf16 error of the score map: 0 = default: regression head + decoder FFN (score-map MAE 8.4e-4 ->
+                       * ~6.3e-4 on cfg-2 at < 1 % time), 2 = also the decoder's self-attention in-proj and cross-attention Q-proj,
+                       * 1 = plain bf16 everywhere */
+} cs_config;
+
+/* Replaces CrossScoreNet.__init__ (task/core.py:27-56). NULL on failure. */
+cs_handle cs_create(const cs_config* cfg);
+void cs_destroy(cs_handle h);
+const char* cs_last_error(void);
+
+/* Replaces load_state_dict for one tensor: `name` is the checkpoint key without the "model." prefix (ckpt layout:
+ * SURVEY.md 8b), `data` fp32, row-major, host or device memory (is_device), `shape[ndim]` as in the state dict. */
+int cs_set_weight(cs_handle h, const char* name, const float* data, int is_device, int ndim, const int64_t* shape);
+/* Number of tensors cs_finalize expects and the i-th expected name (for loaders / strict checking). */
+int cs_num_weights(cs_handle h);
+const char* cs_weight_name(cs_handle h, int i);
+/* Packs weights to bf16 / fused layouts (QKV, both decoder layers' KV). Fails if a tensor is missing. */
+int cs_finalize(cs_handle h);
+
+/* Replaces CrossScoreNet.forward (task/core.py:58-117) with norm_img=False.
+ *   query:  (B,3,H,W) fp32 device, contiguous;   refs: (B,N,3,H,W) fp32 device, contiguous
+ *   score_out: (B, P*(H/P), P*(W/P)) fp32 device
+ *   attn_out:  NULL, or (B, h, w, N, h, w) fp32 device = probabilities of head `head_id` of the LAST decoder
+ *              layer's cross-attention (model/cross_reference.py:91-93)
+ *   mean_out:  NULL, or (B) fp32 device = per-image mean of the score map (utils/io/score_summariser.py:180-192) */
+int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N, int H, int W, float* score_out,
+               float* attn_out, int head_id, float* mean_out, cs_stream stream);
+/* Reference-feature cache.  In predict the N references of every query are drawn from one finite
+ * reference_dir (dataloading/dataset/simple_reference.py:55-58, utils/neighbour/sampler.py:27-34), and a reference's
+ * decoder input -- final LayerNorm of its DINOv2 tokens + multi-view PE, task/core.py:141-153,93-98 -- does not depend on the
+ * query or on its view slot.  cs_encode_references encodes R images once into bf16 tokens (R, h*w, C); cs_forward_cached
+ * scores B queries against gathered tokens (B, N, h*w, C).  Results are bit-identical to cs_forward on the same images; the
+ * encoder work per query drops from 1+N images to 1 (a separate mode: it changes the algorithmic FLOPs). */
+int cs_encode_references(cs_handle h, const float* imgs, int R, int H, int W, uint16_t* tokens_out, cs_stream stream);
+int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_tokens, int B, int N, int H, int W,
+                      float* score_out, float* attn_out, int head_id, float* mean_out, cs_stream stream);
+/* Bytes of library-owned workspace a forward of this shape needs (grown lazily, never shrunk). */
+size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
+
+/* Per-kernel-family timing with HIP events on the launch stream (for bench.py's roofline object).
+ * Families = kernel symbols: 0..6 cs_gemm_kernel<epilogue>, 16 + dh/16 cs_attn_kernel<dh>, 32 everything else
+ * (LayerNorm, im2col, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */
+int cs_profile_enable(cs_handle h, int on);
+int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, double* flops);
+/* algorithmic HBM bytes (operands and results once each) of the recorded launches of one family */
+int cs_profile_read_bytes(cs_handle h, int family, double* bytes);
+
+/* ---- single-op entry points (used by the parity tests; same kernels the forward launches) ------------- */
+/* out = epilogue(bias + A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. bf16 = raw uint16. */
+int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
+               const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np,
+               int gw, int P, int act, float powp,
+               /* LayerNorm fold (CsEpilogue 7-9): producer outputs, then consumer inputs; NULL / 0 when unused */
+               uint16_t* out_bf16, float* stats_out, int stats_sp, const float* ln_part, int ln_sp, const float* col_s,
+               float ln_eps, cs_stream stream);
+/* softmax(QK^T/sqrt(dh))V for `batch` x `heads`; strides in elements; lse may be NULL. */
+int cs_op_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* V, uint16_t* O, int ldq, int ldk, int ldv,
+                    int ldo, long long q_bs, long long k_bs, long long v_bs, long long o_bs, int batch, int heads,
+                    int Lq, int Lk, int dh, float* lse, cs_stream stream);
+int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int ldk, long long q_bs, long long k_bs,
+                            int batch, int heads, int Lq, int Lk, int dh, const float* lse, int head, float* out,
+                            cs_stream stream);
+int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
+                    uint16_t* out_bf16, cs_stream stream);
+int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream);
+/* Input stage: device uint8 HWC image (3 channels, rows in_row_bytes apart) -> fp32 CHW [3][out_h][out_w], the
+ * tensor cs_forward consumes.  Same operations, in the same order, as the reference's CPU transforms: x/255 (utils/io/images.py:14-29),
+ * antialiased bilinear resize to (rs_h, rs_w) (T.Resize, task/predict.py:87-93; skipped when equal to the input size), crop window
+ * (crop_y, crop_x, out_h, out_w) of the resized image (dataloading/transformation/crop.py:8-25, nvs_dataset.py:227-241), then
+ * (v - mean) / std (T.Normalize, task/predict.py:68-74).  mean3 / std3 are HOST pointers; scratch (device, in_h*rs_w*3 floats) is
+ * needed only when resizing.  Filter tables of the last size pair are cached in the library (not thread-safe, like the handle). */
+int cs_op_preprocess_u8(const uint8_t* img, int in_h, int in_w, int in_row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int out_h,
+                        int out_w, const float* mean3, const float* std3, float* out, float* scratch, cs_stream stream);
+/* Output stage: score map -> the integer images the reference's writers store (PNG compression stays on the host).
+ * gray16: metric_map_write, utils/io/images.py:49-63 (signed_range 1: (m+1)*32767 for the SSIM intrinsic range, 0: m*65535), truncated.
+ * rgb: gray2rgb, utils/misc/image.py:37-52 (Normalize(vmin,vmax), 256-entry colormap, u8 truncation); lut256x3 = the colormap's byte
+ * table on the device (matplotlib "turbo" in the reference). */
+int cs_op_score_to_gray16(const float* score, long long n, int signed_range, uint16_t* out, cs_stream stream);
+int cs_op_score_to_rgb(const float* score, long long n, float vmin, float vmax, const uint8_t* lut256x3, uint8_t* out, cs_stream stream);
+int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream);
+int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
+/* fp32 [rows][K] -> bf16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
+ * rows of a projection, LayerNorm gamma into its columns */
+int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
+                    cs_stream stream);
+/* LayerNorm fold constants of a projection: s[n] = sum_k packed W'[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] */
+int cs_op_ln_fold_consts(const uint16_t* w_packed, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
+                         float* s_out, float* c_out, cs_stream stream);
+/* number of column tiles the GEMM launcher uses for N output columns (LayerNorm partial-sum slots per row = 4 x this) */
+int cs_gemm_column_tiles(int N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
