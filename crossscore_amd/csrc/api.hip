@@ -111,8 +111,6 @@ struct cs_model {
   // lanes: internal streams that run independent image chunks / batch groups concurrently (forked from and joined to
   // the caller's stream with events), so one kernel's tail and the memory-bound stages overlap another's MFMA work
   hipStream_t lane_st[CS_MAX_LANES] = {};
-  hipStream_t dec_st = nullptr;                       // decodes the first half of the batch while the lanes still encode the second
-  hipEvent_t ev_half[CS_MAX_LANES] = {}, ev_dec = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join[CS_MAX_LANES] = {};
   // profiling
   bool prof = false;
@@ -335,9 +333,7 @@ void cs_destroy(cs_handle h) {
   if (h->pos_tab && h->pos_tab_owned) hipFree(h->pos_tab);
   if (h->pe_tab && h->pe_tab != h->pe) hipFree(h->pe_tab);
   if (h->ws) hipFree(h->ws);
-  for (int l = 0; l < CS_MAX_LANES; ++l) { if (h->lane_st[l]) hipStreamDestroy(h->lane_st[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); if (h->ev_half[l]) hipEventDestroy(h->ev_half[l]); }
-  if (h->dec_st) hipStreamDestroy(h->dec_st);
-  if (h->ev_dec) hipEventDestroy(h->ev_dec);
+  for (int l = 0; l < CS_MAX_LANES; ++l) { if (h->lane_st[l]) hipStreamDestroy(h->lane_st[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   delete h;
@@ -742,12 +738,8 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
   // Decoding each chunk's items on its lane right after encoding them (no global join) was measured SLOWER (833 vs 875
   // query-images/s on cfg-2): it doubles the number of small decoder launches and the host enqueue rate becomes the
   // limit.  The decoder therefore runs after a join, as one group on the caller's stream.
-  // What does pay: the items whose chunks are all enqueued after the first half of the chunk list are decoded on a THIRD stream
-  // while the lanes still encode the second half, so only the second half's decoder is exposed at the end of the step.
-  const int nchunks = (p.I + p.Ic - 1) / p.Ic;
-  int half_chunks = (nchunks / 2 / NL) * NL;  // whole rounds of the lanes
-  if (NL < 2 || mode == 2 || nchunks < 2 * NL) half_chunks = 0;
-  int half_imgs = 0;
+  const bool chunk_decodes = false;
+  (void)per_item;
   if (int r = fork(NL)) return r;
   {
     // chunk sizes: the short remainder (if any) goes FIRST so that it overlaps the long chunks instead of trailing them
@@ -756,38 +748,20 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
     auto run_chunk = [&](int ic) {
       Launcher& L = LL[chunk % NL];
       enc_chunk(L, chunk % NL, i0, ic);
+      if (chunk_decodes) dec_group(L, i0 / per_item, ic / per_item);
       i0 += ic; ++chunk;
-      if (half_chunks && chunk == half_chunks) half_imgs = i0;
     };
     if (rem) run_chunk(rem);
-    while (i0 < p.I) {
-      run_chunk(p.Ic);
-      if (half_chunks && chunk == half_chunks) {
-        if (half_imgs % per_item != 0) { half_chunks = 0; continue; }  // the boundary splits a batch item: no early decode
-        if (!h->dec_st) HIPCHK(hipStreamCreateWithFlags(&h->dec_st, hipStreamNonBlocking));
-        if (!h->ev_dec) HIPCHK(hipEventCreateWithFlags(&h->ev_dec, hipEventDisableTiming));
-        for (int l = 0; l < NL; ++l) {
-          if (!h->ev_half[l]) HIPCHK(hipEventCreateWithFlags(&h->ev_half[l], hipEventDisableTiming));
-          HIPCHK(hipEventRecord(h->ev_half[l], lst[l]));
-          HIPCHK(hipStreamWaitEvent(h->dec_st, h->ev_half[l], 0));
-        }
-        Launcher LD{h, h->dec_st};
-        dec_group(LD, 0, half_imgs / per_item);
-        if (LD.rc) return LD.rc;
-        HIPCHK(hipEventRecord(h->ev_dec, h->dec_st));
-      }
-    }
+    while (i0 < p.I) run_chunk(p.Ic);
   }
   if (int r = join(NL)) return r;
   if (int r = lanes_rc()) return r;
   if (mode == 2) return 0;
-  {  // the rest of the batch (all of it without the early group) on the caller's stream, then wait for the early group
+  if (!chunk_decodes) {  // every image's tokens are in place (join above) before any decoder group starts
     (void)ND;
-    const int b0 = half_chunks ? half_imgs / per_item : 0;
     Launcher LD{h, st};
-    if (b0 < B) dec_group(LD, b0, B - b0);
+    dec_group(LD, 0, B);
     if (LD.rc) return LD.rc;
-    if (half_chunks) HIPCHK(hipStreamWaitEvent(st, h->ev_dec, 0));
   }
   Launcher L{h, st};
   if (mean_out) {
