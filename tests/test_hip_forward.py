@@ -112,6 +112,23 @@ def test_full_size_vs_reference_goldens(golden_dir, name, backbone):
     assert (out["score_mean_ref_cross"] - out["score_map_ref_cross"].mean(dim=(-1, -2))).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("B,N,H,W", [(1, 1, 28, 28), (1, 4, 56, 42), (3, 1, 70, 98), (2, 3, 98, 57), (5, 2, 42, 42), (1, 6, 112, 84),
+                                     (4, 1, 31, 45), (2, 5, 85, 71)])
+def test_tiny_shape_sweep_vs_oracle(B, N, H, W):
+    """Ragged everything: single-row-panel GEMMs, 1..6 references, sizes that are not multiples of 14 (trailing pixels ignored,
+    HF:141-149), odd batch sizes over two lanes.  Tiny backbone, fp32 oracle on the host."""
+    net, arch, sd = _net(TINY, 11)
+    q, r = synth.make_inputs(B, N, H, W, 100 + B * 7 + N)
+    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    ref = _oracle(arch, sd, q, r)["score_map_ref_cross"]
+    assert tuple(out.shape) == tuple(ref.shape) == (B, 14 * (H // 14), 14 * (W // 14))
+    mae, mx = _compare(out, ref)
+    assert mae < 1.5e-3 and mx < 2 * MAX_TOL, (mae, mx)  # tiny-backbone bound, see __graft_entry__.smoke
+    again = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+    assert torch.equal(out, again)
+
+
 def test_tail_precision_levels(golden_dir):
     """Split-bf16 operands for the head + decoder FFN (default) must lower the error against the reference golden; every level
     stays inside the 1e-3 bound and the plain-bf16 level keeps working."""
