@@ -1,9 +1,10 @@
 """Output side of the predict drop-in: what the reference writes after each batch and at the end of the run.
 
 Mirrors
-  BatchWriter                                   utils/io/batch_writer.py:26-135,155-200,263-270 (score maps, query / reference images,
-                                                item-path json; attention-weight images and ground-truth maps are not produced by predict
-                                                with the default flags and are not written here)
+  BatchWriter                                   utils/io/batch_writer.py:26-135,155-270 (score maps, query / reference images, item-path
+                                                json, attention-weight images of the centre query patch; ground-truth score maps do not
+                                                exist in predict and are not written)
+  attn2rgb                                      utils/misc/image.py:55-77
   get_vrange / metric_map_write / gray2rgb      batch_writer.py:9-21, utils/io/images.py:49-63, utils/misc/image.py:37-52
   SummaryWriterPredictedOnlineTestPrediction    utils/io/score_summariser.py:142-250 (per-image mean -> CSV, "%.4f")
 The float -> integer image conversion runs on the GPU (cs_op_score_to_gray16 / cs_op_score_to_rgb: 2 or 3 bytes per pixel cross
@@ -42,6 +43,21 @@ def colormap_table(name: str = "turbo") -> np.ndarray:
 
     lut = np.asarray(matplotlib.colormaps[name](np.arange(256)))[:, :3]
     return (lut * 255.0).astype(np.uint8)
+
+
+def attn2rgb(attn_map: np.ndarray, table: np.ndarray) -> np.ndarray:
+    """utils/misc/image.py:55-77: softmax weights on a log scale (eps = 1e-8) through the colormap; (H, W) fp32 -> (H, W, 3) uint8."""
+    eps = 1e-8
+    a = np.asarray(attn_map, np.float32).clip(0, 1)
+    a = (a + eps).clip(0, 1)
+    a = np.log(a) - np.log(eps)
+    x = (a - 0.0) / np.float32(-np.log(eps) - 0.0)   # plt.Normalize(vmin=0, vmax=-log(eps)) on a float32 array
+    x = x * np.float32(256)
+    idx = x.astype(np.int64)
+    idx[x == 256] = 255
+    idx[~(x >= 0)] = 0
+    idx[x > 256] = 255
+    return table[np.clip(idx, 0, 255)]
 
 
 def name_stem(path: str) -> str:
@@ -95,10 +111,12 @@ class BatchWriter:
         m = cfg.model.predict.metric
         self.encoder = ScoreMapEncoder(m.type, m.min, m.max, self.write_config.score_map_colour_mode, device)
         self.img_mean_std = img_mean_std.detach().float().cpu()
+        # batch_writer.py:42-45: attention images only when the model returns the weights
+        self.write_attn = bool(self.write_flag["attn_weights"]) and bool(cfg.model.need_attn_weights)
         self.out_dir_dict = {"batch": Path(self.out_dir, "batch")}
         if self.write_flag["batch"]:
             for k in self.write_flag.keys():
-                if k not in ("batch", "score_map_prediction") and self.write_flag[k] and k in ("item_path_json", "image_query", "image_reference"):
+                if k not in ("batch", "score_map_prediction") and self.write_flag[k] and k in ("item_path_json", "image_query", "image_reference", "attn_weights"):
                     self.out_dir_dict[k] = Path(self.out_dir_dict["batch"], k)
                     self.out_dir_dict[k].mkdir(parents=True, exist_ok=True)
 
@@ -131,6 +149,26 @@ class BatchWriter:
                     path = d / f"ref{ref_idx:02}_{name_stem(rp)}.png"
                     save_png(path, self._de_norm_u8(img))
                     written.append(str(path))
+        if self.write_attn and len(batch_input["item_paths"]["reference/cross/imgs"]) > 0:
+            written += self._write_attn_weights(batch_input, batch_output, local_rank, batch_idx)
+        return written
+
+    def _write_attn_weights(self, batch_input, batch_output, local_rank, batch_idx) -> List[str]:
+        """batch_writer.py:202-261 with check_patch_mode="centre": per query, the (N_ref, h, w) attention of its centre patch."""
+        written = []
+        table = colormap_table("turbo")
+        stems = [name_stem(p) for p in batch_input["item_paths"]["query/img"]]
+        ref_paths = np.array(batch_input["item_paths"]["reference/cross/imgs"]).T  # (B, N_ref)
+        amap = batch_output["attn_weights_map_ref_cross"]                           # (B, h, w, N_ref, h, w)
+        th, tw = amap.shape[1:3]
+        for b, stem in enumerate(stems):
+            d = self.out_dir_dict["attn_weights"] / f"r{local_rank}_B{batch_idx:04}_b{b:03}_{stem}" / "cross"
+            d.mkdir(parents=True, exist_ok=True)
+            maps = amap[b, th // 2, tw // 2].detach().float().cpu().numpy()        # (N_ref, h, w)
+            for ref_idx, (rp, m) in enumerate(zip(ref_paths[b], maps)):
+                path = d / f"ref{ref_idx:02}_{name_stem(rp)}.png"
+                save_png(path, attn2rgb(m, table))
+                written.append(str(path))
         return written
 
     def _de_norm_u8(self, img_chw: torch.Tensor) -> np.ndarray:

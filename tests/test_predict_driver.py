@@ -93,6 +93,20 @@ def test_writer_oracle_matches_matplotlib():
     assert np.array_equal(wo.gray16(s01, [-1, 1]), ((s01 + 1) * 32767).astype(np.int32).astype(np.uint16))
 
 
+def test_attn2rgb_matches_matplotlib():
+    import matplotlib
+    import matplotlib.pyplot as plt
+    from crossscore_amd.writers import attn2rgb, colormap_table
+
+    rng = np.random.Generator(np.random.PCG64(4))
+    a = rng.dirichlet(np.ones(37 * 37)).astype(np.float32).reshape(37, 37)
+    a[0, :3] = (0.0, 1.0, 1e-9)
+    eps = 1e-8                                              # utils/misc/image.py:55-77, with colormaps[...] for the removed cm.get_cmap
+    m = a.clip(0, 1); m = (m + eps).clip(0, 1); m = np.log(m) - np.log(eps)
+    ref = (matplotlib.colormaps["turbo"](plt.Normalize(vmin=0, vmax=-np.log(eps))(m))[:, :, :3] * 255.0).astype(np.uint8)
+    assert np.array_equal(attn2rgb(a, colormap_table("turbo")), ref)
+
+
 def test_summariser_csv_format(tmp_path):
     from crossscore_amd.writers import ScoreSummariser, name_stem
 
@@ -132,7 +146,8 @@ def test_predict_run_matches_oracle_pipeline(tmp_path, colour_mode):
                                           "this_main.resize_short_side=56", "data.neighbour_config.cross=2",
                                           "data.neighbour_config.deterministic=True", "data.loader.validation.batch_size=2",
                                           f"logger.predict.write.config.score_map_colour_mode={colour_mode}",
-                                          "logger.predict.write.flag.item_path_json=True"])
+                                          "logger.predict.write.flag.item_path_json=True", "model.need_attn_weights=True",
+                                          "logger.predict.write.flag.attn_weights=True", "model.need_attn_weights_head_id=1"])
     res = predict(cfg, now="NOW")
     out_dir = str(tmp_path / "run" / "predict" / "NOW")
     assert res["out_dir"] == out_dir and len(res["rows"]) == 3
@@ -160,6 +175,9 @@ def test_predict_run_matches_oracle_pipeline(tmp_path, colour_mode):
             assert got.shape == want.shape and (np.abs(got.astype(int) - want.astype(int)).max(axis=2) > 24).mean() < 0.02
         assert os.path.exists(os.path.join(out_dir, "batch", "image_query", name))
         assert len(os.listdir(os.path.join(out_dir, "batch", "image_reference", name[:-4], "cross"))) == 2
+        att = sorted(os.listdir(os.path.join(out_dir, "batch", "attn_weights", name[:-4], "cross")))
+        assert att == ["ref00_s00001_test_ours_1000_gt_frame_00000.png", "ref01_s00001_test_ours_1000_gt_frame_00001.png"]
+        assert np.array(Image.open(os.path.join(out_dir, "batch", "attn_weights", name[:-4], "cross", att[0]))).shape == (4, 4, 3)
     # de-normalised query image round-trips to the resized uint8 image (u8 truncation: at most one level off)
     q0 = np.array(Image.open(os.path.join(out_dir, "batch", "image_query", "r0_B0000_b000_s00001_test_ours_1000_renders_frame_00000.png")))
     x0 = po.preprocess_u8(np.array(Image.open(os.path.join(qd, "frame_00000.png"))), (56, 67))
