@@ -168,10 +168,13 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
         }
       }
     l_run = l_run * alpha + psum;
+    // rescale the running output only when some row's maximum moved (alpha == 1 exactly otherwise): wave-uniform branch
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+      for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) ot[d][e] *= alpha;
+        for (int e = 0; e < 16; ++e) ot[d][e] *= alpha;
+    }
 
     // ---- O^T += V^T P^T : V^T fragments via transposed LDS reads ----
 #pragma unroll
