@@ -132,11 +132,28 @@ class SimpleReferenceItems:
         return {"query/img": self.query_paths[idx], "query/score_map": EMPTY, "reference/cross/imgs": refs}
 
 
-def load_batch(items: List[Dict[str, object]], stage: InputStage, zero_reference: bool = False) -> Dict[str, object]:
+def decode_items(items: List[Dict[str, object]], zero_reference: bool = False, pool=None) -> Dict[str, np.ndarray]:
+    """path -> decoded uint8 image for every file the items name (host side; PIL releases the GIL while decoding, so a thread pool
+    plays the role of the reference's DataLoader workers, task/predict.py:110-117)."""
+    paths = []
+    for it in items:
+        paths.append(it["query/img"])
+        if not zero_reference:
+            paths += [p for p in it["reference/cross/imgs"] if p != EMPTY]
+    uniq = list(dict.fromkeys(paths))
+    imgs = list(pool.map(read_image_u8, uniq)) if pool is not None else [read_image_u8(p) for p in uniq]
+    return dict(zip(uniq, imgs))
+
+
+def load_batch(items: List[Dict[str, object]], stage: InputStage, zero_reference: bool = False,
+               decoded: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, object]:
     """One batch dict with the keys `_core_step` reads (task/core.py:265-272) plus `item_paths` in the collated layout the
-    writers expect (default_collate turns the per-item list of N reference paths into N lists of B paths)."""
+    writers expect (default_collate turns the per-item list of N reference paths into N lists of B paths).  `decoded` holds
+    images already read by decode_items (a reference image shared by several items of the batch is decoded once)."""
     B = len(items)
-    q_imgs = [read_image_u8(it["query/img"]) for it in items]
+    decoded = decoded if decoded is not None else {}
+    get = lambda p: decoded[p] if p in decoded else read_image_u8(p)  # noqa: E731
+    q_imgs = [get(it["query/img"]) for it in items]
     geo = {stage.geometry(*im.shape[:2])[1][2:] for im in q_imgs}
     if len(geo) != 1:
         raise ValueError(f"query images of one batch must share the processed size, got {sorted(geo)}")
@@ -151,7 +168,7 @@ def load_batch(items: List[Dict[str, object]], stage: InputStage, zero_reference
                 # nvs_dataset.py:459-470: placeholders and zero_reference are all-zero images BEFORE T.Normalize -> (0 - mean) / std
                 refs[b, n] = stage.zero_image_value[:, None, None]
                 continue
-            ri = read_image_u8(p)
+            ri = get(p)
             if stage.geometry(*ri.shape[:2])[1][2:] != (oh, ow):
                 raise ValueError(f"{p}: processed size differs from the query's {oh}x{ow}")
             stage(ri, refs[b, n])

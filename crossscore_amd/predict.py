@@ -27,7 +27,7 @@ import torch
 
 from . import parallel, synth
 from .config import load_config
-from .data import InputStage, SimpleReferenceItems, load_batch
+from .data import InputStage, SimpleReferenceItems, decode_items, load_batch
 from .model import CrossScoreNet, load_lightning_checkpoint
 from .writers import BatchWriter, ScoreSummariser
 
@@ -88,9 +88,19 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
 
     lo, hi = parallel.shard_bounds(len(items), world, rank)
     bs = int(cfg.data.loader.validation.batch_size)
+    zero_ref = bool(cfg.data.dataset.zero_reference)
+    # Host side of the loader: the file lists of all batches are fixed up front (sampling order = item order, like a shuffle=False
+    # DataLoader), images are decoded by `num_workers` threads, and the next batch is decoded while the GPU scores this one.
+    batches = [[items[i] for i in range(start, min(start + bs, hi))] for start in range(lo, hi, bs)]
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=max(1, int(cfg.data.loader.validation.num_workers)))
+    prefetch = ThreadPoolExecutor(max_workers=1)
+    pending = prefetch.submit(decode_items, batches[0], zero_ref, pool) if batches else None
     files, n_done, t_model = [], 0, 0.0
-    for batch_idx, start in enumerate(range(lo, hi, bs)):
-        batch = load_batch([items[i] for i in range(start, min(start + bs, hi))], stage, bool(cfg.data.dataset.zero_reference))
+    for batch_idx, its in enumerate(batches):
+        decoded = pending.result()
+        pending = prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool) if batch_idx + 1 < len(batches) else None
+        batch = load_batch(its, stage, zero_ref, decoded)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         out = net(query_img=batch["query/img"], ref_cross_imgs=batch["reference/cross/imgs"], need_attn_weights=bool(cfg.model.need_attn_weights),
@@ -102,6 +112,8 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
         if writer is not None:
             files += writer.write_out(batch, out, local_rank, batch_idx)
     files += summariser.summarise()
+    prefetch.shutdown()
+    pool.shutdown()
     parallel.barrier()
     return {"out_dir": cfg.logger.predict.out_dir, "files": files, "rows": summariser.rows,
             "query_images_per_sec": n_done / t_model if t_model > 0 else 0.0}
