@@ -21,7 +21,8 @@ hipError_t cs_gemm_launch(const CsGemmParams* p, int epi, hipStream_t stream);
 const char* cs_attn_check(const CsAttnParams* p, int dh, int batch);
 hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, hipStream_t stream);
 hipError_t cs_im2col_launch(const float* q, const float* refs, int N, int img0, bf16_t* out, int I, int H, int W, int P, int Kp,
-                            hipStream_t st);
+                            float* pmean, hipStream_t st);
+hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipStream_t st);
 hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32, bf16_t* obf,
                                hipStream_t st);
 hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
@@ -97,6 +98,7 @@ struct cs_model {
   std::vector<void*> owned;  // device allocations of packed weights
   // packed
   bf16_t* Wpatch = nullptr; float* bpatch = nullptr;
+  float* wsum = nullptr;  // [3][C] fp32 sums of the patch weights per channel (mean-centred patch embedding)
   std::vector<EncLayer> enc;
   std::vector<DecLayer> dec;
   bf16_t* Wkv_all = nullptr; float* bkv_all = nullptr;
@@ -169,6 +171,7 @@ struct Plan {
   // encoder chunk buffers, one set per lane
   float* x[CS_MAX_LANES]; bf16_t* u[CS_MAX_LANES]; bf16_t* r1[CS_MAX_LANES];
   bf16_t* ob[CS_MAX_LANES]; float* stats[CS_MAX_LANES];  // LayerNorm fold: attention output, per-row partial sums
+  float* pmean[CS_MAX_LANES];                            // per-patch channel means removed by im2col
   // decoder
   float *xq, *y, *lse, *hf; bf16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid, *q3, *hid3;
 };
@@ -201,6 +204,7 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
     p.u[l] = a.take<bf16_t>(Mc * C);
     p.r1[l] = a.take<bf16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * 3 * C, (size_t)p.Ic * p.Np * m->Kp)));
     p.ob[l] = a.take<bf16_t>(m->lnfold ? Mc * C : 0);
+    p.pmean[l] = a.take<float>((size_t)p.Ic * p.Np * 4);
     p.stats[l] = a.take<float>(m->lnfold ? Mc * (size_t)m->ln_sp * 2 : 0);
   }
   p.xq = a.take<float>(M * C);
@@ -396,6 +400,7 @@ int cs_finalize(cs_handle h) {
   NEED(t_pb, e + "patch_embeddings.projection.bias", C)
   h->cls = t_cls->d; h->pos = t_pos->d; h->bpatch = t_pb->d;
   { ALLOC_BF(wp, (size_t)C * h->Kp) if (int r = pack(t_pw->d, (int)C, (int)(3 * P * P), h->Kp, wp)) return r; h->Wpatch = wp; }
+  { ALLOC_F(ws, (size_t)3 * C) HIPCHK(cs_patch_wsum_launch(t_pw->d, (int)C, (int)P, ws, st)); h->wsum = ws; }
   h->enc.resize(c.enc_layers);
   for (int l = 0; l < c.enc_layers; ++l) {
     const std::string p = "backbone.encoder.layer." + std::to_string(l) + ".";
@@ -567,7 +572,9 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
     hipStream_t s = L.st;
     float* x = p.x[slot]; bf16_t* u = p.u[slot]; bf16_t* r1 = p.r1[slot];
     const int Mc = ic * p.T;
-    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, s), "im2col"); L.end();
+    // patches are mean-centred per channel before the bf16 rounding; the patch GEMM adds mean * sum(W) back in fp32
+    float* pmean = p.pmean[slot];
+    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, pmean, s), "im2col"); L.end();
     const bool fold = h->lnfold;
     bf16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
     L.begin(32, 0);
@@ -575,7 +582,7 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
     L.end();
     {
       CsGemmParams g = gp(r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, x, C);
-      g.pos = h->pos_tab; g.Np = p.Np;
+      g.pos = h->pos_tab; g.Np = p.Np; g.pmean = pmean; g.wsum = h->wsum;
       if (fold) { g.out_bf16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }  // bf16 rows + LayerNorm partial sums for layer 0
       L.gemm(g, CS_EPI_PATCH_F32, 3.0 * P * P);
     }
@@ -867,7 +874,7 @@ int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const floa
 
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream) {
   if (!x || !out || I <= 0 || P <= 0 || H < P || W < P || Kp % 8 || Kp < 3 * P * P) return fail(CS_ERR_BAD_ARG, "im2col: bad arguments");
-  HIPCHK(cs_im2col_launch(x, nullptr, 0, 0, out, I, H, W, P, Kp, (hipStream_t)stream));
+  HIPCHK(cs_im2col_launch(x, nullptr, 0, 0, out, I, H, W, P, Kp, nullptr, (hipStream_t)stream));
   return 0;
 }
 

@@ -71,6 +71,8 @@ struct CsGemmParams {
   int ldc;
   // CS_EPI_PATCH_F32 / CS_EPI_HEAD_SCORE extras
   const float* pos;   // [(1+Np)][ldc] position table (patch)
+  const float* pmean; // patch epilogue: [M][4] per-row channel means removed by im2col (nullptr: none), added back as pmean . wsum
+  const float* wsum;  // [3][ldc] fp32 sums of the patch weights over each channel's P*P taps
   int Np;             // patches per image
   int gw;             // patch-grid width
   int P;              // patch size (head)

@@ -51,11 +51,18 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 // Same result, coalesced on both sides: one block per (image, patch row).  The 3*P image rows of the patch row are read with
 // consecutive lanes on consecutive pixels, scattered into an LDS image of the gw output rows ([gw][Kp] bf16, pad columns zero),
 // which is then streamed out as one contiguous piece.  (The gather kernel above reads 56-byte runs: 2.3 TB/s; this one 4+.)
+// With `pmean`, each patch's per-channel mean (fp32, fixed summation order) is removed before the bf16 rounding and stored as
+// pmean[row][ch]; the patch GEMM adds mean * sum(W) back in fp32 (gemm.hip patch_dc).
 template <int P>
 __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ xq, const float* __restrict__ xr, int N, int img0,
-                                                           bf16_t* __restrict__ out, int H, int W, int gh, int gw, int Kp) {
+                                                           bf16_t* __restrict__ out, int H, int W, int gh, int gw, int Kp,
+                                                           float* __restrict__ pmean) {
   extern __shared__ __attribute__((aligned(16))) char im_smem[];
-  bf16_t* tile = reinterpret_cast<bf16_t*>(im_smem);
+  bf16_t* tile = reinterpret_cast<bf16_t*>(im_smem);                                   // [gw][Kp]
+  const int Wu = gw * P;
+  float* stage = reinterpret_cast<float*>(im_smem + (size_t)gw * Kp * sizeof(bf16_t));  // [P][Wu] one channel (centring only)
+  float* mean = stage + (size_t)P * Wu;                                                // [gw]
+  float* part = mean + gw;                                                             // [gw][P] row sums
   const int img = blockIdx.x / gh, pi = blockIdx.x - img * gh;
   const int g_img = img0 + img;
   const int bb = g_img / (1 + N), vv = g_img - bb * (1 + N);
@@ -66,19 +73,61 @@ __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restric
     const int pj = i / (Kp - KK);
     tile[pj * Kp + KK + (i - pj * (Kp - KK))] = 0;
   }
-  const int Wu = gw * P;
-  for (int r = wv; r < 3 * P; r += 4) {  // image row (ch, dy) of this patch row, one wave per row
-    const int ch = r / P, dy = r - ch * P;
-    const float* src = x + ((size_t)ch * H + (pi * P + dy)) * W;
-    for (int xx = lane; xx < Wu; xx += 64) {
-      const int pj = xx / P, dx = xx - pj * P;
-      tile[pj * Kp + ch * P * P + dy * P + dx] = f2bf(src[xx]);
+  if (pmean == nullptr) {
+    for (int r = wv; r < 3 * P; r += 4) {  // image row (ch, dy) of this patch row, one wave per row
+      const int ch = r / P, dy = r - ch * P;
+      const float* src = x + ((size_t)ch * H + (pi * P + dy)) * W;
+      for (int xx = lane; xx < Wu; xx += 64) {
+        const int pj = xx / P, dx = xx - pj * P;
+        tile[pj * Kp + ch * P * P + dy * P + dx] = f2bf(src[xx]);
+      }
+    }
+  } else {
+    for (int ch = 0; ch < 3; ++ch) {
+      for (int dy = wv; dy < P; dy += 4) {
+        const float* src = x + ((size_t)ch * H + (pi * P + dy)) * W;
+        for (int xx = lane; xx < Wu; xx += 64) stage[dy * Wu + xx] = src[xx];
+      }
+      __syncthreads();
+      // fixed summation order (row sums, then the P row sums of a patch): the mean, and every rounding after it, is reproducible
+      for (int i = tid; i < gw * P; i += 256) {
+        const int pj = i / P, dy = i - pj * P;
+        float sacc = 0.f;
+        for (int dx = 0; dx < P; ++dx) sacc += stage[dy * Wu + pj * P + dx];
+        part[i] = sacc;
+      }
+      __syncthreads();
+      if (tid < gw) {
+        float sacc = 0.f;
+        for (int dy = 0; dy < P; ++dy) sacc += part[tid * P + dy];
+        const float mu = sacc / (float)(P * P);
+        mean[tid] = mu;
+        pmean[(((size_t)img * gh + pi) * gw + tid) * 4 + ch] = mu;
+        if (ch == 0) pmean[(((size_t)img * gh + pi) * gw + tid) * 4 + 3] = 0.f;
+      }
+      __syncthreads();
+      for (int dy = wv; dy < P; dy += 4)
+        for (int xx = lane; xx < Wu; xx += 64) {
+          const int pj = xx / P, dx = xx - pj * P;
+          tile[pj * Kp + ch * P * P + dy * P + dx] = f2bf(stage[dy * Wu + xx] - mean[pj]);
+        }
+      __syncthreads();
     }
   }
   __syncthreads();
   uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)img * gh + pi) * gw * Kp);
   const uint4* srcv = reinterpret_cast<const uint4*>(tile);
   for (int i = tid; i < gw * Kp / 8; i += 256) dst[i] = srcv[i];
+}
+
+// wsum[ch][n] = sum over the P*P taps of channel ch of the fp32 patch weight W[n][ch*P*P + t]   (one thread per (ch, n))
+__global__ void patch_wsum_kernel(const float* __restrict__ w, int C, int PP, float* __restrict__ wsum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * C) return;
+  const int ch = i / C, n = i - ch * C;
+  float s = 0.f;
+  for (int t = 0; t < PP; ++t) s += w[(size_t)n * 3 * PP + ch * PP + t];
+  wsum[(size_t)ch * C + n] = s;
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -359,19 +408,30 @@ __global__ __launch_bounds__(256) void score_mean_kernel(const float* __restrict
 
 extern "C" {
 
+hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipStream_t st) {
+  hipLaunchKernelGGL(patch_wsum_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, st, w, C, P * P, wsum);
+  return hipGetLastError();
+}
+
+// pmean: [I*gh*gw][4] fp32 or nullptr.  With pmean the patches are mean-centred; when the gather fallback has to be used the
+// means are written as zeros (nothing removed, nothing to add back).
 hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, bf16_t* out, int I, int H, int W, int P, int Kp,
-                            hipStream_t st) {
+                            float* pmean, hipStream_t st) {
   const int gh = H / P, gw = W / P;
-  const size_t lds = (size_t)gw * Kp * sizeof(bf16_t);
-  if (P == 14 && Kp >= 3 * P * P && lds <= 150 * 1024 && (long long)I * gh < (1ll << 31)) {
+  const size_t lds = (size_t)gw * Kp * sizeof(bf16_t) + (pmean ? ((size_t)P * gw * P + gw + (size_t)gw * P) * sizeof(float) : 0);
+  if (P == 14 && Kp >= 3 * P * P && lds <= 156 * 1024 && (long long)I * gh < (1ll << 31) && gw <= 256) {
     static bool attr_done = false;
     if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(im2col_rows_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(im2col_rows_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
       if (e != hipSuccess) return e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(im2col_rows_kernel<14>, dim3(I * gh), dim3(256), lds, st, xq, xr, N, img0, out, H, W, gh, gw, Kp);
+    hipLaunchKernelGGL(im2col_rows_kernel<14>, dim3(I * gh), dim3(256), lds, st, xq, xr, N, img0, out, H, W, gh, gw, Kp, pmean);
     return hipGetLastError();
+  }
+  if (pmean) {
+    hipError_t e = hipMemsetAsync(pmean, 0, (size_t)I * gh * gw * 4 * sizeof(float), st);
+    if (e != hipSuccess) return e;
   }
   const long long total = (long long)I * gh * gw * (Kp / 8);
   const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);

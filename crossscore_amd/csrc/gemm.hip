@@ -183,6 +183,17 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F&
   (f(std::integral_constant<int, Js>{}), ...);
 }
 
+// Patch embedding on mean-centred patches: im2col removed each patch's per-channel mean before the bf16 rounding (a smooth image
+// patch is mostly its mean, and a bf16 rounding error of the weights times that mean was the largest single error term of the
+// encoder on natural images); the exact contribution mean_ch * sum_taps(W[n][ch]) comes back here in fp32.
+__device__ __forceinline__ f32x4_t patch_dc(const CsGemmParams& p, int m, int n) {
+  const f32x4_t mu = *reinterpret_cast<const f32x4_t*>(p.pmean + (size_t)m * 4);
+  f32x4_t r = mu[0] * *reinterpret_cast<const f32x4_t*>(p.wsum + n);
+  r += mu[1] * *reinterpret_cast<const f32x4_t*>(p.wsum + (size_t)p.ldc + n);
+  r += mu[2] * *reinterpret_cast<const f32x4_t*>(p.wsum + 2 * (size_t)p.ldc + n);
+  return r;
+}
+
 template <int EPI> struct EpiTraits {
   static constexpr bool kLN = EPI == CS_EPI_LN_BF16 || EPI == CS_EPI_LN_GELU_BF16;           // LayerNorm-folded consumer
   static constexpr bool kHalf = EPI == CS_EPI_BIAS_BF16 || EPI == CS_EPI_BIAS_GELU_BF16 || EPI == CS_EPI_BIAS_RELU_BF16 ||
@@ -456,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
             for (int q = 0; q < NRD; ++q) {
               const int m = mrow0 + q * RPI;
               seg[q] += *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)(m % p.Np + 1) * p.ldc + n);
+              if (p.pmean) seg[q] += patch_dc(p, m, n);
             }
           }
 #pragma unroll
@@ -500,6 +512,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
               if (p.resid) seg[q] += *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m * p.ldr + n);
             } else {
               seg[q] += *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)(m % p.Np + 1) * p.ldc + n);
+              if (p.pmean) seg[q] += patch_dc(p, m, n);
               row = (size_t)(m + m / p.Np + 1);
             }
             *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + row * p.ldc + n) = seg[q];
