@@ -570,11 +570,9 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
         rl = true;
       }
     }
-    if (!CS_ABL(16)) {
     last_dma = issued < total;
     if (issued < total && !CS_ABL(4)) issue_one();  // refill the slot just vacated
     else if (issued < total) ++issued;
-    }
     CS_T(2);
     if (!CS_ABL(2)) {
       const char* sa = smem + c_ring * STAGE_BYTES + frow * 64 + coff;
@@ -600,11 +598,6 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
       __builtin_amdgcn_sched_group_barrier(0x008, LOOK * NSUB, 0);
     }
     CS_T(3);
-    if (CS_ABL(16)) {  // experiment: refill after the MFMA section
-    last_dma = issued < total;
-    if (issued < total && !CS_ABL(4)) issue_one();
-    else if (issued < total) ++issued;
-    }
     int ve = 0;
     if constexpr (STEP >= 0) {
       if (have_prev) ve = epi_step(std::integral_constant<int, (STEP >= 0 ? STEP : 0)>{}, std::false_type{});
