@@ -153,6 +153,26 @@ def test_structured_images_vs_oracle():
     assert mae < 8e-4 and mx < MAX_TOL, (mae, mx)
 
 
+def test_attention_weights_full_size_vs_oracle():
+    """need_attn_weights at the real token counts (ViT-S, 518^2, N=2: 1369 x 2738 weights per query): rows are probability
+    distributions, agree with the oracle's explicit softmax, and asking for them does not change the score map."""
+    net, arch, sd = _net("facebook/dinov2-small", 2)
+    q, r = synth.make_inputs(1, 2, 518, 518, 2)
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    out = net(tq, tr, True, 5, False)
+    plain = net(tq, tr, False, 0, False)
+    torch.cuda.synchronize()
+    aw = out["attn_weights_map_ref_cross"]
+    assert tuple(aw.shape) == (1, 37, 37, 2, 37, 37)
+    assert torch.equal(out["score_map_ref_cross"], plain["score_map_ref_cross"])
+    rows = aw.reshape(1369, -1)
+    assert (rows.sum(-1) - 1).abs().max() < 1e-4 and rows.min() >= 0
+    ref = _oracle(arch, sd, q, r, need_w=True, head=5)["attn_weights_map_ref_cross"].reshape(1369, -1)
+    d = (rows.cpu() - ref).abs()
+    assert float(d.sum(-1).max()) < 0.05, float(d.sum(-1).max())   # total-variation-like distance per row (bf16 logits)
+    assert float(d.max()) < 2e-2
+
+
 def test_tail_precision_levels(golden_dir):
     """Split-bf16 operands for the head + decoder FFN (default) must lower the error against the reference golden; every level
     stays inside the 1e-3 bound and the plain-bf16 level keeps working."""
