@@ -173,6 +173,25 @@ def test_attention_weights_full_size_vs_oracle():
     assert float(d.max()) < 2e-2
 
 
+def test_forward_on_a_side_stream_is_stream_ordered():
+    """All work is ordered on the caller's stream (internal lanes fork from and join to it): producing the inputs and consuming
+    the outputs on a non-default stream without any device synchronisation gives the same bits."""
+    net, arch, sd = _net(TINY, 7)
+    q, r = synth.make_inputs(3, 2, 56, 70, 7)
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    base = net(tq, tr, False, 0, False)["score_map_ref_cross"].clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            q2 = tq * 1.0                                  # produced on the side stream just before the call
+            out = net(q2, tr, False, 0, False)["score_map_ref_cross"]
+            acc = out + 0.0                                # consumed on the side stream right after it
+    side.synchronize()
+    assert torch.equal(acc, base)
+
+
 def test_tail_precision_levels(golden_dir):
     """Split-bf16 operands for the head + decoder FFN (default) must lower the error against the reference golden; every level
     stays inside the 1e-3 bound and the plain-bf16 level keeps working."""
