@@ -113,6 +113,7 @@ struct cs_model {
   // lanes: internal streams that run independent image chunks / batch groups concurrently (forked from and joined to
   // the caller's stream with events), so one kernel's tail and the memory-bound stages overlap another's MFMA work
   hipStream_t lane_st[CS_MAX_LANES] = {};
+  hipStream_t last_stream = nullptr; hipEvent_t ev_done = nullptr;  // ordering of calls that arrive on different streams
   hipEvent_t ev_fork = nullptr, ev_join[CS_MAX_LANES] = {};
   // profiling
   bool prof = false;
@@ -337,6 +338,7 @@ void cs_destroy(cs_handle h) {
   if (h->pos_tab && h->pos_tab_owned) hipFree(h->pos_tab);
   if (h->pe_tab && h->pe_tab != h->pe) hipFree(h->pe_tab);
   if (h->ws) hipFree(h->ws);
+  if (h->ev_done) hipEventDestroy(h->ev_done);
   for (int l = 0; l < CS_MAX_LANES; ++l) { if (h->lane_st[l]) hipStreamDestroy(h->lane_st[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -506,7 +508,7 @@ size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W) {
 
 // mode 0: full forward (query + reference images); mode 1: query images + cached reference tokens (`ref_tokens`, bf16
 // [B][N][Np][C]); mode 2: encode `B` images as references into `tokens_out` (bf16 [B][Np][C]), no decoder.
-static int forward_impl(cs_handle h, int mode, const float* query, const float* refs, const bf16_t* ref_tokens, bf16_t* tokens_out,
+static int forward_body(cs_handle h, int mode, const float* query, const float* refs, const bf16_t* ref_tokens, bf16_t* tokens_out,
                         int B, int N, int H, int W, float* score_out, float* attn_out, int head_id, float* mean_out,
                         cs_stream stream) {
   if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
@@ -775,6 +777,21 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
     L.begin(32, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();
   }
   return L.rc;
+}
+
+static int forward_impl(cs_handle h, int mode, const float* query, const float* refs, const bf16_t* ref_tokens, bf16_t* tokens_out,
+                        int B, int N, int H, int W, float* score_out, float* attn_out, int head_id, float* mean_out,
+                        cs_stream stream) {
+  // The workspace is shared by every call on this handle: a call on a different stream than the previous one first waits for that
+  // one to finish (calls on one stream are ordered anyway).
+  if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
+  hipStream_t st = (hipStream_t)stream;
+  if (h->ev_done && h->last_stream != st) HIPCHK(hipStreamWaitEvent(st, h->ev_done, 0));
+  const int rc = forward_body(h, mode, query, refs, ref_tokens, tokens_out, B, N, H, W, score_out, attn_out, head_id, mean_out, stream);
+  if (!h->ev_done) HIPCHK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(h->ev_done, st));
+  h->last_stream = st;
+  return rc;
 }
 
 int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N, int H, int W, float* score_out, float* attn_out,

@@ -9,7 +9,8 @@
  *
  * Ownership: the caller (PyTorch) owns every input / output / weight-source buffer; the library owns only its
  * packed bf16 weights and its workspace.  Threading: a handle is not thread-safe; one handle per process per
- * GPU.  All work is enqueued on the caller's hipStream_t; no entry point synchronises the device except
+ * GPU.  All work is enqueued on the caller's hipStream_t (a forward that arrives on another stream than the previous one
+ * waits for it: the workspace is shared); no entry point synchronises the device except
  * cs_finalize, cs_profile_* and cs_destroy.  Every function returning int returns 0 on success; on failure
  * cs_last_error() describes it (CS_ERR_* below) and nothing was launched on the bad-argument paths.
  */

@@ -192,6 +192,24 @@ def test_forward_on_a_side_stream_is_stream_ordered():
     assert torch.equal(acc, base)
 
 
+def test_calls_alternating_between_two_streams_do_not_race():
+    """The handle's workspace is shared by all calls; a call that arrives on another stream waits for the previous call."""
+    net, arch, sd = _net(TINY, 9)
+    ins = [synth.make_inputs(2, 3, 70, 84, 20 + i) for i in range(2)]
+    tens = [(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()) for q, r in ins]
+    want = [net(q, r, False, 0, False)["score_map_ref_cross"].clone() for q, r in tens]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = []
+    for it in range(6):
+        k = it % 2
+        with torch.cuda.stream(streams[k]):
+            got.append((k, net(tens[k][0], tens[k][1], False, 0, False)["score_map_ref_cross"]))
+    torch.cuda.synchronize()
+    for k, g in got:
+        assert torch.equal(g, want[k])
+
+
 def test_tail_precision_levels(golden_dir):
     """Split-bf16 operands for the head + decoder FFN (default) must lower the error against the reference golden; every level
     stays inside the 1e-3 bound and the plain-bf16 level keeps working."""
