@@ -209,10 +209,18 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
       for (int g4 = 0; g4 < 4; ++g4) {
         const int dd = d * 32 + 8 * g4 + 4 * hh;
         if (dd < DH) {
+          const float v0 = ot[d][4 * g4 + 0] * inv, v1 = ot[d][4 * g4 + 1] * inv, v2 = ot[d][4 * g4 + 2] * inv, v3 = ot[d][4 * g4 + 3] * inv;
           uint2 o;
-          o.x = pack_bf16x2(ot[d][4 * g4 + 0] * inv, ot[d][4 * g4 + 1] * inv);
-          o.y = pack_bf16x2(ot[d][4 * g4 + 2] * inv, ot[d][4 * g4 + 3] * inv);
+          o.x = pack_bf16x2(v0, v1);
+          o.y = pack_bf16x2(v2, v3);
           *reinterpret_cast<uint2*>(op + dd) = o;
+          if (p.o_split) {  // split-bf16 operand for the out-projection: lo = bf16(v - hi), hi repeated (elementwise.hip split3_kernel)
+            uint2 lo;
+            lo.x = pack_bf16x2(v0 - bf2f((bf16_t)(o.x & 0xffff)), v1 - bf2f((bf16_t)(o.x >> 16)));
+            lo.y = pack_bf16x2(v2 - bf2f((bf16_t)(o.y & 0xffff)), v3 - bf2f((bf16_t)(o.y >> 16)));
+            *reinterpret_cast<uint2*>(op + p.o_split + dd) = lo;
+            *reinterpret_cast<uint2*>(op + 2 * p.o_split + dd) = o;
+          }
         }
       }
     if (p.lse && hh == 0) p.lse[((size_t)bat * p.heads + head) * p.Lq + q] = m_run + log2f(l_tot);

@@ -98,4 +98,5 @@ struct CsAttnParams {
   int nbatch;                                          // filled by the launcher
   float scale_log2e;                                   // (1/sqrt(dh)) * log2(e)
   float* lse;                                          // optional [batch][heads][Lq]: m*ln2-scaled log-sum-exp (base 2)
+  int o_split;                                         // 0, or C: O rows are [hi | lo | hi] (3C wide, split-bf16 operand of the out-projection)
 };

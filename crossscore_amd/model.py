@@ -100,7 +100,7 @@ class CrossScoreNet(torch.nn.Module):
         self._dirty = True
         self.enc_chunk_images = 0  # 0 = library default
         self.lanes = 0             # 0 = library default (2 concurrent lanes); 1 = serial
-        self.tail_precision = 0    # split-bf16 operands: 0 = head + decoder FFN (default), 2 = + decoder in-proj / Q-proj, 1 = plain bf16
+        self.tail_precision = 0    # split-bf16 operands: 0 = head + decoder FFN (default), 2 = + decoder in/Q/out-projections, 1 = plain bf16
         self.ln_fold = 0           # 1 = fold the encoder LayerNorms into the QKV / fc1 GEMM epilogues (opt-in; slower so far)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 

@@ -56,7 +56,8 @@ typedef struct cs_config {
   int lanes;         /* internal streams that run independent image chunks / batch groups concurrently: 0 = default (2), 1 = serial, up to 4 */
   int tail_precision; /* split-bf16 (hi + lo, three-term) operands = fp32-grade products with the bf16 MFMA kernel, for the linears that
                        * carry most of the bf16 error of the score map: 0 = default: regression head + decoder FFN (score-map MAE 8.4e-4 ->
-                       * ~6.3e-4 on cfg-2 at < 1 % time), 2 = also the decoder's self-attention in-proj and cross-attention Q-proj,
+                       * ~6.1e-4 on cfg-2 at < 2 % time), 2 = also the decoder's self-attention in-proj, cross-attention Q-proj and both
+                       * out-projections (attention writes its output as hi | lo | hi): 5.0e-4 at a further 1.8 %,
                        * 1 = plain bf16 everywhere */
 } cs_config;
 
