@@ -230,6 +230,7 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
 // launch helpers that record profiling events when enabled
 struct Launcher {
   cs_model* m; hipStream_t st; int rc = 0;
+  int bpc = 0;  // GEMM blocks per CU hint (CsGemmParams::bpc)
   void begin(int family, double flops, double bytes = 0) {
     if (!m->prof) return;
     ProfRec r{}; r.family = family; r.flops = flops; r.bytes = bytes;
@@ -241,6 +242,7 @@ struct Launcher {
   bool gemm(CsGemmParams g, int epi, double k_real = 0) {
     if (rc) return false;
     if (const char* e = cs_gemm_check(&g, epi)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
+    g.bpc = bpc;
     // algorithmic HBM bytes of one launch: A and W once (bf16), bias, the output once, the residual / position addend once
     const double mn = (double)g.M * g.N;
     const bool f32out = epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32 || epi == CS_EPI_HEAD_SCORE;
@@ -750,6 +752,9 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
 
   Launcher LL[CS_MAX_LANES] = {Launcher{h, lst[0]}, Launcher{h, lst[1]}, Launcher{h, lst[2]}, Launcher{h, lst[3]}};
   auto lanes_rc = [&]() { for (int l = 0; l < CS_MAX_LANES; ++l) if (LL[l].rc) return LL[l].rc; return 0; };
+  // encoder lanes share the GPU: their GEMMs oversubscribe the CUs so that blocks are short and slots change hands often
+  // (cfg-2, same box: 9.03 -> 8.84 ms with 3..16 blocks per CU; alone on the GPU two per CU is best: 9.27 vs 9.38..9.73 ms)
+  if (NL >= 2) for (int l = 0; l < CS_MAX_LANES; ++l) LL[l].bpc = 4;
   const int per_item = 1 + N_enc;
   // Decoding each chunk's items on its lane right after encoding them (no global join) was measured SLOWER (833 vs 875
   // query-images/s on cfg-2): it doubles the number of small decoder launches and the host enqueue rate becomes the

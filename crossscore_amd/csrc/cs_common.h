@@ -71,6 +71,7 @@ struct CsGemmParams {
   int ldc;
   // CS_EPI_PATCH_F32 / CS_EPI_HEAD_SCORE extras
   const float* pos;   // [(1+Np)][ldc] position table (patch)
+  int bpc;            // persistent blocks per CU to launch (0 = 2, the number that is resident)
   const float* pmean; // patch epilogue: [M][4] per-row channel means removed by im2col (nullptr: none), added back as pmean . wsum
   const float* wsum;  // [3][ldc] fp32 sums of the patch weights over each channel's P*P taps
   int Np;             // patches per image

@@ -723,7 +723,10 @@ hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   // two persistent blocks per CU (LDS and registers admit two); grid is a multiple of 8 so that b%8 labels the XCD group
-  int grid = (2 * g_num_cus / 8) * 8;
+  // p.bpc > 2 oversubscribes the CUs (only two blocks are resident per CU; the rest queue behind them): each block then walks
+  // fewer tiles and gives its slot back sooner, which pays when a second stream's kernels share the GPU (two encoder lanes:
+  // -2 % step time with 3..16 blocks per CU) and costs when the kernel runs alone (+1..5 %).
+  int grid = ((p.bpc > 0 ? p.bpc : 2) * g_num_cus / 8) * 8;
 #ifdef CS_ABLATE
   if (const char* e = getenv("CS_GEMM_GRID")) grid = atoi(e);
 #endif

@@ -7,7 +7,9 @@ sys.path.insert(0, %r)
 from crossscore_amd import synth
 from crossscore_amd.config import model_config
 from crossscore_amd.model import CrossScoreNet
+import os
 net = CrossScoreNet(model_config()); net.load_numpy_state_dict(synth.make_state_dict(net.arch, 1)); net = net.cuda()
+net.lanes = int(os.environ.get('CS_AB_LANES', '0')); net.enc_chunk_images = int(os.environ.get('CS_AB_CHUNK', '0'))
 q, r = synth.make_inputs(8, 5, 518, 518, 1); tq = torch.from_numpy(q).cuda(); tr = torch.from_numpy(r).cuda()
 for _ in range(4): net(tq, tr, False, 0, False)
 torch.cuda.synchronize(); t = time.time()
