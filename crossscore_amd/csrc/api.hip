@@ -575,12 +575,16 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   };
 
   // ================= encoder (Dinov2Model.forward, HF:451-477): image chunks, alternating lanes =================
-  auto enc_chunk = [&](Launcher& L, int slot, int i0, int ic) {
+  // `stage` selects what is enqueued: -1 = patch embedding, 0..L-1 = one encoder layer, L = final LayerNorm / split.  The host
+  // enqueues the lanes' chunks stage by stage in turn, so both lanes have work from the first microsecond of the step (a whole
+  // chunk is ~90 launches = 0.3 ms of enqueue time, during which the other lane would idle).
+  auto enc_chunk = [&](Launcher& L, int slot, int i0, int ic, int stage) {
     hipStream_t s = L.st;
     float* x = p.x[slot]; bf16_t* u = p.u[slot]; bf16_t* r1 = p.r1[slot];
     const int Mc = ic * p.T;
     // patches are mean-centred per channel before the bf16 rounding; the patch GEMM adds mean * sum(W) back in fp32
     float* pmean = p.pmean[slot];
+    if (stage == -1) {
     L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, pmean, s), "im2col"); L.end();
     const bool fold = h->lnfold;
     bf16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
@@ -593,7 +597,11 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       if (fold) { g.out_bf16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }  // bf16 rows + LayerNorm partial sums for layer 0
       L.gemm(g, CS_EPI_PATCH_F32, 3.0 * P * P);
     }
+    }
+    const bool fold = h->lnfold;
+    bf16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
     for (int l = 0; l < c.enc_layers; ++l) {
+      if (l != stage) continue;
       const EncLayer& E = h->enc[l];
       const bool last = l == c.enc_layers - 1;
       CsAttnParams a{};
@@ -646,6 +654,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.gemm(g, CS_EPI_RESID_F32);
       }
     }
+    if (stage != c.enc_layers) return;
     L.begin(32, 0);
     L.misc(cs_final_ln_split_launch(x, ic, i0, p.Np, C, mode == 2 ? -1 : N_enc, h->lnfg, h->lnfb, 1e-6f, h->pe_tab, p.xq, p.q_bf,
                                     mode == 2 ? tokens_out : p.mem_bf, s), "final_ln");
@@ -759,26 +768,25 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   // Decoding each chunk's items on its lane right after encoding them (no global join) was measured SLOWER (833 vs 875
   // query-images/s on cfg-2): it doubles the number of small decoder launches and the host enqueue rate becomes the
   // limit.  The decoder therefore runs after a join, as one group on the caller's stream.
-  const bool chunk_decodes = false;
   (void)per_item;
   if (int r = fork(NL)) return r;
   {
-    // chunk sizes: the short remainder (if any) goes FIRST so that it overlaps the long chunks instead of trailing them
-    int chunk = 0, i0 = 0;
+    // chunk sizes: the short remainder (if any) goes FIRST so that it overlaps the long chunks instead of trailing them;
+    // chunk k runs on lane k % NL, and the chunks of one round (one per lane) are enqueued stage by stage in turn
+    std::vector<std::pair<int, int>> chunks;  // (first image, images)
+    int i0 = 0;
     const int rem = p.I % p.Ic;
-    auto run_chunk = [&](int ic) {
-      Launcher& L = LL[chunk % NL];
-      enc_chunk(L, chunk % NL, i0, ic);
-      if (chunk_decodes) dec_group(L, i0 / per_item, ic / per_item);
-      i0 += ic; ++chunk;
-    };
-    if (rem) run_chunk(rem);
-    while (i0 < p.I) run_chunk(p.Ic);
+    if (rem) { chunks.push_back({0, rem}); i0 = rem; }
+    for (; i0 < p.I; i0 += p.Ic) chunks.push_back({i0, p.Ic});
+    for (size_t base = 0; base < chunks.size(); base += NL)
+      for (int stage = -1; stage <= c.enc_layers; ++stage)
+        for (int l = 0; l < NL && base + l < chunks.size(); ++l)
+          enc_chunk(LL[l], l, chunks[base + l].first, chunks[base + l].second, stage);
   }
   if (int r = join(NL)) return r;
   if (int r = lanes_rc()) return r;
   if (mode == 2) return 0;
-  if (!chunk_decodes) {  // every image's tokens are in place (join above) before any decoder group starts
+  {  // every image's tokens are in place (join above) before the decoder starts
     (void)ND;
     Launcher LD{h, st};
     dec_group(LD, 0, B);
