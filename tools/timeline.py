@@ -1,0 +1,31 @@
+"""Concurrency timeline of one bench run from a rocprofv3 --kernel-trace CSV: how much of the steady-state time has 0 / 1 / >=2
+kernels in flight, and which kernels run while nothing else does.  usage: timeline.py <dir with *kernel_trace.csv>"""
+import collections, csv, glob, os, sys
+fn = glob.glob(os.path.join(sys.argv[1], "**/*kernel_trace.csv"), recursive=True)[0]
+rows = [r for r in csv.DictReader(open(fn))]
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
+# steady state: from the end of the 6th to the end of the 14th regression-head GEMM (one per forward): back-to-back timed steps
+heads = sorted(e for s, e, n in ev if "cs_gemm_kernel<6," in n or "cs_gemm_kernel<(CsEpilogue)6" in n)
+if len(heads) < 15: raise SystemExit(f"only {len(heads)} forwards in the trace")
+lo, hi = heads[5], heads[13]
+steps = 8
+pts = []
+for s, e, n in ev:
+    s2, e2 = max(s, lo), min(e, hi)
+    if e2 > s2: pts += [(s2, 1, n), (e2, -1, n)]
+pts.sort()
+depth, last, hist, solo = 0, lo, collections.Counter(), collections.Counter()
+active = collections.Counter()
+for t, d, n in pts:
+    hist[min(depth, 3)] += t - last
+    if depth == 1:
+        k = next(iter(k for k, v in active.items() if v > 0))
+        solo[k.replace("void (anonymous namespace)::", "").split("(")[0][:40]] += t - last
+    last = t
+    depth += d; active[n] += d
+hist[min(depth, 3)] += hi - last
+tot = sum(hist.values())
+print("%d steps, %.2f ms per step" % (steps, (hi - lo) / 1e6 / steps))
+print("steady-state window %.1f ms: idle %.1f %%, one kernel %.1f %%, two %.1f %%, three+ %.1f %%" % (tot / 1e6, *(100 * hist[i] / tot for i in range(4))))
+print("time with exactly one kernel in flight, by kernel:")
+for k, v in solo.most_common(8): print("   %-42s %.1f %%" % (k, 100 * v / tot))
