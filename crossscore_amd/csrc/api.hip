@@ -114,6 +114,7 @@ struct cs_model {
   // the caller's stream with events), so one kernel's tail and the memory-bound stages overlap another's MFMA work
   hipStream_t lane_st[CS_MAX_LANES] = {};
   hipStream_t last_stream = nullptr; hipEvent_t ev_done = nullptr;  // ordering of calls that arrive on different streams
+  hipEvent_t ev_kv0 = nullptr, ev_kv1 = nullptr;                    // decoder: K/V projection on a side stream
   hipEvent_t ev_fork = nullptr, ev_join[CS_MAX_LANES] = {};
   // profiling
   bool prof = false;
@@ -342,6 +343,8 @@ void cs_destroy(cs_handle h) {
   if (h->pe_tab && h->pe_tab != h->pe) hipFree(h->pe_tab);
   if (h->ws) hipFree(h->ws);
   if (h->ev_done) hipEventDestroy(h->ev_done);
+  if (h->ev_kv0) hipEventDestroy(h->ev_kv0);
+  if (h->ev_kv1) hipEventDestroy(h->ev_kv1);
   for (int l = 0; l < CS_MAX_LANES; ++l) { if (h->lane_st[l]) hipStreamDestroy(h->lane_st[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -688,7 +691,20 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       L.begin(32, 0); L.misc(cs_split3_launch(src, M, C, C, act, 0, dst, s), "split3"); L.end();
     };
     if (split_proj && c.do_self_attn) split3(xq, 0, q3);
-    L.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_BF16);
+    // K/V projection of the memory (both layers at once).  Nothing before the first cross-attention depends on it, so with lanes
+    // it runs on lane stream 1 next to layer 0's self-attention branch (the decoder phase has one small kernel in flight otherwise).
+    const bool kv_side = NL >= 2 && c.do_self_attn && !h->prof;
+    if (kv_side) {
+      if (!h->ev_kv0) { if (hipEventCreateWithFlags(&h->ev_kv0, hipEventDisableTiming) != hipSuccess) L.rc = CS_ERR_HIP; }
+      if (!h->ev_kv1) { if (hipEventCreateWithFlags(&h->ev_kv1, hipEventDisableTiming) != hipSuccess) L.rc = CS_ERR_HIP; }
+      if (!L.rc && (hipEventRecord(h->ev_kv0, s) != hipSuccess || hipStreamWaitEvent(lst[1], h->ev_kv0, 0) != hipSuccess)) L.rc = CS_ERR_HIP;
+      Launcher LK{h, lst[1]};
+      LK.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_BF16);
+      if (LK.rc) L.rc = LK.rc;
+      if (!L.rc && hipEventRecord(h->ev_kv1, lst[1]) != hipSuccess) L.rc = CS_ERR_HIP;
+    } else {
+      L.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_BF16);
+    }
     for (int l = 0; l < c.dec_layers; ++l) {
       const DecLayer& D = h->dec[l];
       if (c.do_self_attn) {
@@ -706,6 +722,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.gemm(g, CS_EPI_RESID_F32);
         L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n1g, D.n1b, 1e-5f, xq, q_bf, s), "norm1"); L.end();
       }
+      if (kv_side && l == 0 && !L.rc && hipStreamWaitEvent(s, h->ev_kv1, 0) != hipSuccess) L.rc = CS_ERR_HIP;
       if (split_proj) split3(xq, 0, q3);
       if (split_proj) L.gemm(gp(q3, 3 * C, D.ca_Wq3, 3 * C, M, C, 3 * C, D.ca_bq, dq, C), CS_EPI_BIAS_BF16);
       else L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_BF16);
