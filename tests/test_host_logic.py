@@ -179,3 +179,23 @@ def test_gloo_world2_shard_gather(tmp_path):
         "if rank == 0: print('GLOO_OK', world)\n")
     res = _run_workers(2, str(script))
     assert res.returncode == 0 and "GLOO_OK 2" in res.stdout, res.stdout[-2000:]
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench.json is a verbatim bench.py line: the keys the driver and the judge read must be there."""
+    import json
+
+    path = os.path.join(REPO, "profiles", "r01_bench.json")
+    r = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["metric"].startswith("query-images/sec") and r["unit"] == "query-images/sec" and r["higher_is_better"] is True
+    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "bf16" and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert (rf["bound"] == "hbm") == (rf["unit"] == "GB/s") and (rf["traffic"] is None or rf["traffic"] > 0)
+    cb = r["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+    assert r["score_map_mae"] < 1e-3
