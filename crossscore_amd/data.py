@@ -132,14 +132,15 @@ class SimpleReferenceItems:
         return {"query/img": self.query_paths[idx], "query/score_map": EMPTY, "reference/cross/imgs": refs}
 
 
-def decode_items(items: List[Dict[str, object]], zero_reference: bool = False, pool=None) -> Dict[str, np.ndarray]:
+def decode_items(items: List[Dict[str, object]], zero_reference: bool = False, pool=None, skip=()) -> Dict[str, np.ndarray]:
     """path -> decoded uint8 image for every file the items name (host side; PIL releases the GIL while decoding, so a thread pool
-    plays the role of the reference's DataLoader workers, task/predict.py:110-117)."""
+    plays the role of the reference's DataLoader workers, task/predict.py:110-117).  Reference paths in `skip` (already in the
+    token cache) are not decoded."""
     paths = []
     for it in items:
         paths.append(it["query/img"])
         if not zero_reference:
-            paths += [p for p in it["reference/cross/imgs"] if p != EMPTY]
+            paths += [p for p in it["reference/cross/imgs"] if p != EMPTY and p not in skip]
     uniq = list(dict.fromkeys(paths))
     imgs = list(pool.map(read_image_u8, uniq)) if pool is not None else [read_image_u8(p) for p in uniq]
     return dict(zip(uniq, imgs))
@@ -175,3 +176,61 @@ def load_batch(items: List[Dict[str, object]], stage: InputStage, zero_reference
     item_paths = {"query/img": [it["query/img"] for it in items], "query/score_map": [it["query/score_map"] for it in items],
                   "reference/cross/imgs": [[it["reference/cross/imgs"][n] for it in items] for n in range(N)]}
     return {"query/img": query, "reference/cross/imgs": refs, "item_paths": item_paths}
+
+
+class ReferenceTokenCache:
+    """SURVEY.md 8f-3 inside the predict loop: references are sampled from one finite directory, so each reference image is
+    pre-processed and encoded ONCE (CrossScoreNet.encode_references) and queries are scored with forward_cached -- the same bits
+    as the full forward (tests/test_hip_forward.py), with 1 instead of 1 + N images through the encoder per query."""
+
+    def __init__(self, net, stage: InputStage, keep_images: bool, max_images: int = 4096):
+        self.net, self.stage, self.keep_images, self.max_images = net, stage, keep_images, max_images
+        self.tokens: Dict[object, torch.Tensor] = {}
+        self.images: Dict[object, torch.Tensor] = {}
+
+    def has(self, path: str) -> bool:
+        return any(k[0] == path for k in self.tokens)
+
+    def gather(self, ref_lists: List[List[str]], decoded: Dict[str, np.ndarray], size: Tuple[int, int], zero_reference: bool):
+        """ref_lists: per item the N reference paths -> (tokens (B,N,Np,C) bf16, images (B,N,3,h,w) fp32 or None)."""
+        oh, ow = size
+        keys = [[(EMPTY if (p == EMPTY or zero_reference) else p, oh, ow) for p in refs] for refs in ref_lists]
+        missing = list(dict.fromkeys(k for ks in keys for k in ks if k not in self.tokens))
+        if missing:
+            if len(self.tokens) + len(missing) > self.max_images:
+                self.tokens.clear()
+                self.images.clear()
+                missing = list(dict.fromkeys(k for ks in keys for k in ks))
+            buf = torch.empty((len(missing), 3, oh, ow), dtype=torch.float32, device=self.stage.device)
+            for i, k in enumerate(missing):
+                if k[0] == EMPTY:
+                    buf[i] = self.stage.zero_image_value[:, None, None]
+                    continue
+                img = decoded[k[0]] if k[0] in decoded else read_image_u8(k[0])
+                if self.stage.geometry(*img.shape[:2])[1][2:] != (oh, ow):
+                    raise ValueError(f"{k[0]}: processed size differs from the query's {oh}x{ow}")
+                self.stage(img, buf[i])
+            tok = self.net.encode_references(buf)
+            for i, k in enumerate(missing):
+                self.tokens[k] = tok[i]
+                if self.keep_images:
+                    self.images[k] = buf[i].clone()
+        tokens = torch.stack([torch.stack([self.tokens[k] for k in ks]) for ks in keys])
+        images = torch.stack([torch.stack([self.images[k] for k in ks]) for ks in keys]) if self.keep_images else None
+        return tokens, images
+
+
+def load_query_batch(items: List[Dict[str, object]], stage: InputStage, decoded: Dict[str, np.ndarray]):
+    """Query tensors + item paths of one batch (the references come from a ReferenceTokenCache)."""
+    q_imgs = [decoded[it["query/img"]] if it["query/img"] in decoded else read_image_u8(it["query/img"]) for it in items]
+    geo = {stage.geometry(*im.shape[:2])[1][2:] for im in q_imgs}
+    if len(geo) != 1:
+        raise ValueError(f"query images of one batch must share the processed size, got {sorted(geo)}")
+    oh, ow = next(iter(geo))
+    query = torch.empty((len(items), 3, oh, ow), dtype=torch.float32, device=stage.device)
+    for b, qi in enumerate(q_imgs):
+        stage(qi, query[b])
+    N = len(items[0]["reference/cross/imgs"])
+    item_paths = {"query/img": [it["query/img"] for it in items], "query/score_map": [it["query/score_map"] for it in items],
+                  "reference/cross/imgs": [[it["reference/cross/imgs"][n] for it in items] for n in range(N)]}
+    return {"query/img": query, "reference/cross/imgs": None, "item_paths": item_paths}, (oh, ow)

@@ -27,7 +27,7 @@ import torch
 
 from . import parallel, synth
 from .config import load_config
-from .data import InputStage, SimpleReferenceItems, decode_items, load_batch
+from .data import InputStage, ReferenceTokenCache, SimpleReferenceItems, decode_items, load_batch, load_query_batch
 from .model import CrossScoreNet, load_lightning_checkpoint
 from .writers import BatchWriter, ScoreSummariser
 
@@ -95,16 +95,33 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, int(cfg.data.loader.validation.num_workers)))
     prefetch = ThreadPoolExecutor(max_workers=1)
-    pending = prefetch.submit(decode_items, batches[0], zero_ref, pool) if batches else None
+    # this_main.cache_reference_tokens (this build's key, default on): every reference image goes through the encoder once per run
+    # instead of once per query that samples it; the score maps are bit-identical
+    use_cache = bool(cfg.this_main.get("cache_reference_tokens", True)) and int(cfg.data.neighbour_config.cross) > 0
+    cache = ReferenceTokenCache(net, stage, keep_images=bool(writer is not None and cfg.logger.predict.write.flag.image_reference),
+                                max_images=int(cfg.this_main.get("reference_cache_max_images", 4096))) if use_cache else None
+    cached_paths = lambda: {k[0] for k in cache.tokens} if cache is not None else ()  # noqa: E731
+    pending = prefetch.submit(decode_items, batches[0], zero_ref, pool, cached_paths()) if batches else None
     files, n_done, t_model = [], 0, 0.0
     for batch_idx, its in enumerate(batches):
         decoded = pending.result()
-        pending = prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool) if batch_idx + 1 < len(batches) else None
-        batch = load_batch(its, stage, zero_ref, decoded)
+        if cache is None:
+            pending = prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool) if batch_idx + 1 < len(batches) else None
+            batch = load_batch(its, stage, zero_ref, decoded)
+        else:
+            batch, size = load_query_batch(its, stage, decoded)
+            tokens, ref_imgs = cache.gather([it["reference/cross/imgs"] for it in its], decoded, size, zero_ref)
+            batch["reference/cross/imgs"] = ref_imgs
+            # (submitted after gather so that the set of cached paths is current; decoding overlaps the forward below)
+            pending = (prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool, cached_paths())
+                       if batch_idx + 1 < len(batches) else None)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        out = net(query_img=batch["query/img"], ref_cross_imgs=batch["reference/cross/imgs"], need_attn_weights=bool(cfg.model.need_attn_weights),
-                  need_attn_weights_head_id=int(cfg.model.need_attn_weights_head_id), norm_img=False)
+        if cache is None:
+            out = net(query_img=batch["query/img"], ref_cross_imgs=batch["reference/cross/imgs"], need_attn_weights=bool(cfg.model.need_attn_weights),
+                      need_attn_weights_head_id=int(cfg.model.need_attn_weights_head_id), norm_img=False)
+        else:
+            out = net.forward_cached(batch["query/img"], tokens, bool(cfg.model.need_attn_weights), int(cfg.model.need_attn_weights_head_id))
         torch.cuda.synchronize(device)
         t_model += time.perf_counter() - t0
         n_done += batch["query/img"].shape[0]

@@ -193,6 +193,36 @@ def test_predict_run_matches_oracle_pipeline(tmp_path, colour_mode):
 
 
 @pytest.mark.gpu
+def test_reference_token_cache_gives_identical_outputs(tmp_path):
+    """this_main.cache_reference_tokens on / off: same files, same bytes in the score maps, same CSV."""
+    from PIL import Image
+    from crossscore_amd.config import model_config
+    from crossscore_amd.model import CrossScoreNet
+    from crossscore_amd.predict import predict
+
+    qd, rd = _make_scene(str(tmp_path / "data"), n_query=5, n_ref=4)
+    arch = CrossScoreNet(model_config(**{"backbone.from_pretrained": TINY})).arch
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(arch, 6).items()}
+    outs = {}
+    for flag in (True, False):
+        cfg = load_config("default_predict", [f"data.dataset.query_dir={qd}", f"data.dataset.reference_dir={rd}",
+                                              f"model.backbone.from_pretrained={TINY}", "this_main.resize_short_side=56",
+                                              "data.neighbour_config.cross=3", "data.loader.validation.batch_size=2",
+                                              f"logger.predict.out_dir={tmp_path}/out_{flag}", f"this_main.cache_reference_tokens={flag}",
+                                              "logger.predict.write.config.score_map_colour_mode=gray"])
+        np.random.seed(0)
+        outs[flag] = predict(cfg, state_dict=sd, now="T")
+    a, b = outs[True], outs[False]
+    assert [r[:3] for r in a["rows"]] == [r[:3] for r in b["rows"]] and [r[3] for r in a["rows"]] == [r[3] for r in b["rows"]]
+    fa = sorted(f[len(a["out_dir"]):] for f in a["files"])
+    fb = sorted(f[len(b["out_dir"]):] for f in b["files"])
+    assert fa == fb and len(fa) > 10
+    for rel in fa:
+        if rel.endswith(".png"):
+            assert np.array_equal(np.array(Image.open(a["out_dir"] + rel)), np.array(Image.open(b["out_dir"] + rel))), rel
+
+
+@pytest.mark.gpu
 def test_output_stage_kernels_bit_exact():
     from crossscore_amd.writers import ScoreMapEncoder
 
