@@ -83,7 +83,8 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
     net.load_state_dict(state_dict, strict=True)
     net = net.to(device)
 
-    writer = BatchWriter(cfg, "predict", net.img_mean_std, device) if cfg.logger.predict.write.flag.batch else None
+    writer = (BatchWriter(cfg, "predict", net.img_mean_std, device, workers=max(1, int(cfg.data.loader.validation.num_workers) // 2))
+              if cfg.logger.predict.write.flag.batch else None)
     summariser = ScoreSummariser(cfg.model.predict.metric.type, cfg.model.predict.metric.min, cfg.logger.predict.out_dir)
 
     lo, hi = parallel.shard_bounds(len(items), world, rank)
@@ -128,6 +129,8 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
         summariser.update(batch, out)
         if writer is not None:
             files += writer.write_out(batch, out, local_rank, batch_idx)
+    if writer is not None:
+        writer.finish()
     files += summariser.summarise()
     prefetch.shutdown()
     pool.shutdown()

@@ -101,7 +101,10 @@ def save_png(path, arr: np.ndarray) -> None:
 
 
 class BatchWriter:
-    def __init__(self, cfg, phase: str, img_mean_std: torch.Tensor, device: torch.device):
+    """PNG compression runs on a small thread pool (zlib releases the GIL): the arrays are materialised in the calling thread,
+    the files are complete after finish()."""
+
+    def __init__(self, cfg, phase: str, img_mean_std: torch.Tensor, device: torch.device, workers: int = 4):
         if phase not in ("test", "predict"):
             raise ValueError(f"Phase {phase} not supported. Has to be a Lightening phase test/predict.")
         self.cfg = cfg
@@ -111,6 +114,9 @@ class BatchWriter:
         m = cfg.model.predict.metric
         self.encoder = ScoreMapEncoder(m.type, m.min, m.max, self.write_config.score_map_colour_mode, device)
         self.img_mean_std = img_mean_std.detach().float().cpu()
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self._pending = []
         # batch_writer.py:42-45: attention images only when the model returns the weights
         self.write_attn = bool(self.write_flag["attn_weights"]) and bool(cfg.model.need_attn_weights)
         self.out_dir_dict = {"batch": Path(self.out_dir, "batch")}
@@ -137,7 +143,7 @@ class BatchWriter:
             stems = [name_stem(p) for p in batch_input["item_paths"]["query/img"]]
             for b, (stem, img) in enumerate(zip(stems, batch_input["query/img"])):
                 path = self.out_dir_dict["image_query"] / f"r{local_rank}_B{batch_idx:04}_b{b:03}_{stem}.png"
-                save_png(path, self._de_norm_u8(img))
+                self._save(path, self._de_norm_u8(img))
                 written.append(str(path))
         if self.write_flag["image_reference"] and len(batch_input["item_paths"]["reference/cross/imgs"]) > 0:
             stems = [name_stem(p) for p in batch_input["item_paths"]["query/img"]]
@@ -147,7 +153,7 @@ class BatchWriter:
                 d.mkdir(parents=True, exist_ok=True)
                 for ref_idx, (rp, img) in enumerate(zip(ref_paths[b], batch_input["reference/cross/imgs"][b])):
                     path = d / f"ref{ref_idx:02}_{name_stem(rp)}.png"
-                    save_png(path, self._de_norm_u8(img))
+                    self._save(path, self._de_norm_u8(img))
                     written.append(str(path))
         if self.write_attn and len(batch_input["item_paths"]["reference/cross/imgs"]) > 0:
             written += self._write_attn_weights(batch_input, batch_output, local_rank, batch_idx)
@@ -167,9 +173,18 @@ class BatchWriter:
             maps = amap[b, th // 2, tw // 2].detach().float().cpu().numpy()        # (N_ref, h, w)
             for ref_idx, (rp, m) in enumerate(zip(ref_paths[b], maps)):
                 path = d / f"ref{ref_idx:02}_{name_stem(rp)}.png"
-                save_png(path, attn2rgb(m, table))
+                self._save(path, attn2rgb(m, table))
                 written.append(str(path))
         return written
+
+    def _save(self, path, arr: np.ndarray) -> None:
+        self._pending.append(self._pool.submit(save_png, path, np.ascontiguousarray(arr)))
+
+    def finish(self) -> None:
+        """Waits for every queued file (re-raises the first failure)."""
+        pending, self._pending = self._pending, []
+        for f in pending:
+            f.result()
 
     def _de_norm_u8(self, img_chw: torch.Tensor) -> np.ndarray:
         """de_norm_img + u8 (utils/misc/image.py:25-34, utils/io/images.py:20-23): x*std + mean, *255, truncated to uint8."""
@@ -188,7 +203,7 @@ class BatchWriter:
             imgs = self.encoder(batch_output[key])
             for b, stem in enumerate(stems):
                 path = d / f"r{local_rank}_B{batch_idx:04}_b{b:03}_{stem}.png"
-                save_png(path, imgs[b])
+                self._save(path, imgs[b])
                 written.append(str(path))
         return written
 
