@@ -289,7 +289,8 @@ def main():
                     result[f"speedup_vs_eager_{k}"] = value / v["value"]
     parallel.barrier()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

@@ -71,3 +71,9 @@ def max_over_ranks(value: float, device: torch.device | str = "cpu") -> float:
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def shutdown() -> None:
+    """Tears the process group down (quiet exit of multi-rank runs)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
