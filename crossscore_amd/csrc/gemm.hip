@@ -304,7 +304,9 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   // ---- bias vector -> LDS once per block (read back by inline-asm ds_read at each tile start: a global load there would be
   //      consumed at once and drain the LDS-DMA queue once per tile) ----
   const unsigned bias_lds = (unsigned)(size_t)CS_LDS_PTR(smem + Cfg::BIAS_OFF);
-  const bool bias_in_lds = p.bias && !kLN && p.N <= Cfg::BIAS_MAX;
+  // (a block that owns a single tile reads its 48 bias values per wave straight from global memory: the drain that costs a
+  //  multi-tile block a queue of LDS-DMA falls on the empty prologue there, and the 6 KB fill + barrier would be pure overhead)
+  const bool bias_in_lds = p.bias && !kLN && p.N <= Cfg::BIAS_MAX && my_tiles > 1;
   if (bias_in_lds) {
     for (int i = tid * 4; i < p.N; i += 1024) patch_write16(bias_lds + i * 4, *reinterpret_cast<const f32x4_t*>(p.bias + i));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
