@@ -20,7 +20,7 @@ class CsConfig(C.Structure):
         ("hidden", C.c_int), ("enc_layers", C.c_int), ("enc_heads", C.c_int), ("mlp_ratio", C.c_int),
         ("patch", C.c_int), ("pos_grid", C.c_int), ("pe_h", C.c_int), ("pe_w", C.c_int),
         ("dec_layers", C.c_int), ("dec_heads", C.c_int), ("do_self_attn", C.c_int), ("do_short_cut", C.c_int),
-        ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int), ("ln_fold", C.c_int), ("lanes", C.c_int), ("tail_precision", C.c_int),
+        ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int), ("ln_fold", C.c_int), ("lanes", C.c_int), ("tail_precision", C.c_int), ("enc_fused", C.c_int),
     ]
 
 
@@ -55,6 +55,10 @@ SYMBOLS = {
     "cs_op_pack_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "cs_op_ln_fold_consts": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cs_gemm_column_tiles": (_i, [_i]),
+    "cs_panel_supported": (_i, [_i, _i]),
+    "cs_panel_image_bytes": (_sz, [_i]),
+    "cs_op_panel_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cs_op_encoder_panel": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
 }
 
 _lib = None

@@ -8,7 +8,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrossscore_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "preprocess.hip"]
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip"]
+
+
+# panel.hip: its GELU arithmetic shares one wave's issue stream with the MFMAs; SLP-packed v_pk_fma_f32 (dependent-issue nops)
+# costs more there than scalar fma chains
+EXTRA_FLAGS = {"panel.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -35,7 +40,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + EXTRA_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", o]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for cmd, p in procs:
         out, _ = p.communicate()

@@ -42,6 +42,12 @@ hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int 
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
 hipError_t cs_score_gray16_launch(const float* score, size_t n, int signed_range, uint16_t* out, hipStream_t stream);
 hipError_t cs_score_rgb_launch(const float* score, size_t n, float vmin, float vmax, const uint8_t* lut, uint8_t* out, hipStream_t stream);
+int cs_panel_supported(int C, int mlp_ratio);
+size_t cs_panel_image_bytes(int with_outproj);
+hipError_t cs_panel_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
+                                bf16_t* img, hipStream_t st);
+const char* cs_panel_check(const CsPanelParams* p);
+hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st);
 hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int oh,
                                 int ow, const float* mean, const float* stdv, float* out, float* scratch, hipStream_t stream);
 }
@@ -75,6 +81,7 @@ struct EncLayer {
   bf16_t *Wqkv, *Wo, *W1, *W2;
   // LayerNorm fold (CS_EPI_LN_*): Wqkv / W1 above are then the gamma-scaled versions and these hold s[n], c[n]
   float *s_qkv, *c_qkv, *s_1, *c_1;
+  bf16_t* panel_img;  // token-panel kernel (panel.hip): packed unit stream [Wo | W1 / W2 interleaved]; Wqkv / c_qkv / c_1 are then the LN-folded ones
 };
 struct DecLayer {
   float *sa_bin, *sa_bo, *ca_bq, *ca_bo, *l1b, *l2b, *n1g, *n1b, *n2g, *n2b, *n3g, *n3b;
@@ -93,6 +100,8 @@ struct cs_model {
   std::map<std::string, Tensor> w;
   bool finalized = false;
   int Kp = 0;  // padded patch K
+  bool panel = false;   // encoder layers run as QKV GEMM + attention + ONE token-panel kernel (panel.hip; hidden == 384 only)
+  float *ones = nullptr, *zeros = nullptr;  // [C]: layer 0's norm1 without gamma/beta (they are folded into its QKV projection)
   bool lnfold = false;  // encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass)
   int ln_sp = 0;        // partial-sum slots per row the producing epilogues write (4 per column tile)
   std::vector<void*> owned;  // device allocations of packed weights
@@ -266,6 +275,18 @@ struct Launcher {
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "attention launch: %s", hipGetErrorString(e)); return false; }
     return true;
   }
+  bool panel(const CsPanelParams& q) {
+    if (rc) return false;
+    if (const char* e = cs_panel_check(&q)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
+    const double M = q.M, C = m->cfg.hidden, F = (double)m->cfg.mlp_ratio * C;
+    // algorithmic bytes: x read + written (fp32), attention output read, u written (bf16), the weight stream once
+    begin(40, 2.0 * M * C * C * (q.attn_o ? 1 : 0) + 4.0 * M * C * F,
+          M * C * (8.0 + (q.attn_o ? 2.0 : 0.0) + (q.u_out ? 2.0 : 0.0)) + (double)cs_panel_image_bytes(q.attn_o ? 1 : 0));
+    hipError_t e = cs_panel_launch(&q, st);
+    end();
+    if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "panel launch: %s", hipGetErrorString(e)); return false; }
+    return true;
+  }
   bool misc(hipError_t e, const char* what) {
     if (rc) return false;
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e)); return false; }
@@ -331,6 +352,8 @@ cs_handle cs_create(const cs_config* cfg) {
   // opt-in: measured slower than separate LayerNorm kernels on cfg-2 (kernel-time sum 10.2 vs 9.5 ms: the folded consumers run
   // at the 256-register limit and their tile-switch loads drain the LDS-DMA queue)
   m->lnfold = c.ln_fold == 1 && (m->ln_sp == 4 || m->ln_sp == 8 || m->ln_sp == 16);
+  // default for ViT-S: out-proj + norm2 + MLP + next norm1 in one launch per layer, the 4C hidden never leaves the registers
+  m->panel = c.enc_fused != 1 && !m->lnfold && cs_panel_supported(c.hidden, c.mlp_ratio);
   return m;
 }
 
@@ -429,8 +452,9 @@ int cs_finalize(cs_handle h) {
     HIPCHK(cs_vec_mul_launch(f2b->d, l2->d, b2_s, (int)C, st));
     L.bo = bo_s; L.b2 = b2_s; L.ls1 = nullptr; L.ls2 = nullptr;
     ALLOC_BF(wqkv, (size_t)3 * C * C) ALLOC_F(bqkv, (size_t)3 * C)
-    const float* g1 = h->lnfold ? n1w->d : nullptr;  // LayerNorm gamma folded into the columns of the consuming projection
-    const float* g2 = h->lnfold ? n2w->d : nullptr;
+    const bool fold = h->lnfold || h->panel;
+    const float* g1 = fold ? n1w->d : nullptr;  // LayerNorm gamma folded into the columns of the consuming projection
+    const float* g2 = fold ? n2w->d : nullptr;
     if (int r = pack(qw->d, (int)C, (int)C, (int)C, wqkv, nullptr, g1)) return r;
     if (int r = pack(kw->d, (int)C, (int)C, (int)C, wqkv + C * C, nullptr, g1)) return r;
     if (int r = pack(vw->d, (int)C, (int)C, (int)C, wqkv + 2 * C * C, nullptr, g1)) return r;
@@ -441,7 +465,13 @@ int cs_finalize(cs_handle h) {
     if (int r = pack(f2w->d, (int)C, (int)F, (int)F, w2, l2->d)) return r;
     L.Wqkv = wqkv; L.bqkv = bqkv; L.Wo = wo; L.W1 = w1; L.W2 = w2;
     L.s_qkv = L.c_qkv = L.s_1 = L.c_1 = nullptr;
-    if (h->lnfold) {
+    L.panel_img = nullptr;
+    if (h->panel) {
+      ALLOC_BF(img, cs_panel_image_bytes(1) / sizeof(bf16_t))
+      HIPCHK(cs_panel_pack_launch(ow->d, l1->d, f1w->d, n2w->d, f2w->d, l2->d, img, st));
+      L.panel_img = img;
+    }
+    if (fold) {
       ALLOC_F(sq, (size_t)3 * C) ALLOC_F(cq, (size_t)3 * C) ALLOC_F(s1v, (size_t)F) ALLOC_F(c1v, (size_t)F)
       const float* wsrc[3] = {qw->d, kw->d, vw->d};
       for (int part = 0; part < 3; ++part)
@@ -452,6 +482,13 @@ int cs_finalize(cs_handle h) {
     }
   }
   { NEED(g, "backbone.layernorm.weight", C) NEED(b, "backbone.layernorm.bias", C) h->lnfg = g->d; h->lnfb = b->d; }
+  if (h->panel) {
+    ALLOC_F(on, (size_t)C) ALLOC_F(ze, (size_t)C)
+    std::vector<float> hv((size_t)C, 1.0f);
+    HIPCHK(hipMemcpy(on, hv.data(), (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ze, 0, (size_t)C * sizeof(float)));
+    h->ones = on; h->zeros = ze;
+  }
   { NEED(pe, "pos_enc_fn.PE", 1, c.pe_h, c.pe_w, C) h->pe = pe->d; }
   h->dec.resize(c.dec_layers);
   { ALLOC_BF(wkv, (size_t)c.dec_layers * 2 * C * C) ALLOC_F(bkv, (size_t)c.dec_layers * 2 * C) h->Wkv_all = wkv; h->bkv_all = bkv; }
@@ -612,6 +649,19 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
       a.q_bs = a.k_bs = a.v_bs = (long long)p.T * 3 * C; a.o_bs = (long long)p.T * C;
       a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = LOG2E / std::sqrt((float)enc_dh); a.lse = nullptr;
+      if (h->panel) {
+        // u = bf16 normalised rows (norm1 without gamma/beta: folded into Wqkv / c_qkv), written by the previous layer's panel
+        // kernel; layer 0 gets it from the LayerNorm kernel
+        if (l == 0) { L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, h->ones, h->zeros, 1e-6f, nullptr, u, s), "ln1"); L.end(); }
+        L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C), CS_EPI_BIAS_BF16);
+        a.O = u;
+        L.attn(a, enc_dh, ic);
+        CsPanelParams q{};
+        q.x = x; q.attn_o = u; q.img = E.panel_img; q.bo = E.bo; q.b1 = E.c_1; q.b2 = E.b2; q.u_out = last ? nullptr : u;
+        q.M = Mc; q.eps = 1e-6f;
+        L.panel(q);
+        continue;
+      }
       if (fold) {
         // u holds bf16(x) and `stats` the per-row partial sums, both written by the epilogue that produced x: LayerNorm is
         // applied inside the consuming projection's epilogue (CS_EPI_LN_*), there is no separate LN pass over x
@@ -976,9 +1026,25 @@ int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, con
   return 0;
 }
 
+int cs_op_panel_pack(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
+                     uint16_t* img, cs_stream stream) {
+  if (!w1 || !w2 || !img) return fail(CS_ERR_BAD_ARG, "panel_pack: null argument");
+  HIPCHK(cs_panel_pack_launch(wo, ls1, w1, g2, w2, ls2, img, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, const float* bo, const float* b1, const float* b2,
+                        uint16_t* u_out, int M, float eps, cs_stream stream) {
+  CsPanelParams q{};
+  q.x = x; q.attn_o = attn_o; q.img = img; q.bo = bo; q.b1 = b1; q.b2 = b2; q.u_out = u_out; q.M = M; q.eps = eps;
+  if (const char* e = cs_panel_check(&q)) return fail(CS_ERR_BAD_ARG, "%s", e);
+  HIPCHK(cs_panel_launch(&q, (hipStream_t)stream));
+  return 0;
+}
+
 int cs_op_ln_fold_consts(const uint16_t* w_packed, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
                          float* s_out, float* c_out, cs_stream stream) {
-  if (!w_packed || !w || !beta || !s_out || !c_out || N <= 0 || K <= 0 || ldp < K) return fail(CS_ERR_BAD_ARG, "ln_fold_consts: bad arguments");
+  if (!w || !beta || !c_out || (w_packed && (!s_out || ldp < K)) || N <= 0 || K <= 0) return fail(CS_ERR_BAD_ARG, "ln_fold_consts: bad arguments");
   HIPCHK(cs_ln_fold_consts_launch(w_packed, ldp, w, beta, bias, N, K, s_out, c_out, (hipStream_t)stream));
   return 0;
 }

@@ -41,6 +41,49 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// GELU(x) = x * Phi(x) with the exact (erf) Phi of HF ACT2FN["gelu"] (HF modeling_dinov2.py:293-297) approximated by
+// Phi(x) ~ 0.5 + x * P(x^2), x clamped to +-4.2; P is a degree-7 minimax fit of the GELU error:
+// max |GELU_fit - GELU_erf| = 6.7e-5 (2.1e-4 as evaluated in fp32 Horner form, near |x| = 4 where y ~ x; a bf16 half-ulp is
+// 2e-3 at |y| = 1 and 8e-3 at 4).  12 plain VALU ops, no
+// transcendentals: the fc1 epilogue was spending more issue slots on erf (v_exp + v_rcp) than its K loop on MFMAs
+// (PMC: SQ_ACTIVE_INST_VALU 51 % vs MFMA pipe busy 26 % with the Abramowitz-Stegun erf).
+// Four values per call as two packed-fp32 Horner chains (v_pk_fma_f32) issued alternately from one asm block: a lone chain pays
+// a dependent-issue bubble on every packed fma, and the compiler's scheduler serialises the chains again whatever the source
+// order.  The fitted Phi stays inside [-1.2e-6, 1 + 1.2e-6] on the clamped range, so it is not clamped again.
+__device__ __forceinline__ unsigned long long gelu_c(float c) { return (unsigned long long)__float_as_uint(c); }
+__device__ __forceinline__ void gelu_erf4(float (&v)[4]) {
+  const f32x2_t xa = {v[0], v[1]}, xb = {v[2], v[3]};
+  const f32x2_t ca = {__builtin_amdgcn_fmed3f(v[0], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(v[1], -4.2f, 4.2f)};
+  const f32x2_t cb = {__builtin_amdgcn_fmed3f(v[2], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(v[3], -4.2f, 4.2f)};
+  const f32x2_t ta = ca * ca, tb = cb * cb;
+  const f32x2_t c1 = {8.3297297734e-08f, 8.3297297734e-08f};
+  f32x2_t qa, qb;
+  // q = c0*t + c1, then q = q*t + c_k: the scalar operand is a register pair whose low half is broadcast (op_sel_hi 0)
+  // (leading / trailing s_nop: the packed-fma result hazard against the compiler's own neighbouring instructions)
+  asm("s_nop 0\n\t"
+      "v_pk_fma_f32 %0, %2, %4, %5 op_sel_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %1, %3, %4, %5 op_sel_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %6 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %6 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %7 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %7 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %8 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %8 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %9 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %9 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %10 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %10 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %11 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %11 op_sel_hi:[1,1,0]\n\t"
+      "s_nop 0"
+      : "=&v"(qa), "=&v"(qb)
+      : "v"(ta), "v"(tb), "s"(gelu_c(-9.6129670387e-10f)), "v"(c1), "s"(gelu_c(-3.1398569575e-06f)), "s"(gelu_c(6.8266010957e-05f)),
+        "s"(gelu_c(-9.6075936689e-04f)), "s"(gelu_c(9.3374518106e-03f)), "s"(gelu_c(-6.5599355124e-02f)), "s"(gelu_c(3.9850871469e-01f)));
+  const f32x2_t ya = xa * __builtin_elementwise_fma(ca, qa, f32x2_t{0.5f, 0.5f});
+  const f32x2_t yb = xb * __builtin_elementwise_fma(cb, qb, f32x2_t{0.5f, 0.5f});
+  v[0] = ya[0]; v[1] = ya[1]; v[2] = yb[0]; v[3] = yb[1];
+}
+
 // ---- kernel parameter blocks (plain structs; launchers live in the matching .hip files) -------------
 enum CsEpilogue {
   CS_EPI_BIAS_BF16 = 0,        // out_bf16[m][n] = acc + bias[n]
@@ -100,4 +143,21 @@ struct CsAttnParams {
   float scale_log2e;                                   // (1/sqrt(dh)) * log2(e)
   float* lse;                                          // optional [batch][heads][Lq]: m*ln2-scaled log-sum-exp (base 2)
   int o_split;                                         // 0, or C: O rows are [hi | lo | hi] (3C wide, split-bf16 operand of the out-projection)
+};
+
+// Encoder "token panel" kernel (panel.hip): one launch per DINOv2 layer does, for 128-row panels of the residual stream,
+//   x += attn_o Wo'^T + bo'                 (attention output projection, LayerScale folded; HF modeling_dinov2.py:249-252,365-370)
+//   x += GELU(LN2(x) W1'^T + b1') W2'^T + b2'   (norm2 + MLP + LayerScale; HF:373-378, 293-297)
+//   u_out = bf16((x - mean) * rstd)         (norm1 of the NEXT layer without gamma/beta: they are folded into its QKV projection)
+// The weights arrive as one pre-packed stream of 24-KiB "units" in the exact LDS image / consumption order (cs_panel_pack_*).
+struct CsPanelParams {
+  float* x;                // [M][C] fp32 residual stream, updated in place
+  const bf16_t* attn_o;    // [M][C] bf16 attention output, or null: no out-projection (x is taken as is)
+  const bf16_t* img;       // unit stream: [12 Wo units (if attn_o)] [96 MLP units]
+  const float* bo;         // [C] out-projection bias (LayerScale folded), used when attn_o
+  const float* b1;         // [4C] fc1 bias with LN2 beta folded in
+  const float* b2;         // [C] fc2 bias (LayerScale folded)
+  bf16_t* u_out;           // [M][C] or null
+  int M;
+  float eps;               // LayerNorm eps (1e-6 in DINOv2)
 };

@@ -344,12 +344,12 @@ __global__ __launch_bounds__(256) void ln_fold_consts_kernel(const bf16_t* __res
   if (n >= N) return;
   float s = 0.f, c = 0.f;
   for (int k = lane; k < K; k += 64) {
-    s += bf2f(wp[(size_t)n * ldp + k]);
+    if (wp) s += bf2f(wp[(size_t)n * ldp + k]);
     c += beta[k] * w[(size_t)n * K + k];
   }
   s = wave_sum(s);
   c = wave_sum(c);
-  if (lane == 0) { s_out[n] = s; c_out[n] = c + (bias ? bias[n] : 0.f); }
+  if (lane == 0) { if (s_out) s_out[n] = s; c_out[n] = c + (bias ? bias[n] : 0.f); }
 }
 
 __global__ void vec_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {

@@ -61,49 +61,6 @@ __device__ long long* g_cs_dbg = nullptr;
 #define CS_T(k) do { } while (0)
 #endif
 
-// GELU(x) = x * Phi(x) with the exact (erf) Phi of HF ACT2FN["gelu"] (HF modeling_dinov2.py:293-297) approximated by
-// Phi(x) ~ 0.5 + x * P(x^2), x clamped to +-4.2; P is a degree-7 minimax fit of the GELU error:
-// max |GELU_fit - GELU_erf| = 6.7e-5 (2.1e-4 as evaluated in fp32 Horner form, near |x| = 4 where y ~ x; a bf16 half-ulp is
-// 2e-3 at |y| = 1 and 8e-3 at 4).  12 plain VALU ops, no
-// transcendentals: the fc1 epilogue was spending more issue slots on erf (v_exp + v_rcp) than its K loop on MFMAs
-// (PMC: SQ_ACTIVE_INST_VALU 51 % vs MFMA pipe busy 26 % with the Abramowitz-Stegun erf).
-// Four values per call as two packed-fp32 Horner chains (v_pk_fma_f32) issued alternately from one asm block: a lone chain pays
-// a dependent-issue bubble on every packed fma, and the compiler's scheduler serialises the chains again whatever the source
-// order.  The fitted Phi stays inside [-1.2e-6, 1 + 1.2e-6] on the clamped range, so it is not clamped again.
-__device__ __forceinline__ unsigned long long gelu_c(float c) { return (unsigned long long)__float_as_uint(c); }
-__device__ __forceinline__ void gelu_erf4(float (&v)[4]) {
-  const f32x2_t xa = {v[0], v[1]}, xb = {v[2], v[3]};
-  const f32x2_t ca = {__builtin_amdgcn_fmed3f(v[0], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(v[1], -4.2f, 4.2f)};
-  const f32x2_t cb = {__builtin_amdgcn_fmed3f(v[2], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(v[3], -4.2f, 4.2f)};
-  const f32x2_t ta = ca * ca, tb = cb * cb;
-  const f32x2_t c1 = {8.3297297734e-08f, 8.3297297734e-08f};
-  f32x2_t qa, qb;
-  // q = c0*t + c1, then q = q*t + c_k: the scalar operand is a register pair whose low half is broadcast (op_sel_hi 0)
-  // (leading / trailing s_nop: the packed-fma result hazard against the compiler's own neighbouring instructions)
-  asm("s_nop 0\n\t"
-      "v_pk_fma_f32 %0, %2, %4, %5 op_sel_hi:[1,0,0]\n\t"
-      "v_pk_fma_f32 %1, %3, %4, %5 op_sel_hi:[1,0,0]\n\t"
-      "v_pk_fma_f32 %0, %0, %2, %6 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %1, %1, %3, %6 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %0, %0, %2, %7 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %1, %1, %3, %7 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %0, %0, %2, %8 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %1, %1, %3, %8 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %0, %0, %2, %9 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %1, %1, %3, %9 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %0, %0, %2, %10 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %1, %1, %3, %10 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %0, %0, %2, %11 op_sel_hi:[1,1,0]\n\t"
-      "v_pk_fma_f32 %1, %1, %3, %11 op_sel_hi:[1,1,0]\n\t"
-      "s_nop 0"
-      : "=&v"(qa), "=&v"(qb)
-      : "v"(ta), "v"(tb), "s"(gelu_c(-9.6129670387e-10f)), "v"(c1), "s"(gelu_c(-3.1398569575e-06f)), "s"(gelu_c(6.8266010957e-05f)),
-        "s"(gelu_c(-9.6075936689e-04f)), "s"(gelu_c(9.3374518106e-03f)), "s"(gelu_c(-6.5599355124e-02f)), "s"(gelu_c(3.9850871469e-01f)));
-  const f32x2_t ya = xa * __builtin_elementwise_fma(ca, qa, f32x2_t{0.5f, 0.5f});
-  const f32x2_t yb = xb * __builtin_elementwise_fma(cb, qb, f32x2_t{0.5f, 0.5f});
-  v[0] = ya[0]; v[1] = ya[1]; v[2] = yb[0]; v[3] = yb[1];
-}
-
 // RegressionLayer activation (regression_layer.py:26-62); kept out of line so the unrolled head epilogue does not spill
 __device__ __noinline__ float head_activation(float v, int act, float powp) {
   float y = act == 0 ? 1.0f / (1.0f + __expf(-v)) : tanhf(v);

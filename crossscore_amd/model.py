@@ -101,6 +101,7 @@ class CrossScoreNet(torch.nn.Module):
         self.enc_chunk_images = 0  # 0 = library default
         self.lanes = 0             # 0 = library default (2 concurrent lanes); 1 = serial
         self.tail_precision = 0    # split-bf16 operands: 0 = head + decoder FFN (default), 2 = + decoder in/Q/out-projections, 1 = plain bf16
+        self.enc_fused = 0         # 0 = token-panel kernel per encoder layer where supported (hidden 384), 1 = unfused kernels
         self.ln_fold = 0           # 1 = fold the encoder LayerNorms into the QKV / fc1 GEMM epilogues (opt-in; slower so far)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
@@ -133,7 +134,7 @@ class CrossScoreNet(torch.nn.Module):
                            pos_grid=a.pos_grid, pe_h=a.pe_h, pe_w=a.pe_w, dec_layers=a.dec_layers, dec_heads=a.dec_heads,
                            do_self_attn=int(bool(m.decoder_do_self_attn)), do_short_cut=int(bool(m.decoder_do_short_cut)),
                            act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold), tail_precision=int(self.tail_precision),
-                           lanes=int(self.lanes))
+                           lanes=int(self.lanes), enc_fused=int(self.enc_fused))
         with torch.cuda.device(device):
             h = lib.cs_create(C.byref(cc))
             if not h:

@@ -59,6 +59,9 @@ typedef struct cs_config {
                        * ~6.1e-4 on cfg-2 at < 2 % time), 2 = also the decoder's self-attention in-proj, cross-attention Q-proj and both
                        * out-projections (attention writes its output as hi | lo | hi): 5.0e-4 at a further 1.8 %,
                        * 1 = plain bf16 everywhere */
+  int enc_fused;      /* encoder layer structure: 0 = default: with hidden == 384 (ViT-S) each layer is QKV GEMM + attention + ONE
+                       * token-panel kernel (out-projection, residual, norm2, fc1, GELU, fc2, residual and the next layer's norm1; the 4C
+                       * hidden activations stay in registers), else the unfused kernels; 1 = always the unfused kernels */
 } cs_config;
 
 /* Replaces CrossScoreNet.__init__ (task/core.py:27-56). NULL on failure. */
@@ -96,7 +99,7 @@ int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_token
 size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
 
 /* Per-kernel-family timing with HIP events on the launch stream (for bench.py's roofline object).
- * Families = kernel symbols: 0..6 cs_gemm_kernel<epilogue>, 16 + dh/16 cs_attn_kernel<dh>, 32 everything else
+ * Families = kernel symbols: 0..9 cs_gemm_kernel<epilogue>, 16 + dh/16 cs_attn_kernel<dh>, 40 cs_panel_kernel, 32 everything else
  * (LayerNorm, im2col, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */
 int cs_profile_enable(cs_handle h, int on);
 int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, double* flops);
@@ -144,6 +147,18 @@ int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, con
 /* LayerNorm fold constants of a projection: s[n] = sum_k packed W'[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] */
 int cs_op_ln_fold_consts(const uint16_t* w_packed, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
                          float* s_out, float* c_out, cs_stream stream);
+/* Encoder token-panel kernel (csrc/panel.hip; hidden 384, MLP 1536 only).  cs_op_panel_pack builds the weight stream the kernel
+ * consumes from fp32 matrices: wo (C,C) [NULL: no out-projection units] with per-row scale ls1 (layer_scale1), w1 (4C,C) with
+ * per-column scale g2 (norm2 gamma), w2 (C,4C) with per-row scale ls2 (layer_scale2); scales may be NULL.  img must hold
+ * cs_panel_image_bytes(wo != NULL) bytes.  cs_op_encoder_panel then computes, in place on x (M,C) fp32,
+ *   x += attn_o Wo'^T + bo   (skipped when attn_o is NULL);   x += GELU(norm(x) W1'^T + b1) W2'^T + b2;
+ *   u_out = bf16(norm(x))    (skipped when NULL), norm = LayerNorm without gamma/beta (HF modeling_dinov2.py:361-380). */
+int cs_panel_supported(int hidden, int mlp_ratio);
+size_t cs_panel_image_bytes(int with_outproj);
+int cs_op_panel_pack(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
+                     uint16_t* img, cs_stream stream);
+int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, const float* bo, const float* b1, const float* b2,
+                        uint16_t* u_out, int M, float eps, cs_stream stream);
 /* number of column tiles the GEMM launcher uses for N output columns (LayerNorm partial-sum slots per row = 4 x this) */
 int cs_gemm_column_tiles(int N);
 

@@ -110,3 +110,21 @@ def ln_fold_consts(w_packed, w, beta, bias):
 
 def column_tiles(N):
     return _lib.load().cs_gemm_column_tiles(N)
+
+
+def panel_pack(wo, ls1, w1, g2, w2, ls2):
+    """fp32 weights -> the unit stream of the encoder token-panel kernel (uint8 tensor of cs_panel_image_bytes)."""
+    lib = _lib.load()
+    n = lib.cs_panel_image_bytes(1 if wo is not None else 0)
+    img = torch.zeros(n, dtype=torch.uint8, device=w1.device)
+    _lib.check(lib.cs_op_panel_pack(_p(wo), _p(ls1), _p(w1), _p(g2), _p(w2), _p(ls2), _p(img), _stream()))
+    return img
+
+
+def encoder_panel(x, attn_o, img, bo, b1, b2, want_u=True, eps=1e-6):
+    """In place on x (M,384) fp32; returns u (M,384) bf16 or None."""
+    lib = _lib.load()
+    M = x.shape[0]
+    u = torch.zeros((M, x.shape[1]), dtype=torch.bfloat16, device=x.device) if want_u else None
+    _lib.check(lib.cs_op_encoder_panel(_p(x), _p(attn_o), _p(img), _p(bo), _p(b1), _p(b2), _p(u), M, eps, _stream()))
+    return u
