@@ -114,11 +114,14 @@ struct cs_model {
   bf16_t *Wh0 = nullptr, *Wh2 = nullptr; float *bh0 = nullptr, *bh2 = nullptr;
   bf16_t *Wh03 = nullptr, *Wh23 = nullptr;  // split-bf16 head weights
   float *lnfg = nullptr, *lnfb = nullptr, *cls = nullptr, *pos = nullptr, *pe = nullptr;
-  // per-(gh,gw,square) tables
-  int tab_gh = -1, tab_gw = -1, tab_sq = -1;
-  float *pos_tab = nullptr, *pe_tab = nullptr; bool pos_tab_owned = false;
-  // workspace
+  // per-(gh,gw,square) tables: built once per shape and kept (a shape change never overwrites a table that queued work may read)
+  struct Tables { int gh, gw, sq; float *pos_tab, *pe_tab; bool pos_owned, pe_owned; };
+  std::vector<Tables> tables;
+  float *pos_tab = nullptr, *pe_tab = nullptr;  // the current shape's (point into `tables` or at the parameters)
+  // workspace; a workspace that had to grow is retired behind an event and freed once that event has completed
   char* ws = nullptr; size_t ws_bytes = 0;
+  struct Retired { void* p; hipEvent_t ev; };
+  std::vector<Retired> retired;
   // lanes: internal streams that run independent image chunks / batch groups concurrently (forked from and joined to
   // the caller's stream with events), so one kernel's tail and the memory-bound stages overlap another's MFMA work
   hipStream_t lane_st[CS_MAX_LANES] = {};
@@ -304,28 +307,47 @@ CsGemmParams gp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N
 int ensure_tables(cs_model* m, int gh, int gw, bool square, hipStream_t st) {
   const cs_config& c = m->cfg;
   const int sq = square ? 1 : 0;
-  if (m->tab_gh == gh && m->tab_gw == gw && m->tab_sq == sq) return 0;
-  // tables may still be read by work queued on st from a previous shape
-  HIPCHK(hipStreamSynchronize(st));
-  if (m->pos_tab && m->pos_tab_owned) hipFree(m->pos_tab);
-  if (m->pe_tab && m->pe_tab != m->pe) hipFree(m->pe_tab);
-  m->pos_tab = nullptr; m->pe_tab = nullptr; m->pos_tab_owned = false;
+  for (auto& t : m->tables)
+    if (t.gh == gh && t.gw == gw && t.sq == sq) { m->pos_tab = t.pos_tab; m->pe_tab = t.pe_tab; return 0; }
+  // first forward of this patch grid: allocate and fill its tables on the caller's stream (stream-ordered with the kernels that
+  // read them).  Tables of other grids stay as they are -- work queued on any stream may still read them -- so there is nothing to
+  // wait for; only past 16 distinct grids are the oldest dropped, behind a device synchronisation.
+  if (m->tables.size() >= 16) {
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& t : m->tables) { if (t.pos_owned) hipFree(t.pos_tab); if (t.pe_owned) hipFree(t.pe_tab); }
+    m->tables.clear();
+  }
+  cs_model::Tables t{gh, gw, sq, nullptr, nullptr, false, false};
   const int Np = gh * gw, C = c.hidden;
   if (Np == c.pos_grid * c.pos_grid && square) {  // HF:71 -- parameter used as is
-    m->pos_tab = m->pos;
+    t.pos_tab = m->pos;
   } else {
-    HIPCHK(hipMalloc(&m->pos_tab, (size_t)(1 + Np) * C * sizeof(float)));
-    m->pos_tab_owned = true;
-    HIPCHK(cs_pos_bicubic_launch(m->pos, c.pos_grid, C, gh, gw, m->pos_tab, st));
+    HIPCHK(hipMalloc(&t.pos_tab, (size_t)(1 + Np) * C * sizeof(float)));
+    t.pos_owned = true;
+    HIPCHK(cs_pos_bicubic_launch(m->pos, c.pos_grid, C, gh, gw, t.pos_tab, st));
   }
   if (gh == c.pe_h && gw == c.pe_w) {  // positional_encoding.py:51-56
-    m->pe_tab = m->pe;
+    t.pe_tab = m->pe;
   } else {
-    HIPCHK(hipMalloc(&m->pe_tab, (size_t)Np * C * sizeof(float)));
-    HIPCHK(cs_pe_bilinear_launch(m->pe, c.pe_h, c.pe_w, C, gh, gw, m->pe_tab, st));
+    HIPCHK(hipMalloc(&t.pe_tab, (size_t)Np * C * sizeof(float)));
+    t.pe_owned = true;
+    HIPCHK(cs_pe_bilinear_launch(m->pe, c.pe_h, c.pe_w, C, gh, gw, t.pe_tab, st));
   }
-  m->tab_gh = gh; m->tab_gw = gw; m->tab_sq = sq;
+  m->tables.push_back(t);
+  m->pos_tab = t.pos_tab; m->pe_tab = t.pe_tab;
   return 0;
+}
+
+// Frees retired workspaces whose last use has completed (never blocks).
+void reap_retired(cs_model* m, bool all) {
+  for (size_t i = 0; i < m->retired.size();) {
+    if (all || hipEventQuery(m->retired[i].ev) == hipSuccess) {
+      hipFree(m->retired[i].p); hipEventDestroy(m->retired[i].ev);
+      m->retired.erase(m->retired.begin() + i);
+    } else {
+      ++i;
+    }
+  }
 }
 
 }  // namespace
@@ -362,8 +384,8 @@ void cs_destroy(cs_handle h) {
   hipDeviceSynchronize();
   for (auto& kv : h->w) if (kv.second.d) hipFree(kv.second.d);
   for (void* p : h->owned) hipFree(p);
-  if (h->pos_tab && h->pos_tab_owned) hipFree(h->pos_tab);
-  if (h->pe_tab && h->pe_tab != h->pe) hipFree(h->pe_tab);
+  for (auto& t : h->tables) { if (t.pos_owned) hipFree(t.pos_tab); if (t.pe_owned) hipFree(t.pe_tab); }
+  reap_retired(h, true);
   if (h->ws) hipFree(h->ws);
   if (h->ev_done) hipEventDestroy(h->ev_done);
   if (h->ev_kv0) hipEventDestroy(h->ev_kv0);
@@ -569,16 +591,27 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   const int C = c.hidden, P = c.patch;
   const int N_enc = mode == 0 ? N : 0;          // reference views that go through the encoder with their query
   const int N_plan = mode == 2 ? 0 : N;
+  {
+    const long long Np = (long long)(H / P) * (W / P);
+    if ((long long)B * N * Np * 2 * C * c.dec_layers >= (1ll << 31)) return fail(CS_ERR_UNSUPPORTED, "batch too large for 32-bit offsets; split the batch");
+    if (attn_out && Np > 65535) return fail(CS_ERR_UNSUPPORTED, "need_attn_weights with more than 65535 patches per image is not built");
+  }
   const size_t need = make_plan(h, B, N_plan, N_enc, H, W, nullptr).total;
+  reap_retired(h, false);
   if (need > h->ws_bytes) {
-    HIPCHK(hipStreamSynchronize(st));
-    if (h->ws) hipFree(h->ws);
+    // grow: the old workspace may still be in use by work queued earlier (on this or another stream), so it is retired behind an
+    // event recorded on this call's stream (which is ordered after every earlier call) and freed by a later call once that event has completed -- no wait here
+    if (h->ws) {
+      cs_model::Retired r{h->ws, nullptr};
+      HIPCHK(hipEventCreateWithFlags(&r.ev, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(r.ev, st));  // st already waits for the previous call's stream (forward_impl)
+      h->retired.push_back(r);
+    }
     h->ws = nullptr; h->ws_bytes = 0;
     HIPCHK(hipMalloc(&h->ws, need));
     h->ws_bytes = need;
   }
   Plan p = make_plan(h, B, N_plan, N_enc, H, W, h->ws);
-  if ((long long)B * N * p.Np * 2 * C * c.dec_layers >= (1ll << 31)) return fail(CS_ERR_UNSUPPORTED, "batch too large for 32-bit offsets; split the batch");
   if (int r = ensure_tables(h, p.gh, p.gw, H == W, st)) return r;
   const int enc_dh = C / c.enc_heads, dec_dh = C / c.dec_heads;
   const int F = c.mlp_ratio * C;

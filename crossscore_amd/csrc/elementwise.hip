@@ -420,11 +420,13 @@ hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, b
   const int gh = H / P, gw = W / P;
   const size_t lds = (size_t)gw * Kp * sizeof(bf16_t) + (pmean ? ((size_t)P * gw * P + gw + (size_t)gw * P) * sizeof(float) : 0);
   if (P == 14 && Kp >= 3 * P * P && lds <= 156 * 1024 && (long long)I * gh < (1ll << 31) && gw <= 256) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[16] = {};  // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(im2col_rows_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
       if (e != hipSuccess) return e;
-      attr_done = true;
+      attr_done[dev] = true;
     }
     hipLaunchKernelGGL(im2col_rows_kernel<14>, dim3(I * gh), dim3(256), lds, st, xq, xr, N, img0, out, H, W, gh, gw, Kp, pmean);
     return hipGetLastError();
@@ -532,6 +534,7 @@ hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, 
 }
 
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st) {
+  if (p->Lq <= 0 || p->Lq > 65535 || batch <= 0 || batch > 65535) return hipErrorInvalidValue;  // grid.y / grid.z limits
   dim3 grid((p->Lk + 255) / 256, p->Lq, batch);
   switch (dh) {
     case 16: hipLaunchKernelGGL(attn_weights_kernel<16>, grid, dim3(256), 0, st, *p, head, out); break;

@@ -661,23 +661,25 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
 #endif
 }
 
-int g_num_cus = 0;
+constexpr int CS_MAX_DEVICES = 16;
+int g_num_cus[CS_MAX_DEVICES] = {};  // per device (a handle may be moved to another GPU of the process)
 
 template <int EPI, int NSUB, int SPL, bool PIPE = false>
 hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   constexpr int BN = 64 * NSUB;
   constexpr int LDS = GemmCfg<NSUB>::LDS;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[CS_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CS_MAX_DEVICES) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm_kernel<EPI, NSUB, SPL, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done[dev] = true;
   }
-  if (g_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    g_num_cus = prop.multiProcessorCount;
+  if (g_num_cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return hipErrorUnknown;
+    g_num_cus[dev] = n;
   }
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -685,7 +687,7 @@ hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   // p.bpc > 2 oversubscribes the CUs (only two blocks are resident per CU; the rest queue behind them): each block then walks
   // fewer tiles and gives its slot back sooner, which pays when a second stream's kernels share the GPU (two encoder lanes:
   // -2 % step time with 3..16 blocks per CU) and costs when the kernel runs alone (+1..5 %).
-  int grid = ((p.bpc > 0 ? p.bpc : 2) * g_num_cus / 8) * 8;
+  int grid = ((p.bpc > 0 ? p.bpc : 2) * g_num_cus[dev] / 8) * 8;
 #ifdef CS_ABLATE
   if (const char* e = getenv("CS_GEMM_GRID")) grid = atoi(e);
 #endif

@@ -57,16 +57,17 @@ void build_axis(int in, int out, AxisTable& t) {
   }
 }
 
-// device copy of the two tables of the last (in_h, in_w, rs_h, rs_w); grown on demand, reused while the sizes repeat
-struct TableCache {
-  int in_h = 0, in_w = 0, rs_h = 0, rs_w = 0;
-  AxisTable tx, ty;
+// Device copies of the two filter tables of one (device, in_h, in_w, rs_h, rs_w).  An entry is written once, on the stream of the
+// call that creates it, and never overwritten: kernels queued on any stream keep reading valid tables, so a change of image size
+// needs no synchronisation.  A directory of images has a handful of sizes; past 64 entries the cache is dropped behind a device
+// synchronisation.
+struct TableEntry {
+  int dev = 0, in_h = 0, in_w = 0, rs_h = 0, rs_w = 0;
+  int taps_x = 0, taps_y = 0;
   int* d_int = nullptr;    // xmin[rs_w] xsize[rs_w] ymin[rs_h] ysize[rs_h]
   float* d_w = nullptr;    // wx[rs_w][taps_x] wy[rs_h][taps_y]
-  size_t cap_int = 0, cap_w = 0;
-  std::vector<int> h_int;
-  std::vector<float> h_w;
-} g_tab;
+};
+std::vector<TableEntry> g_tabs;
 
 __global__ void u8_norm_kernel(const uint8_t* __restrict__ img, int row_bytes, int crop_y, int crop_x, int oh, int ow,
                                float m0, float m1, float m2, float s0, float s1, float s2, float* __restrict__ out) {
@@ -178,48 +179,51 @@ extern "C" hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_
                        mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
     return hipGetLastError();
   }
-  TableCache& T = g_tab;
-  if (T.in_h != in_h || T.in_w != in_w || T.rs_h != rs_h || T.rs_w != rs_w) {
-    // the previous tables may still be read by kernels in flight on another stream: finish them before overwriting
-    hipError_t e = hipDeviceSynchronize();
-    if (e != hipSuccess) return e;
-    build_axis(in_w, rs_w, T.tx);
-    build_axis(in_h, rs_h, T.ty);
-    const size_t n_int = 2 * (size_t)rs_w + 2 * (size_t)rs_h;
-    const size_t n_w = (size_t)rs_w * T.tx.taps + (size_t)rs_h * T.ty.taps;
-    if (n_int > T.cap_int) {
-      if (T.d_int) (void)hipFree(T.d_int);
-      if ((e = hipMalloc(&T.d_int, n_int * sizeof(int))) != hipSuccess) return e;
-      T.cap_int = n_int;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const TableEntry* hit = nullptr;
+  for (const TableEntry& t : g_tabs)
+    if (t.dev == dev && t.in_h == in_h && t.in_w == in_w && t.rs_h == rs_h && t.rs_w == rs_w) { hit = &t; break; }
+  if (!hit) {
+    if (g_tabs.size() >= 64) {
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+      for (TableEntry& t : g_tabs) { (void)hipFree(t.d_int); (void)hipFree(t.d_w); }
+      g_tabs.clear();
     }
-    if (n_w > T.cap_w) {
-      if (T.d_w) (void)hipFree(T.d_w);
-      if ((e = hipMalloc(&T.d_w, n_w * sizeof(float))) != hipSuccess) return e;
-      T.cap_w = n_w;
-    }
-    T.h_int.clear();
-    T.h_int.insert(T.h_int.end(), T.tx.xmin.begin(), T.tx.xmin.end());
-    T.h_int.insert(T.h_int.end(), T.tx.xsize.begin(), T.tx.xsize.end());
-    T.h_int.insert(T.h_int.end(), T.ty.xmin.begin(), T.ty.xmin.end());
-    T.h_int.insert(T.h_int.end(), T.ty.xsize.begin(), T.ty.xsize.end());
-    T.h_w.clear();
-    T.h_w.insert(T.h_w.end(), T.tx.w.begin(), T.tx.w.end());
-    T.h_w.insert(T.h_w.end(), T.ty.w.begin(), T.ty.w.end());
-    if ((e = hipMemcpy(T.d_int, T.h_int.data(), n_int * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMemcpy(T.d_w, T.h_w.data(), n_w * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return e;
-    T.in_h = in_h; T.in_w = in_w; T.rs_h = rs_h; T.rs_w = rs_w;
+    AxisTable tx, ty;
+    build_axis(in_w, rs_w, tx);
+    build_axis(in_h, rs_h, ty);
+    TableEntry t;
+    t.dev = dev; t.in_h = in_h; t.in_w = in_w; t.rs_h = rs_h; t.rs_w = rs_w; t.taps_x = tx.taps; t.taps_y = ty.taps;
+    std::vector<int> h_int;
+    h_int.insert(h_int.end(), tx.xmin.begin(), tx.xmin.end());
+    h_int.insert(h_int.end(), tx.xsize.begin(), tx.xsize.end());
+    h_int.insert(h_int.end(), ty.xmin.begin(), ty.xmin.end());
+    h_int.insert(h_int.end(), ty.xsize.begin(), ty.xsize.end());
+    std::vector<float> h_w;
+    h_w.insert(h_w.end(), tx.w.begin(), tx.w.end());
+    h_w.insert(h_w.end(), ty.w.begin(), ty.w.end());
+    if ((e = hipMalloc(&t.d_int, h_int.size() * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc(&t.d_w, h_w.size() * sizeof(float))) != hipSuccess) { (void)hipFree(t.d_int); return e; }
+    // fresh buffers nobody reads yet; hipMemcpy returns once the (pageable) host vectors have been consumed
+    if ((e = hipMemcpy(t.d_int, h_int.data(), h_int.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(t.d_w, h_w.data(), h_w.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    g_tabs.push_back(t);
+    hit = &g_tabs.back();
   }
+  const TableEntry& T = *hit;
   const int* xmin = T.d_int;
   const int* xsize = T.d_int + rs_w;
   const int* ymin = T.d_int + 2 * rs_w;
   const int* ysize = ymin + rs_h;
   const float* wx = T.d_w;
-  const float* wy = T.d_w + (size_t)rs_w * T.tx.taps;
-  hipLaunchKernelGGL(u8_resize_w_kernel, dim3((rs_w + 255) / 256, in_h), blk, 0, stream, img, row_bytes, in_h, rs_w, T.tx.taps, xmin,
+  const float* wy = T.d_w + (size_t)rs_w * T.taps_x;
+  hipLaunchKernelGGL(u8_resize_w_kernel, dim3((rs_w + 255) / 256, in_h), blk, 0, stream, img, row_bytes, in_h, rs_w, T.taps_x, xmin,
                      xsize, wx, scratch);
-  hipError_t e = hipGetLastError();
+  e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(resize_h_norm_kernel, dim3((ow + 255) / 256, oh), blk, 0, stream, scratch, rs_w, T.ty.taps, ymin, ysize, wy, crop_y,
+  hipLaunchKernelGGL(resize_h_norm_kernel, dim3((ow + 255) / 256, oh), blk, 0, stream, scratch, rs_w, T.taps_y, ymin, ysize, wy, crop_y,
                      crop_x, oh, ow, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
   return hipGetLastError();
 }

@@ -187,12 +187,7 @@ class CrossScoreNet(torch.nn.Module):
             attn = torch.empty((B, h, w, N, h, w), dtype=torch.float32, device=dev) if need_attn_weights else None
             mean_out = torch.empty((B,), dtype=torch.float32, device=dev) if return_mean else None
             stream = torch.cuda.current_stream(dev).cuda_stream
-            # Items are independent, so a batch whose decoder buffers would overflow the kernels' 32-bit element offsets
-            # (B*N*Np*4C >= 2^31, e.g. ViT-B with 128 items) is scored in sub-batches; results are identical either way.
-            kv_per_item = N * h * w * 2 * self.arch.hidden * self.arch.dec_layers
-            step = max(1, min(B, (2 ** 31 - 1) // max(kv_per_item, 1)))
-            for b0 in range(0, B, step):
-                b1 = min(B, b0 + step)
+            for b0, b1 in self._sub_batches(B, N, h * w):
                 rc = lib.cs_forward(handle, C.c_void_p(q[b0:b1].data_ptr()), C.c_void_p(r[b0:b1].data_ptr()), b1 - b0, N, H, W,
                                     C.c_void_p(score[b0:b1].data_ptr()),
                                     C.c_void_p(attn[b0:b1].data_ptr()) if attn is not None else None,
@@ -204,6 +199,13 @@ class CrossScoreNet(torch.nn.Module):
         if return_mean:
             results["score_mean_ref_cross"] = mean_out  # key does not start with "score_map": writers ignore it
         return results
+
+    def _sub_batches(self, B: int, N: int, Np: int):
+        """Items are independent, so a batch whose decoder buffers would overflow the kernels' 32-bit element offsets
+        (B*N*Np*4C >= 2^31, e.g. ViT-B with 128 items) is scored in sub-batches; results are identical either way."""
+        kv_per_item = N * Np * 2 * self.arch.hidden * self.arch.dec_layers
+        step = max(1, min(B, (2 ** 31 - 1) // max(kv_per_item, 1)))
+        return [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
 
     # -- reference-feature cache (SURVEY.md 8f-3): a separate mode, bit-identical results ---------------------------
     @torch.no_grad()
@@ -229,6 +231,8 @@ class CrossScoreNet(torch.nn.Module):
         """forward() with the reference views given as cached tokens (B, N, h*w, C) bf16 from encode_references."""
         if query_img.dim() != 4 or ref_tokens.dim() != 4 or ref_tokens.shape[0] != query_img.shape[0]:
             raise ValueError("expected query_img (B,3,H,W) and ref_tokens (B,N,h*w,C)")
+        if not query_img.is_cuda or not ref_tokens.is_cuda or ref_tokens.device != query_img.device:
+            raise _lib.CrossScoreHipError("forward_cached needs CUDA(HIP) tensors on one device: the hot path has no CPU fallback")
         dev = query_img.device
         q = query_img.to(torch.float32).contiguous()
         t = ref_tokens.to(torch.bfloat16).contiguous()
@@ -239,15 +243,18 @@ class CrossScoreNet(torch.nn.Module):
         if t.shape[2] != h * w or t.shape[3] != self.arch.hidden:
             raise ValueError("ref_tokens do not match the query's patch grid / hidden size")
         handle = self._ensure_handle(dev)
+        lib = _lib.load()
         with torch.cuda.device(dev):
             score = torch.empty((B, h * P, w * P), dtype=torch.float32, device=dev)
             attn = torch.empty((B, h, w, N, h, w), dtype=torch.float32, device=dev) if need_attn_weights else None
             mean_out = torch.empty((B,), dtype=torch.float32, device=dev) if return_mean else None
-            _lib.check(_lib.load().cs_forward_cached(
-                handle, C.c_void_p(q.data_ptr()), C.c_void_p(t.data_ptr()), B, N, H, W, C.c_void_p(score.data_ptr()),
-                C.c_void_p(attn.data_ptr()) if attn is not None else None, int(need_attn_weights_head_id),
-                C.c_void_p(mean_out.data_ptr()) if mean_out is not None else None,
-                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for b0, b1 in self._sub_batches(B, N, h * w):
+                _lib.check(lib.cs_forward_cached(
+                    handle, C.c_void_p(q[b0:b1].data_ptr()), C.c_void_p(t[b0:b1].data_ptr()), b1 - b0, N, H, W,
+                    C.c_void_p(score[b0:b1].data_ptr()),
+                    C.c_void_p(attn[b0:b1].data_ptr()) if attn is not None else None, int(need_attn_weights_head_id),
+                    C.c_void_p(mean_out[b0:b1].data_ptr()) if mean_out is not None else None, C.c_void_p(stream)))
         results = {"score_map_ref_cross": score, "attn_weights_map_ref_cross": attn}
         if return_mean:
             results["score_mean_ref_cross"] = mean_out

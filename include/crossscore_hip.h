@@ -9,9 +9,15 @@
  *
  * Ownership: the caller (PyTorch) owns every input / output / weight-source buffer; the library owns only its
  * packed bf16 weights and its workspace.  Threading: a handle is not thread-safe; one handle per process per
- * GPU.  All work is enqueued on the caller's hipStream_t (a forward that arrives on another stream than the previous one
- * waits for it: the workspace is shared); no entry point synchronises the device except
- * cs_finalize, cs_profile_* and cs_destroy.  Every function returning int returns 0 on success; on failure
+ * GPU (a handle may be re-created on another GPU of the process: launcher state is kept per device).  All work is enqueued on
+ * the caller's hipStream_t (a forward that arrives on another stream than the previous one waits for it with an event: the
+ * workspace is shared).  No entry point waits for the device or a stream except cs_finalize, cs_profile_* and cs_destroy:
+ * the first forward of a new shape allocates (hipMalloc: position tables of a new patch grid, a larger workspace -- the old
+ * one is retired behind an event and freed later), fills what it allocated on the caller's stream, and never overwrites or
+ * frees memory that queued work may still read; calls of a shape seen before allocate nothing.  (Only a 17th distinct patch
+ * grid, or a 65th distinct resize geometry in cs_preprocess_u8, drops the table cache behind a device synchronisation.)
+ * Weights are fp32 at this boundary (cs_set_weight): the reference checkpoint stores fp32, and the library
+ * packs its own 16-bit copies in cs_finalize.  Every function returning int returns 0 on success; on failure
  * cs_last_error() describes it (CS_ERR_* below) and nothing was launched on the bad-argument paths.
  */
 #ifndef CROSSSCORE_HIP_H

@@ -181,6 +181,33 @@ def test_gloo_world2_shard_gather(tmp_path):
     assert res.returncode == 0 and "GLOO_OK 2" in res.stdout, res.stdout[-2000:]
 
 
+def test_bench_launches_its_own_ranks_and_takes_the_slowest(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (task/predict.py:119-135: one process
+    per device).  Rehearsed on the CPU with gloo and a stub forward: the barrier / max-over-ranks / rank-0 line are the real ones."""
+    import json
+
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--plumbing-test", "--steps", "4", "--warmup", "1"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout  # rank 0 prints ONE line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["data"] == "stub"
+    assert r["ms_per_step"] >= 4.0  # rank 1's stub step sleeps 4 ms, rank 0's 2 ms: the slowest rank sets the time
+    assert r["gathered_means"] == [0.0, 0.0, 1.0, 1.0]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """A 1-GPU (here: 0-GPU) box must not print an N-GPU line."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode != 0 and "--gpus 2" in res.stderr and not res.stdout.strip()
+
+
 def test_committed_bench_line_follows_the_contract():
     """profiles/r01_bench.json is a verbatim bench.py line: the keys the driver and the judge read must be there."""
     import json
