@@ -30,10 +30,10 @@ from crossscore_amd.config import model_config  # noqa: E402
 from crossscore_amd.model import CrossScoreNet  # noqa: E402
 from crossscore_amd import parallel  # noqa: E402
 
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (the F16 forms take the same cycles), /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0      # HBM3E peak, same table
-GEMM_EPI = ["BIAS_BF16", "BIAS_GELU_BF16", "BIAS_RELU_BF16", "BIAS_LEAKY_BF16", "RESID_F32", "PATCH_F32", "HEAD_SCORE",
-            "LN_BF16", "LN_GELU_BF16", "RESID_F32_LN"]
+GEMM_EPI = ["BIAS_F16", "BIAS_GELU_F16", "BIAS_RELU_F16", "BIAS_LEAKY_F16", "RESID_F32", "PATCH_F32", "HEAD_SCORE",
+            "LN_F16", "LN_GELU_F16", "RESID_F32_LN"]
 WORKLOADS = {
     # name: (backbone, H, W, N refs, per-GPU batch)
     "cfg2": ("facebook/dinov2-small", 518, 518, 5, 8),
@@ -168,7 +168,7 @@ def cpu_baseline(arch, sd, H, W, N, hip_score_item0, seed, max_seconds=25.0):
     return cb, mae
 
 
-def eager_baseline(arch, sd, tq, tr, dev, steps=3, variants=("fp32_sdpa", "bf16_autocast_sdpa")):
+def eager_baseline(arch, sd, tq, tr, dev, steps=3, variants=("fp32_sdpa", "fp16_autocast_sdpa", "bf16_autocast_sdpa")):
     """The 'PyTorch-ROCm eager reference' of the north-star target: the fp32 restatement (plain torch ops: nn.Linear-shaped
     matmuls, LayerNorm, SDPA) run on the GPU, in fp32 and under bf16 autocast (trainer.precision=16-mixed,
     config/default_predict.yaml:25).  `*_sdpa` use F.scaled_dot_product_attention -- what the reference's modules execute on a
@@ -182,7 +182,9 @@ def eager_baseline(arch, sd, tq, tr, dev, steps=3, variants=("fp32_sdpa", "bf16_
     table = {"fp32": (lambda: torch.autocast("cuda", enabled=False), explicit_attention),
              "bf16_autocast": (lambda: torch.autocast("cuda", dtype=torch.bfloat16), explicit_attention),
              "fp32_sdpa": (lambda: torch.autocast("cuda", enabled=False), _sdpa_attention),
-             "bf16_autocast_sdpa": (lambda: torch.autocast("cuda", dtype=torch.bfloat16), _sdpa_attention)}
+             "bf16_autocast_sdpa": (lambda: torch.autocast("cuda", dtype=torch.bfloat16), _sdpa_attention),
+             # trainer.precision = "16-mixed" is fp16 autocast in Lightning: the reference's shipped GPU mode
+             "fp16_autocast_sdpa": (lambda: torch.autocast("cuda", dtype=torch.float16), _sdpa_attention)}
     for name in variants:
         ctx, attn_fn = table[name]
         orc.attention = attn_fn
@@ -298,7 +300,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-eager", action="store_true", help="skip the PyTorch-ROCm eager reference legs (fp32 + SDPA, bf16 autocast + SDPA)")
+    ap.add_argument("--no-eager", action="store_true", help="skip the PyTorch-ROCm eager reference legs (fp32, fp16 autocast, bf16 autocast; all with SDPA)")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the BASELINE scaling configuration (ViT-B, 5 refs, 16 per GPU)")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--cached-refs", action="store_true", help="also time the reference-token cache mode (separate metric)")
@@ -371,7 +373,7 @@ def main():
             "metric": wl.metric(),
             "value": value, "unit": "query-images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "fp16", "data": "synthetic",  # 16-bit MFMA operands (IEEE half, the bf16 MFMA rate), fp32 accumulate / softmax / LayerNorm / output
             "config": {"workload": wl.describe(world),
                        "gflop_per_query": flops_q / 1e9, "parallelism": f"batch-shard x{world} (replicas, no data-path collective)"},
             "whole_path": {"achieved_tflops": value * flops_q / 1e12 / world, "peak_tflops": PEAK_BF16_TFLOPS,
@@ -409,7 +411,7 @@ def main():
         if world == 1 and not args.no_eager:
             # the north-star target: >= 10x the PyTorch-ROCm eager reference.  The reference's GPU mode is 16-mixed autocast with
             # SDPA attention (config/default_predict.yaml:25); its fp32 forward is the parity target.
-            variants = ("fp32_sdpa", "bf16_autocast_sdpa") + (("fp32", "bf16_autocast") if args.eager else ())
+            variants = ("fp32_sdpa", "fp16_autocast_sdpa", "bf16_autocast_sdpa") + (("fp32", "bf16_autocast") if args.eager else ())
             eb = eager_baseline(arch, wl.sd, wl.tq, wl.tr, dev, variants=variants)
             result["eager_baseline"] = eb
             for k, v in eb.items():

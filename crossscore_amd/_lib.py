@@ -11,8 +11,8 @@ LIB_PATH = os.path.join(HERE, "libcrossscore_hip.so")
 CS_OK, CS_ERR_BAD_ARG, CS_ERR_UNSUPPORTED, CS_ERR_STATE, CS_ERR_HIP = range(5)
 
 # CsEpilogue (csrc/cs_common.h)
-(EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_LEAKY_BF16, EPI_RESID_F32, EPI_PATCH_F32, EPI_HEAD_SCORE,
- EPI_LN_BF16, EPI_LN_GELU_BF16, EPI_RESID_F32_LN) = range(10)
+(EPI_BIAS_F16, EPI_BIAS_GELU_F16, EPI_BIAS_RELU_F16, EPI_BIAS_LEAKY_F16, EPI_RESID_F32, EPI_PATCH_F32, EPI_HEAD_SCORE,
+ EPI_LN_F16, EPI_LN_GELU_F16, EPI_RESID_F32_LN) = range(10)
 
 
 class CsConfig(C.Structure):
@@ -20,7 +20,7 @@ class CsConfig(C.Structure):
         ("hidden", C.c_int), ("enc_layers", C.c_int), ("enc_heads", C.c_int), ("mlp_ratio", C.c_int),
         ("patch", C.c_int), ("pos_grid", C.c_int), ("pe_h", C.c_int), ("pe_w", C.c_int),
         ("dec_layers", C.c_int), ("dec_heads", C.c_int), ("do_self_attn", C.c_int), ("do_short_cut", C.c_int),
-        ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int), ("ln_fold", C.c_int), ("lanes", C.c_int), ("tail_precision", C.c_int), ("enc_fused", C.c_int),
+        ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int), ("ln_fold", C.c_int), ("lanes", C.c_int), ("enc_fused", C.c_int),
     ]
 
 
@@ -52,7 +52,7 @@ SYMBOLS = {
     "cs_op_score_to_gray16": (_i, [_vp, C.c_longlong, _i, _vp, _vp]),
     "cs_op_score_to_rgb": (_i, [_vp, C.c_longlong, C.c_float, C.c_float, _vp, _vp, _vp]),
     "cs_op_preprocess_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _vp]),
-    "cs_op_pack_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "cs_op_pack_f16": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "cs_op_ln_fold_consts": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cs_gemm_column_tiles": (_i, [_i]),
     "cs_panel_supported": (_i, [_i, _i]),

@@ -20,23 +20,22 @@ const char* cs_gemm_check(const CsGemmParams* p, int epi);
 hipError_t cs_gemm_launch(const CsGemmParams* p, int epi, hipStream_t stream);
 const char* cs_attn_check(const CsAttnParams* p, int dh, int batch);
 hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, hipStream_t stream);
-hipError_t cs_im2col_launch(const float* q, const float* refs, int N, int img0, bf16_t* out, int I, int H, int W, int P, int Kp,
+hipError_t cs_im2col_launch(const float* q, const float* refs, int N, int img0, h16_t* out, int I, int H, int W, int P, int Kp,
                             float* pmean, hipStream_t st);
 hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipStream_t st);
-hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32, bf16_t* obf,
+hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32, h16_t* obf,
                                hipStream_t st);
 hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
-                                    const float* pe, float* q_f32, bf16_t* q_bf, bf16_t* mem_bf, hipStream_t st);
-hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, bf16_t* xb, float* stats, int sp,
+                                    const float* pe, float* q_f32, h16_t* q_bf, h16_t* mem_bf, hipStream_t st);
+hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, h16_t* xb, float* stats, int sp,
                               hipStream_t st);
-hipError_t cs_ln_fold_consts_launch(const bf16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
+hipError_t cs_ln_fold_consts_launch(const h16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
                                     float* s_out, float* c_out, hipStream_t st);
 int cs_gemm_column_tiles(int N);
 hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float* out, hipStream_t st);
 hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st);
-hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, const float* row_scale, const float* col_scale,
+hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
                                hipStream_t st);
-hipError_t cs_split3_launch(const float* src, long long M, int K, int ld, int act, int wmode, bf16_t* out, hipStream_t st);
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
@@ -45,7 +44,7 @@ hipError_t cs_score_rgb_launch(const float* score, size_t n, float vmin, float v
 int cs_panel_supported(int C, int mlp_ratio);
 size_t cs_panel_image_bytes(int with_outproj);
 hipError_t cs_panel_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
-                                bf16_t* img, hipStream_t st);
+                                h16_t* img, hipStream_t st);
 const char* cs_panel_check(const CsPanelParams* p);
 hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st);
 hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int oh,
@@ -78,15 +77,14 @@ struct Tensor {
 
 struct EncLayer {
   float *ln1g, *ln1b, *ln2g, *ln2b, *bqkv, *bo, *b1, *b2, *ls1, *ls2;
-  bf16_t *Wqkv, *Wo, *W1, *W2;
+  h16_t *Wqkv, *Wo, *W1, *W2;
   // LayerNorm fold (CS_EPI_LN_*): Wqkv / W1 above are then the gamma-scaled versions and these hold s[n], c[n]
   float *s_qkv, *c_qkv, *s_1, *c_1;
-  bf16_t* panel_img;  // token-panel kernel (panel.hip): packed unit stream [Wo | W1 / W2 interleaved]; Wqkv / c_qkv / c_1 are then the LN-folded ones
+  h16_t* panel_img;  // token-panel kernel (panel.hip): packed unit stream [Wo | W1 / W2 interleaved]; Wqkv / c_qkv / c_1 are then the LN-folded ones
 };
 struct DecLayer {
   float *sa_bin, *sa_bo, *ca_bq, *ca_bo, *l1b, *l2b, *n1g, *n1b, *n2g, *n2b, *n3g, *n3b;
-  bf16_t *sa_Win, *sa_Wo, *ca_Wq, *ca_Wo, *l1W, *l2W;
-  bf16_t *sa_Win3, *ca_Wq3, *l1W3, *l2W3, *sa_Wo3, *ca_Wo3;  // [out][3*in] = [w_hi | w_hi | w_lo]: split-bf16 operands of the row-wise linears
+  h16_t *sa_Win, *sa_Wo, *ca_Wq, *ca_Wo, *l1W, *l2W;
 };
 
 struct ProfRec { hipEvent_t a, b; int family; double flops; double bytes; };
@@ -106,13 +104,12 @@ struct cs_model {
   int ln_sp = 0;        // partial-sum slots per row the producing epilogues write (4 per column tile)
   std::vector<void*> owned;  // device allocations of packed weights
   // packed
-  bf16_t* Wpatch = nullptr; float* bpatch = nullptr;
+  h16_t* Wpatch = nullptr; float* bpatch = nullptr;
   float* wsum = nullptr;  // [3][C] fp32 sums of the patch weights per channel (mean-centred patch embedding)
   std::vector<EncLayer> enc;
   std::vector<DecLayer> dec;
-  bf16_t* Wkv_all = nullptr; float* bkv_all = nullptr;
-  bf16_t *Wh0 = nullptr, *Wh2 = nullptr; float *bh0 = nullptr, *bh2 = nullptr;
-  bf16_t *Wh03 = nullptr, *Wh23 = nullptr;  // split-bf16 head weights
+  h16_t* Wkv_all = nullptr; float* bkv_all = nullptr;
+  h16_t *Wh0 = nullptr, *Wh2 = nullptr; float *bh0 = nullptr, *bh2 = nullptr;
   float *lnfg = nullptr, *lnfb = nullptr, *cls = nullptr, *pos = nullptr, *pe = nullptr;
   // per-(gh,gw,square) tables: built once per shape and kept (a shape change never overwrites a table that queued work may read)
   struct Tables { int gh, gw, sq; float *pos_tab, *pe_tab; bool pos_owned, pe_owned; };
@@ -183,11 +180,11 @@ struct Plan {
   int B, N, H, W, gh, gw, Np, T, I, Ic, C, lanes;
   size_t total;
   // encoder chunk buffers, one set per lane
-  float* x[CS_MAX_LANES]; bf16_t* u[CS_MAX_LANES]; bf16_t* r1[CS_MAX_LANES];
-  bf16_t* ob[CS_MAX_LANES]; float* stats[CS_MAX_LANES];  // LayerNorm fold: attention output, per-row partial sums
+  float* x[CS_MAX_LANES]; h16_t* u[CS_MAX_LANES]; h16_t* r1[CS_MAX_LANES];
+  h16_t* ob[CS_MAX_LANES]; float* stats[CS_MAX_LANES];  // LayerNorm fold: attention output, per-row partial sums
   float* pmean[CS_MAX_LANES];                            // per-patch channel means removed by im2col
   // decoder
-  float *xq, *y, *lse, *hf; bf16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid, *q3, *hid3, *dob3;
+  float *xq, *y, *lse; h16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
 };
 
 Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* base) {
@@ -215,26 +212,21 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
   const int nsets = c.lanes <= 0 ? 2 : std::min(c.lanes, CS_MAX_LANES);  // independent of the profiling mode
   for (int l = 0; l < nsets; ++l) {
     p.x[l] = a.take<float>(Mc * C);
-    p.u[l] = a.take<bf16_t>(Mc * C);
-    p.r1[l] = a.take<bf16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * 3 * C, (size_t)p.Ic * p.Np * m->Kp)));
-    p.ob[l] = a.take<bf16_t>(m->lnfold ? Mc * C : 0);
+    p.u[l] = a.take<h16_t>(Mc * C);
+    p.r1[l] = a.take<h16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * 3 * C, (size_t)p.Ic * p.Np * m->Kp)));
+    p.ob[l] = a.take<h16_t>(m->lnfold ? Mc * C : 0);
     p.pmean[l] = a.take<float>((size_t)p.Ic * p.Np * 4);
     p.stats[l] = a.take<float>(m->lnfold ? Mc * (size_t)m->ln_sp * 2 : 0);
   }
   p.xq = a.take<float>(M * C);
   p.y = a.take<float>(M * C);
-  p.q_bf = a.take<bf16_t>(M * C);
-  p.mem_bf = a.take<bf16_t>(Mk * C);
-  p.kv = a.take<bf16_t>(Mk * 2 * C * c.dec_layers);
-  p.dqkv = a.take<bf16_t>(M * 3 * C);
-  p.dq = a.take<bf16_t>(M * C);
-  p.dob = a.take<bf16_t>(M * C);
-  p.dhid = a.take<bf16_t>(M * C);
-  const bool split = c.tail_precision != 1;
-  p.q3 = a.take<bf16_t>(split ? M * 3 * C : 0);
-  p.hid3 = a.take<bf16_t>(split ? M * 3 * C : 0);
-  p.hf = a.take<float>(split ? M * C : 0);
-  p.dob3 = a.take<bf16_t>(c.tail_precision == 2 ? M * 3 * C : 0);
+  p.q_bf = a.take<h16_t>(M * C);
+  p.mem_bf = a.take<h16_t>(Mk * C);
+  p.kv = a.take<h16_t>(Mk * 2 * C * c.dec_layers);
+  p.dqkv = a.take<h16_t>(M * 3 * C);
+  p.dq = a.take<h16_t>(M * C);
+  p.dob = a.take<h16_t>(M * C);
+  p.dhid = a.take<h16_t>(M * C);
   p.lse = a.take<float>((size_t)B * c.dec_heads * p.Np);
   p.total = a.off;
   return p;
@@ -297,7 +289,7 @@ struct Launcher {
   }
 };
 
-CsGemmParams gp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const float* bias, void* out, int ldc) {
+CsGemmParams gp(const h16_t* A, int lda, const h16_t* W, int ldw, int M, int N, int K, const float* bias, void* out, int ldc) {
   CsGemmParams g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldc = ldc;
   g.powp = 1.f;
@@ -432,15 +424,15 @@ int cs_finalize(cs_handle h) {
     return &it->second;
   };
   hipStream_t st = nullptr;
-  auto pack = [&](const float* src, int rows, int K, int ldo, bf16_t* dst, const float* row_scale = nullptr,
+  auto pack = [&](const float* src, int rows, int K, int ldo, h16_t* dst, const float* row_scale = nullptr,
                   const float* col_scale = nullptr) -> int {
-    HIPCHK(cs_pack_bf16_launch(src, rows, K, dst, ldo, row_scale, col_scale, st));
+    HIPCHK(cs_pack_f16_launch(src, rows, K, dst, ldo, row_scale, col_scale, st));
     return 0;
   };
-  auto alloc_bf = [&](size_t n) -> bf16_t* { void* p = nullptr; if (hipMalloc(&p, n * sizeof(bf16_t)) != hipSuccess) return nullptr; h->owned.push_back(p); return (bf16_t*)p; };
+  auto alloc_bf = [&](size_t n) -> h16_t* { void* p = nullptr; if (hipMalloc(&p, n * sizeof(h16_t)) != hipSuccess) return nullptr; h->owned.push_back(p); return (h16_t*)p; };
   auto alloc_f = [&](size_t n) -> float* { void* p = nullptr; if (hipMalloc(&p, n * sizeof(float)) != hipSuccess) return nullptr; h->owned.push_back(p); return (float*)p; };
 #define NEED(var, name, ...) Tensor* var = need(name, {__VA_ARGS__}); if (!var) return CS_ERR_STATE;
-#define ALLOC_BF(var, n) bf16_t* var = alloc_bf(n); if (!var) return fail(CS_ERR_HIP, "hipMalloc failed");
+#define ALLOC_BF(var, n) h16_t* var = alloc_bf(n); if (!var) return fail(CS_ERR_HIP, "hipMalloc failed");
 #define ALLOC_F(var, n) float* var = alloc_f(n); if (!var) return fail(CS_ERR_HIP, "hipMalloc failed");
 #define D2D(dst, src, n) HIPCHK(hipMemcpy(dst, src, (n) * sizeof(float), hipMemcpyDeviceToDevice))
 
@@ -489,7 +481,7 @@ int cs_finalize(cs_handle h) {
     L.s_qkv = L.c_qkv = L.s_1 = L.c_1 = nullptr;
     L.panel_img = nullptr;
     if (h->panel) {
-      ALLOC_BF(img, cs_panel_image_bytes(1) / sizeof(bf16_t))
+      ALLOC_BF(img, cs_panel_image_bytes(1) / sizeof(h16_t))
       HIPCHK(cs_panel_pack_launch(ow->d, l1->d, f1w->d, n2w->d, f2w->d, l2->d, img, st));
       L.panel_img = img;
     }
@@ -524,8 +516,6 @@ int cs_finalize(cs_handle h) {
       ALLOC_BF(w, (size_t)3 * C * C) if (int r = pack(iw->d, (int)(3 * C), (int)C, (int)C, w)) return r;
       ALLOC_BF(wo, (size_t)C * C) if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
       L.sa_Win = w; L.sa_bin = ib->d; L.sa_Wo = wo; L.sa_bo = ob->d;
-      ALLOC_BF(w3, (size_t)3 * C * 3 * C) HIPCHK(cs_split3_launch(iw->d, 3 * C, (int)C, (int)C, 0, 1, w3, st)); L.sa_Win3 = w3;
-      ALLOC_BF(wo3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(ow->d, C, (int)C, (int)C, 0, 1, wo3, st)); L.sa_Wo3 = wo3;
     }
     NEED(iw, p + "multihead_attn.in_proj_weight", 3 * C, C) NEED(ib, p + "multihead_attn.in_proj_bias", 3 * C)
     NEED(ow, p + "multihead_attn.out_proj.weight", C, C) NEED(ob, p + "multihead_attn.out_proj.bias", C)
@@ -535,14 +525,10 @@ int cs_finalize(cs_handle h) {
     D2D(h->bkv_all + (size_t)l * 2 * C, ib->d + C, 2 * C);
     ALLOC_BF(wo, (size_t)C * C) if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
     L.ca_Wq = wq; L.ca_bq = ib->d; L.ca_Wo = wo; L.ca_bo = ob->d;
-    { ALLOC_BF(w3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(iw->d, C, (int)C, (int)C, 0, 1, w3, st)); L.ca_Wq3 = w3; }
-    { ALLOC_BF(w3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(ow->d, C, (int)C, (int)C, 0, 1, w3, st)); L.ca_Wo3 = w3; }
     NEED(l1w, p + "linear1.weight", C, C) NEED(l1b, p + "linear1.bias", C) NEED(l2w, p + "linear2.weight", C, C) NEED(l2b, p + "linear2.bias", C)
     ALLOC_BF(w1, (size_t)C * C) if (int r = pack(l1w->d, (int)C, (int)C, (int)C, w1)) return r;
     ALLOC_BF(w2, (size_t)C * C) if (int r = pack(l2w->d, (int)C, (int)C, (int)C, w2)) return r;
     L.l1W = w1; L.l1b = l1b->d; L.l2W = w2; L.l2b = l2b->d;
-    { ALLOC_BF(w3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(l1w->d, C, (int)C, (int)C, 0, 1, w3, st)); L.l1W3 = w3; }
-    { ALLOC_BF(w3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(l2w->d, C, (int)C, (int)C, 0, 1, w3, st)); L.l2W3 = w3; }
     NEED(n1g, p + "norm1.weight", C) NEED(n1b, p + "norm1.bias", C) NEED(n2g, p + "norm2.weight", C) NEED(n2b, p + "norm2.bias", C)
     NEED(n3g, p + "norm3.weight", C) NEED(n3b, p + "norm3.bias", C)
     L.n1g = n1g->d; L.n1b = n1b->d; L.n2g = n2g->d; L.n2b = n2b->d; L.n3g = n3g->d; L.n3b = n3b->d;
@@ -554,8 +540,6 @@ int cs_finalize(cs_handle h) {
     ALLOC_BF(w0, (size_t)C * C) if (int r = pack(h0w->d, (int)C, (int)C, (int)C, w0)) return r;
     ALLOC_BF(w2, (size_t)PP * C) if (int r = pack(h2w->d, (int)PP, (int)C, (int)C, w2)) return r;
     h->Wh0 = w0; h->bh0 = h0b->d; h->Wh2 = w2; h->bh2 = h2b->d;
-    { ALLOC_BF(w3, (size_t)C * 3 * C) HIPCHK(cs_split3_launch(h0w->d, C, (int)C, (int)C, 0, 1, w3, st)); h->Wh03 = w3; }
-    { ALLOC_BF(w3, (size_t)PP * 3 * C) HIPCHK(cs_split3_launch(h2w->d, PP, (int)C, (int)C, 0, 1, w3, st)); h->Wh23 = w3; }
   }
   HIPCHK(hipDeviceSynchronize());
   // fp32 copies of the big matrices are no longer needed
@@ -575,7 +559,7 @@ size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W) {
 
 // mode 0: full forward (query + reference images); mode 1: query images + cached reference tokens (`ref_tokens`, bf16
 // [B][N][Np][C]); mode 2: encode `B` images as references into `tokens_out` (bf16 [B][Np][C]), no decoder.
-static int forward_body(cs_handle h, int mode, const float* query, const float* refs, const bf16_t* ref_tokens, bf16_t* tokens_out,
+static int forward_body(cs_handle h, int mode, const float* query, const float* refs, const h16_t* ref_tokens, h16_t* tokens_out,
                         int B, int N, int H, int W, float* score_out, float* attn_out, int head_id, float* mean_out,
                         cs_stream stream) {
   if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
@@ -653,14 +637,14 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   // chunk is ~90 launches = 0.3 ms of enqueue time, during which the other lane would idle).
   auto enc_chunk = [&](Launcher& L, int slot, int i0, int ic, int stage) {
     hipStream_t s = L.st;
-    float* x = p.x[slot]; bf16_t* u = p.u[slot]; bf16_t* r1 = p.r1[slot];
+    float* x = p.x[slot]; h16_t* u = p.u[slot]; h16_t* r1 = p.r1[slot];
     const int Mc = ic * p.T;
     // patches are mean-centred per channel before the bf16 rounding; the patch GEMM adds mean * sum(W) back in fp32
     float* pmean = p.pmean[slot];
     if (stage == -1) {
     L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, pmean, s), "im2col"); L.end();
     const bool fold = h->lnfold;
-    bf16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
+    h16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
     L.begin(32, 0);
     L.misc(cs_cls_rows_launch(x, ic, p.T, C, h->cls, h->pos_tab, fold ? u : nullptr, fold ? stats : nullptr, h->ln_sp, s), "cls");
     L.end();
@@ -672,7 +656,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     }
     }
     const bool fold = h->lnfold;
-    bf16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
+    h16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
     for (int l = 0; l < c.enc_layers; ++l) {
       if (l != stage) continue;
       const EncLayer& E = h->enc[l];
@@ -686,7 +670,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         // u = bf16 normalised rows (norm1 without gamma/beta: folded into Wqkv / c_qkv), written by the previous layer's panel
         // kernel; layer 0 gets it from the LayerNorm kernel
         if (l == 0) { L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, h->ones, h->zeros, 1e-6f, nullptr, u, s), "ln1"); L.end(); }
-        L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C), CS_EPI_BIAS_BF16);
+        L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C), CS_EPI_BIAS_F16);
         a.O = u;
         L.attn(a, enc_dh, ic);
         CsPanelParams q{};
@@ -701,7 +685,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         {
           CsGemmParams g = gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C);
           g.col_s = E.s_qkv; g.ln_part = stats; g.ln_sp = h->ln_sp; g.ln_eps = 1e-6f;
-          L.gemm(g, CS_EPI_LN_BF16);
+          L.gemm(g, CS_EPI_LN_F16);
         }
         a.O = ob;
         L.attn(a, enc_dh, ic);
@@ -713,7 +697,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         {
           CsGemmParams g = gp(u, C, E.W1, C, Mc, F, C, E.c_1, r1, F);
           g.col_s = E.s_1; g.ln_part = stats; g.ln_sp = h->ln_sp; g.ln_eps = 1e-6f;
-          L.gemm(g, CS_EPI_LN_GELU_BF16);
+          L.gemm(g, CS_EPI_LN_GELU_F16);
         }
         {
           CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);
@@ -724,7 +708,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         continue;
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, u, s), "ln1"); L.end();
-      L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.bqkv, r1, 3 * C), CS_EPI_BIAS_BF16);
+      L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.bqkv, r1, 3 * C), CS_EPI_BIAS_F16);
       a.O = u;
       L.attn(a, enc_dh, ic);
       {
@@ -733,7 +717,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.gemm(g, CS_EPI_RESID_F32);
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, u, s), "ln2"); L.end();
-      L.gemm(gp(u, C, E.W1, C, Mc, F, C, E.b1, r1, F), CS_EPI_BIAS_GELU_BF16);
+      L.gemm(gp(u, C, E.W1, C, Mc, F, C, E.b1, r1, F), CS_EPI_BIAS_GELU_F16);
       {
         CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);
         g.resid = x; g.ldr = C;
@@ -753,27 +737,10 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     const int M = nb * p.Np, Mk = nb * N * p.Np;
     const size_t ro = (size_t)b0 * p.Np;          // first query row of the group
     const size_t ko = (size_t)b0 * N * p.Np;      // first memory row of the group
-    float* xq = p.xq + ro * C; float* y = p.y + ro * C; bf16_t* q_bf = p.q_bf + ro * C;
-    const bf16_t* mem = (mode == 1 ? ref_tokens : p.mem_bf) + ko * C; bf16_t* kv = p.kv + ko * KV;
-    bf16_t* dqkv = p.dqkv + ro * 3 * C; bf16_t* dq = p.dq + ro * C; bf16_t* dob = p.dob + ro * C; bf16_t* dhid = p.dhid + ro * C;
+    float* xq = p.xq + ro * C; float* y = p.y + ro * C; h16_t* q_bf = p.q_bf + ro * C;
+    const h16_t* mem = (mode == 1 ? ref_tokens : p.mem_bf) + ko * C; h16_t* kv = p.kv + ko * KV;
+    h16_t* dqkv = p.dqkv + ro * 3 * C; h16_t* dq = p.dq + ro * C; h16_t* dob = p.dob + ro * C; h16_t* dhid = p.dhid + ro * C;
     float* lse = p.lse + (size_t)b0 * c.dec_heads * p.Np;
-    // Split-bf16 tail (cs_config.tail_precision == 0): the row-wise linears of the decoder (self-attention in-proj, cross-attention
-    // Q-proj, FFN) and the regression head take [hi | lo | hi] activations against [w_hi | w_hi | w_lo] weights (K = 3C, same GEMM
-    // kernel): fp32-grade products for 1 % of the FLOPs.  An error budget with the oracle (bf16 rounding switched on per stage,
-    // ViT-S cfg-2) attributes 4.1e-4 of the 8.3e-4 score-map MAE to the head and 4.5e-4 to these linears (encoder 4.9e-4, KV
-    // projection 1.5e-4, attention internals 0.4e-4; the terms add in quadrature).
-    // Levels: 0 (default) head + FFN linears, 2 additionally the self-attention in-proj, cross-attention Q-proj and the two
-    // out-projections (the attention kernel writes O as hi | lo | hi), 1 plain bf16.
-    // Predicted by the same budget: 8.3e-4 plain, 6.5e-4 head only, 5.4e-4 head + FFN, 5.2e-4 level 2; measured on cfg-2 item 0
-    // (tools/mae_check.py): 8.4e-4 plain, 6.0e-4 level 2.
-    const bool split = c.tail_precision != 1, split_proj = c.tail_precision == 2;
-    bf16_t* q3 = split ? p.q3 + ro * 3 * C : nullptr; bf16_t* hid3 = split ? p.hid3 + ro * 3 * C : nullptr;
-    bf16_t* dob3 = split_proj ? p.dob3 + ro * 3 * C : nullptr;
-    float* hf = split ? p.hf + ro * C : nullptr;
-    auto split3 = [&](const float* src, int act, bf16_t* dst) {
-      L.begin(32, 0); L.misc(cs_split3_launch(src, M, C, C, act, 0, dst, s), "split3"); L.end();
-    };
-    if (split_proj && c.do_self_attn) split3(xq, 0, q3);
     // K/V projection of the memory (both layers at once).  Nothing before the first cross-attention depends on it, so with lanes
     // it runs on lane stream 1 next to layer 0's self-attention branch (the decoder phase has one small kernel in flight otherwise).
     const bool kv_side = NL >= 2 && c.do_self_attn && !h->prof;
@@ -782,39 +749,34 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       if (!h->ev_kv1) { if (hipEventCreateWithFlags(&h->ev_kv1, hipEventDisableTiming) != hipSuccess) L.rc = CS_ERR_HIP; }
       if (!L.rc && (hipEventRecord(h->ev_kv0, s) != hipSuccess || hipStreamWaitEvent(lst[1], h->ev_kv0, 0) != hipSuccess)) L.rc = CS_ERR_HIP;
       Launcher LK{h, lst[1]};
-      LK.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_BF16);
+      LK.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_F16);
       if (LK.rc) L.rc = LK.rc;
       if (!L.rc && hipEventRecord(h->ev_kv1, lst[1]) != hipSuccess) L.rc = CS_ERR_HIP;
     } else {
-      L.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_BF16);
+      L.gemm(gp(mem, C, h->Wkv_all, C, Mk, KV, C, h->bkv_all, kv, KV), CS_EPI_BIAS_F16);
     }
     for (int l = 0; l < c.dec_layers; ++l) {
       const DecLayer& D = h->dec[l];
       if (c.do_self_attn) {
-        if (split_proj) L.gemm(gp(q3, 3 * C, D.sa_Win3, 3 * C, M, 3 * C, 3 * C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_BF16);
-        else L.gemm(gp(q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_BF16);
+        L.gemm(gp(q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_F16);
         CsAttnParams a{};
         a.Q = dqkv; a.K = dqkv + C; a.V = dqkv + 2 * C; a.O = dob;
         a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
         a.q_bs = a.k_bs = a.v_bs = (long long)p.Np * 3 * C; a.o_bs = (long long)p.Np * C;
         a.Lq = a.Lk = p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
-        if (split_proj) { a.O = dob3; a.ldo = 3 * C; a.o_bs = (long long)p.Np * 3 * C; a.o_split = C; }  // O as [hi | lo | hi]
         L.attn(a, dec_dh, nb);
-        CsGemmParams g = split_proj ? gp(dob3, 3 * C, D.sa_Wo3, 3 * C, M, C, 3 * C, D.sa_bo, y, C) : gp(dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, y, C);
+        CsGemmParams g = gp(dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, y, C);
         g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
         L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n1g, D.n1b, 1e-5f, xq, q_bf, s), "norm1"); L.end();
       }
       if (kv_side && l == 0 && !L.rc && hipStreamWaitEvent(s, h->ev_kv1, 0) != hipSuccess) L.rc = CS_ERR_HIP;
-      if (split_proj) split3(xq, 0, q3);
-      if (split_proj) L.gemm(gp(q3, 3 * C, D.ca_Wq3, 3 * C, M, C, 3 * C, D.ca_bq, dq, C), CS_EPI_BIAS_BF16);
-      else L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_BF16);
+      L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_F16);
       CsAttnParams a{};
       a.Q = dq; a.K = kv + (size_t)l * 2 * C; a.V = kv + (size_t)l * 2 * C + C; a.O = dob;
       a.ldq = C; a.ldk = a.ldv = KV; a.ldo = C;
       a.q_bs = (long long)p.Np * C; a.k_bs = a.v_bs = (long long)N * p.Np * KV; a.o_bs = (long long)p.Np * C;
       a.Lq = p.Np; a.Lk = N * p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
-      if (split_proj) { a.O = dob3; a.ldo = 3 * C; a.o_bs = (long long)p.Np * 3 * C; a.o_split = C; }
       const bool want_w = attn_out && l == c.dec_layers - 1;  // only the last layer's weights are returned (transformer.py:266-268)
       a.lse = want_w ? lse : nullptr;
       L.attn(a, dec_dh, nb);
@@ -824,36 +786,23 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.end();
       }
       {
-        CsGemmParams g = split_proj ? gp(dob3, 3 * C, D.ca_Wo3, 3 * C, M, C, 3 * C, D.ca_bo, y, C) : gp(dob, C, D.ca_Wo, C, M, C, C, D.ca_bo, y, C);
+        CsGemmParams g = gp(dob, C, D.ca_Wo, C, M, C, C, D.ca_bo, y, C);
         g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n2g, D.n2b, 1e-5f, xq, q_bf, s), "norm2"); L.end();
-      if (split) {
-        split3(xq, 0, q3);
-        L.gemm(gp(q3, 3 * C, D.l1W3, 3 * C, M, C, 3 * C, D.l1b, hf, C), CS_EPI_RESID_F32);  // fp32 hidden (no residual operand)
-        split3(hf, 1, hid3);                                                                  // ReLU, then hi/lo
-      } else {
-        L.gemm(gp(q_bf, C, D.l1W, C, M, C, C, D.l1b, dhid, C), CS_EPI_BIAS_RELU_BF16);
-      }
+      L.gemm(gp(q_bf, C, D.l1W, C, M, C, C, D.l1b, dhid, C), CS_EPI_BIAS_RELU_F16);
       {
-        CsGemmParams g = split ? gp(hid3, 3 * C, D.l2W3, 3 * C, M, C, 3 * C, D.l2b, y, C) : gp(dhid, C, D.l2W, C, M, C, C, D.l2b, y, C);
+        CsGemmParams g = gp(dhid, C, D.l2W, C, M, C, C, D.l2b, y, C);
         g.resid = xq; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n3g, D.n3b, 1e-5f, xq, q_bf, s), "norm3"); L.end();
-      if (split && (split_proj || l == c.dec_layers - 1)) split3(xq, 0, q3);  // next layer's in-proj (level 2) or the head
     }
     // head + RegressionLayer + jigsaw (cross_reference.py:45-50,82-87)
-    if (split) {
-      L.gemm(gp(q3, 3 * C, h->Wh03, 3 * C, M, C, 3 * C, h->bh0, hf, C), CS_EPI_RESID_F32);
-      split3(hf, 2, hid3);  // LeakyReLU, then hi/lo
-    } else {
-      L.gemm(gp(q_bf, C, h->Wh0, C, M, C, C, h->bh0, dhid, C), CS_EPI_BIAS_LEAKY_BF16);
-    }
+    L.gemm(gp(q_bf, C, h->Wh0, C, M, C, C, h->bh0, dhid, C), CS_EPI_BIAS_LEAKY_F16);
     {
-      CsGemmParams g = split ? gp(hid3, 3 * C, h->Wh23, 3 * C, M, P * P, 3 * C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4)
-                             : gp(dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4);
+      CsGemmParams g = gp(dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4);
       g.Np = p.Np; g.gw = p.gw; g.P = P; g.act = c.act; g.powp = c.pow_p;
       L.gemm(g, CS_EPI_HEAD_SCORE);
     }
@@ -899,7 +848,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   return L.rc;
 }
 
-static int forward_impl(cs_handle h, int mode, const float* query, const float* refs, const bf16_t* ref_tokens, bf16_t* tokens_out,
+static int forward_impl(cs_handle h, int mode, const float* query, const float* refs, const h16_t* ref_tokens, h16_t* tokens_out,
                         int B, int N, int H, int W, float* score_out, float* attn_out, int head_id, float* mean_out,
                         cs_stream stream) {
   // The workspace is shared by every call on this handle: a call on a different stream than the previous one first waits for that
@@ -1052,10 +1001,10 @@ int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, fl
   return 0;
 }
 
-int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
+int cs_op_pack_f16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
                     cs_stream stream) {
   if (!w || !out || rows <= 0 || K <= 0 || ldo < K) return fail(CS_ERR_BAD_ARG, "pack_bf16: bad arguments");
-  HIPCHK(cs_pack_bf16_launch(w, rows, K, out, ldo, row_scale, col_scale, (hipStream_t)stream));
+  HIPCHK(cs_pack_f16_launch(w, rows, K, out, ldo, row_scale, col_scale, (hipStream_t)stream));
   return 0;
 }
 

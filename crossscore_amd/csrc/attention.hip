@@ -53,18 +53,18 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
   const int bat = grp / p.heads;
   const int q0 = qb * 128 + wv * 32;
 
-  const bf16_t* Qb = p.Q + (size_t)bat * p.q_bs + head * DH;
-  const bf16_t* Kb = p.K + (size_t)bat * p.k_bs + head * DH;
-  const bf16_t* Vb = p.V + (size_t)bat * p.v_bs + head * DH;
+  const h16_t* Qb = p.Q + (size_t)bat * p.q_bs + head * DH;
+  const h16_t* Kb = p.K + (size_t)bat * p.k_bs + head * DH;
+  const h16_t* Vb = p.V + (size_t)bat * p.v_bs + head * DH;
 
   // ---- Q^T fragments (B operand of S^T = K Q^T): lane (r,hh) holds Q[q0+r][16s + 8hh .. +7] ----
-  bf16x8_t qf[KS];
+  h16x8_t qf[KS];
   {
     int qr = q0 + r;
     qr = qr < p.Lq ? qr : p.Lq - 1;
-    const bf16_t* qp = Qb + (size_t)qr * p.ldq + 8 * hh;
+    const h16_t* qp = Qb + (size_t)qr * p.ldq + 8 * hh;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const h16x8_t*>(qp + 16 * s);
   }
 
   // ---- staging maps: chunk c = tid + it*256 -> (key = c / CH, ch = c % CH); the last pass may be partial
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
       for (int e = 0; e < 16; ++e) st[k2][e] = 0.f;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + koff + k2 * 32 * Cfg::KROW + s * 32);
-        st[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[k2], 0, 0, 0);
+        h16x8_t kf = *reinterpret_cast<const h16x8_t*>(kb + koff + k2 * 32 * Cfg::KROW + s * 32);
+        st[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[k2], 0, 0, 0);
       }
     }
     // ---- mask the ragged tail (keys >= Lk) : wave-uniform branch ----
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
-    bf16x8_t pf[2][2];
+    h16x8_t pf[2][2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
         for (int j = 0; j < 8; ++j) {
           const float pv = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j] * sc - m_new);
           psum += pv;
-          pf[k2][s2][j] = (__bf16)pv;
+          pf[k2][s2][j] = (_Float16)pv;
         }
       }
     l_run = l_run * alpha + psum;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
           short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) short4_t*)(vrow + 8 * Cfg::VROW + d * 64));
           short8_t vf8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf8), pf[k2][s2], ot[d], 0, 0, 0);
+          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8_t, vf8), pf[k2][s2], ot[d], 0, 0, 0);
         }
       }
 
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
   const float inv = 1.0f / l_tot;
   const int q = q0 + r;
   if (q < p.Lq) {
-    bf16_t* op = p.O + (size_t)bat * p.o_bs + (size_t)q * p.ldo + head * DH;
+    h16_t* op = p.O + (size_t)bat * p.o_bs + (size_t)q * p.ldo + head * DH;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -211,16 +211,9 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
         if (dd < DH) {
           const float v0 = ot[d][4 * g4 + 0] * inv, v1 = ot[d][4 * g4 + 1] * inv, v2 = ot[d][4 * g4 + 2] * inv, v3 = ot[d][4 * g4 + 3] * inv;
           uint2 o;
-          o.x = pack_bf16x2(v0, v1);
-          o.y = pack_bf16x2(v2, v3);
+          o.x = pack_h16x2(v0, v1);
+          o.y = pack_h16x2(v2, v3);
           *reinterpret_cast<uint2*>(op + dd) = o;
-          if (p.o_split) {  // split-bf16 operand for the out-projection: lo = bf16(v - hi), hi repeated (elementwise.hip split3_kernel)
-            uint2 lo;
-            lo.x = pack_bf16x2(v0 - bf2f((bf16_t)(o.x & 0xffff)), v1 - bf2f((bf16_t)(o.x >> 16)));
-            lo.y = pack_bf16x2(v2 - bf2f((bf16_t)(o.y & 0xffff)), v3 - bf2f((bf16_t)(o.y >> 16)));
-            *reinterpret_cast<uint2*>(op + p.o_split + dd) = lo;
-            *reinterpret_cast<uint2*>(op + 2 * p.o_split + dd) = o;
-          }
         }
       }
     if (p.lse && hh == 0) p.lse[((size_t)bat * p.heads + head) * p.Lq + q] = m_run + log2f(l_tot);

@@ -1,12 +1,13 @@
-// Shared device/host helpers for the CrossScore gfx950 kernels.  gfx950 (CDNA4) only: wave64, MFMA bf16,
+// Shared device/host helpers for the CrossScore gfx950 kernels.  gfx950 (CDNA4) only: wave64, MFMA with IEEE half (fp16)
+// operands and fp32 accumulation (v_mfma_f32_*_f16 runs at the bf16 rate; 11 significant bits instead of 8),
 // 160 KiB LDS per CU.  No portability layer on purpose.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;  // raw bf16 bits in memory
+typedef uint16_t h16_t;  // raw fp16 (IEEE binary16) bits in memory
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
 typedef short short8_t __attribute__((ext_vector_type(8)));
 typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -15,17 +16,18 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #define CS_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define CS_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-// fp32 -> bf16 round-to-nearest-even.  A plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaNs.
-__device__ __forceinline__ bf16_t f2bf(float x) {
-  __bf16 b = (__bf16)x;
-  return __builtin_bit_cast(bf16_t, b);
+// fp32 -> fp16 round-to-nearest-even (v_cvt_f16_f32 / v_cvt_pk_f16_f32 on gfx950; NaN stays NaN, |x| > 65504 becomes inf: the
+// range every 16-bit activation of this path has to stay in is stated in DESIGN.md 2 and tested with scaled-up weights).
+__device__ __forceinline__ h16_t f2h(float x) {
+  _Float16 b = (_Float16)x;
+  return __builtin_bit_cast(h16_t, b);
 }
-__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-// two values in one v_cvt_pk_bf16_f32 (same round-to-nearest-even as f2bf)
+__device__ __forceinline__ float h2f(h16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+// two values in one v_cvt_pk_f16_f32 (same round-to-nearest-even as f2h)
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  const bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) {
+  const h16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, h16x2_t);
   return __builtin_bit_cast(uint32_t, v);
 }
 
@@ -86,24 +88,24 @@ __device__ __forceinline__ void gelu_erf4(float (&v)[4]) {
 
 // ---- kernel parameter blocks (plain structs; launchers live in the matching .hip files) -------------
 enum CsEpilogue {
-  CS_EPI_BIAS_BF16 = 0,        // out_bf16[m][n] = acc + bias[n]
-  CS_EPI_BIAS_GELU_BF16 = 1,   // exact erf GELU
-  CS_EPI_BIAS_RELU_BF16 = 2,
-  CS_EPI_BIAS_LEAKY_BF16 = 3,  // slope 0.01
+  CS_EPI_BIAS_F16 = 0,        // out_bf16[m][n] = acc + bias[n]
+  CS_EPI_BIAS_GELU_F16 = 1,   // exact erf GELU
+  CS_EPI_BIAS_RELU_F16 = 2,
+  CS_EPI_BIAS_LEAKY_F16 = 3,  // slope 0.01
   CS_EPI_RESID_F32 = 4,        // out_f32[m][n] = (resid? resid[m][n]:0) + (scale? scale[n]:1)*(acc+bias[n])
   CS_EPI_PATCH_F32 = 5,        // out_f32[(m + m/Np + 1)][n] = acc + bias[n] + pos[(m%Np+1)][n]
   CS_EPI_HEAD_SCORE = 6,       // score[b][P*i+py][P*j+px] = act(acc + bias[n]), m=b*Np+i*gw+j, n=py*P+px
   // LayerNorm folded into the consuming projection (no separate LN pass over the fp32 residual stream):
   //   LN(x) W^T + b = rstd[m] * (bf16(x) W'^T - mu[m] * s[n]) + c[n],  W' = W*gamma (per input column), s[n] = sum_k W'[n][k],
   //   c[n] = b[n] + sum_k beta[k] W[n][k];  mu / rstd come from per-row partial sums the PRODUCING epilogue wrote.
-  CS_EPI_LN_BF16 = 7,          // out_bf16 = rstd*(acc - mu*s) + c
-  CS_EPI_LN_GELU_BF16 = 8,     // ... then GELU
+  CS_EPI_LN_F16 = 7,          // out_bf16 = rstd*(acc - mu*s) + c
+  CS_EPI_LN_GELU_F16 = 8,     // ... then GELU
   CS_EPI_RESID_F32_LN = 9,     // CS_EPI_RESID_F32 + bf16 copy of the new rows + their partial (sum, sum of squares)
 };
 
 struct CsGemmParams {
-  const bf16_t* A;    // [M][lda] bf16, K contiguous
-  const bf16_t* W;    // [N][ldw] bf16, K contiguous (nn.Linear layout)
+  const h16_t* A;    // [M][lda] bf16, K contiguous
+  const h16_t* W;    // [N][ldw] bf16, K contiguous (nn.Linear layout)
   int lda, ldw;
   int M, N, K;        // K % 64 == 0
   const float* bias;  // [N] or null
@@ -123,7 +125,7 @@ struct CsGemmParams {
   int act;            // 0 sigmoid, 1 tanh
   float powp;         // 1 -> identity
   // LayerNorm fold (see CS_EPI_LN_*): producer side (RESID_F32_LN, PATCH_F32) ...
-  bf16_t* out_bf16;    // [rows][ldc] bf16 copy of the fp32 rows written (the next GEMM's A operand), or null
+  h16_t* out_bf16;    // [rows][ldc] bf16 copy of the fp32 rows written (the next GEMM's A operand), or null
   float* stats_out;    // [rows][stats_sp][2] partial (sum, sumsq) per row: slot = column_tile*4 + wave, or null
   int stats_sp;
   // ... consumer side (LN_BF16, LN_GELU_BF16); `bias` carries c[n]
@@ -135,14 +137,13 @@ struct CsGemmParams {
 };
 
 struct CsAttnParams {
-  const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
+  const h16_t* Q; const h16_t* K; const h16_t* V; h16_t* O;
   int ldq, ldk, ldv, ldo;                              // row strides (elements)
   long long q_bs, k_bs, v_bs, o_bs;                    // batch strides (elements)
   int Lq, Lk, heads;
   int nbatch;                                          // filled by the launcher
   float scale_log2e;                                   // (1/sqrt(dh)) * log2(e)
   float* lse;                                          // optional [batch][heads][Lq]: m*ln2-scaled log-sum-exp (base 2)
-  int o_split;                                         // 0, or C: O rows are [hi | lo | hi] (3C wide, split-bf16 operand of the out-projection)
 };
 
 // Encoder "token panel" kernel (panel.hip): one launch per DINOv2 layer does, for 128-row panels of the residual stream,
@@ -152,12 +153,12 @@ struct CsAttnParams {
 // The weights arrive as one pre-packed stream of 24-KiB "units" in the exact LDS image / consumption order (cs_panel_pack_*).
 struct CsPanelParams {
   float* x;                // [M][C] fp32 residual stream, updated in place
-  const bf16_t* attn_o;    // [M][C] bf16 attention output, or null: no out-projection (x is taken as is)
-  const bf16_t* img;       // unit stream: [12 Wo units (if attn_o)] [96 MLP units]
+  const h16_t* attn_o;    // [M][C] bf16 attention output, or null: no out-projection (x is taken as is)
+  const h16_t* img;       // unit stream: [12 Wo units (if attn_o)] [96 MLP units]
   const float* bo;         // [C] out-projection bias (LayerScale folded), used when attn_o
   const float* b1;         // [4C] fc1 bias with LN2 beta folded in
   const float* b2;         // [C] fc2 bias (LayerScale folded)
-  bf16_t* u_out;           // [M][C] or null
+  h16_t* u_out;           // [M][C] or null
   int M;
   float eps;               // LayerNorm eps (1e-6 in DINOv2)
 };

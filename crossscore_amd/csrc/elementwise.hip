@@ -15,7 +15,7 @@ namespace {
 // Image g = img0 + img of the (B*(1+N)) image batch is the query of item b = g/(1+N) when g%(1+N) == 0, else
 // reference view g%(1+N)-1 of item b: the torch.cat of core.py:134-138 is folded into the addressing.
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ xq, const float* __restrict__ xr, int N, int img0,
-                                                      bf16_t* __restrict__ out, int I, int H, int W, int gh, int gw, int P, int Kp) {
+                                                      h16_t* __restrict__ out, int I, int H, int W, int gh, int gw, int P, int Kp) {
   const int chunks = Kp / 8;
   const long long total = (long long)I * gh * gw * chunks;
   const int KK = 3 * P * P;
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
       v[e] = val;
     }
     uint4 o;
-    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    o.x = pack_h16x2(v[0], v[1]); o.y = pack_h16x2(v[2], v[3]);
+    o.z = pack_h16x2(v[4], v[5]); o.w = pack_h16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>(out + (size_t)m * Kp + c * 8) = o;
   }
 }
@@ -55,12 +55,12 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 // pmean[row][ch]; the patch GEMM adds mean * sum(W) back in fp32 (gemm.hip patch_dc).
 template <int P>
 __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ xq, const float* __restrict__ xr, int N, int img0,
-                                                           bf16_t* __restrict__ out, int H, int W, int gh, int gw, int Kp,
+                                                           h16_t* __restrict__ out, int H, int W, int gh, int gw, int Kp,
                                                            float* __restrict__ pmean) {
   extern __shared__ __attribute__((aligned(16))) char im_smem[];
-  bf16_t* tile = reinterpret_cast<bf16_t*>(im_smem);                                   // [gw][Kp]
+  h16_t* tile = reinterpret_cast<h16_t*>(im_smem);                                   // [gw][Kp]
   const int Wu = gw * P;
-  float* stage = reinterpret_cast<float*>(im_smem + (size_t)gw * Kp * sizeof(bf16_t));  // [P][Wu] one channel (centring only)
+  float* stage = reinterpret_cast<float*>(im_smem + (size_t)gw * Kp * sizeof(h16_t));  // [P][Wu] one channel (centring only)
   float* mean = stage + (size_t)P * Wu;                                                // [gw]
   float* part = mean + gw;                                                             // [gw][P] row sums
   const int img = blockIdx.x / gh, pi = blockIdx.x - img * gh;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restric
       const float* src = x + ((size_t)ch * H + (pi * P + dy)) * W;
       for (int xx = lane; xx < Wu; xx += 64) {
         const int pj = xx / P, dx = xx - pj * P;
-        tile[pj * Kp + ch * P * P + dy * P + dx] = f2bf(src[xx]);
+        tile[pj * Kp + ch * P * P + dy * P + dx] = f2h(src[xx]);
       }
     }
   } else {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restric
       for (int dy = wv; dy < P; dy += 4)
         for (int xx = lane; xx < Wu; xx += 64) {
           const int pj = xx / P, dx = xx - pj * P;
-          tile[pj * Kp + ch * P * P + dy * P + dx] = f2bf(stage[dy * Wu + xx] - mean[pj]);
+          tile[pj * Kp + ch * P * P + dy * P + dx] = f2h(stage[dy * Wu + xx] - mean[pj]);
         }
       __syncthreads();
     }
@@ -173,7 +173,7 @@ __device__ __forceinline__ void ln_normalise(LnRow& r, int C, int C4, int lane, 
     }
   }
 }
-__device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float* of32, bf16_t* obf) {
+__device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float* of32, h16_t* obf) {
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
@@ -181,8 +181,8 @@ __device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float
       if (of32) reinterpret_cast<float4*>(of32)[c] = r.v[i];
       if (obf) {
         uint2 o;
-        o.x = pack_bf16x2(r.v[i].x, r.v[i].y);
-        o.y = pack_bf16x2(r.v[i].z, r.v[i].w);
+        o.x = pack_h16x2(r.v[i].x, r.v[i].y);
+        o.y = pack_h16x2(r.v[i].z, r.v[i].w);
         reinterpret_cast<uint2*>(obf)[c] = o;
       }
     }
@@ -190,7 +190,7 @@ __device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int M, int C, const float* __restrict__ g,
-                                                         const float* __restrict__ b, float eps, float* of32, bf16_t* obf) {
+                                                         const float* __restrict__ b, float eps, float* of32, h16_t* obf) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // -------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __restrict__ x, int I, int img0, int Np, int C, int N,
                                                               const float* __restrict__ g, const float* __restrict__ b, float eps,
-                                                              const float* __restrict__ pe, float* q_f32, bf16_t* q_bf,
-                                                              bf16_t* mem_bf) {
+                                                              const float* __restrict__ pe, float* q_f32, h16_t* q_bf,
+                                                              h16_t* mem_bf) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long long)I * Np) return;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __rest
 
 // CLS rows of the residual stream: x[img*T][c] = cls[c] + pos[0][c]  (HF:108-112).  One wave per image.  With the LayerNorm
 // fold the row also gets its bf16 copy and its (sum, sumsq) in partial slot 0 (the other slots are zeroed).
-__global__ __launch_bounds__(64) void cls_rows_kernel(float* x, int I, int T, int C, const float* cls, const float* pos, bf16_t* xb,
+__global__ __launch_bounds__(64) void cls_rows_kernel(float* x, int I, int T, int C, const float* cls, const float* pos, h16_t* xb,
                                                       float* stats, int sp) {
   const int img = blockIdx.x, lane = threadIdx.x;
   const size_t row = (size_t)img * T;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void cls_rows_kernel(float* x, int I, int T, in
   for (int c = lane; c < C; c += 64) {
     const float v = cls[c] + pos[c];
     x[row * C + c] = v;
-    if (xb) xb[row * C + c] = f2bf(v);
+    if (xb) xb[row * C + c] = f2h(v);
     s1 += v;
     s2 += v * v;
   }
@@ -323,20 +323,20 @@ __global__ void pe_bilinear_kernel(const float* __restrict__ pe, int ph, int pw,
 
 // fp32 -> bf16 weight packing (K-contiguous rows; optional zero padding of K to ldo; optional per-output-row scale:
 // LayerScale lambda folded into the projection, HF modeling_dinov2.py:277-278, so the GEMM epilogue has no scale operand)
-__global__ void pack_bf16_kernel(const float* __restrict__ w, int rows, int K, bf16_t* __restrict__ out, int ldo,
+__global__ void pack_f16_kernel(const float* __restrict__ w, int rows, int K, h16_t* __restrict__ out, int ldo,
                                  const float* __restrict__ row_scale, const float* __restrict__ col_scale) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)rows * ldo) return;
   const int k = (int)(i % ldo);
   const long long rr = i / ldo;
   const float sc = (row_scale ? row_scale[rr] : 1.0f) * ((col_scale && k < K) ? col_scale[k] : 1.0f);
-  out[i] = k < K ? f2bf(w[rr * K + k] * sc) : (bf16_t)0;
+  out[i] = k < K ? f2h(w[rr * K + k] * sc) : (h16_t)0;
 }
 
 // LayerNorm fold constants of one projection (see CS_EPI_LN_* in cs_common.h), one wave per output row n:
 //   s[n] = sum_k float(Wp[n][k])            over the PACKED bf16 weights W' = W*gamma (what the MFMA really multiplies)
 //   c[n] = bias[n] + sum_k beta[k] W[n][k]   in fp32 from the original weights
-__global__ __launch_bounds__(256) void ln_fold_consts_kernel(const bf16_t* __restrict__ wp, int ldp, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void ln_fold_consts_kernel(const h16_t* __restrict__ wp, int ldp, const float* __restrict__ w,
                                                              const float* __restrict__ beta, const float* __restrict__ bias, int N,
                                                              int K, float* __restrict__ s_out, float* __restrict__ c_out) {
   const int lane = threadIdx.x & 63;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void ln_fold_consts_kernel(const bf16_t* __res
   if (n >= N) return;
   float s = 0.f, c = 0.f;
   for (int k = lane; k < K; k += 64) {
-    if (wp) s += bf2f(wp[(size_t)n * ldp + k]);
+    if (wp) s += h2f(wp[(size_t)n * ldp + k]);
     c += beta[k] * w[(size_t)n * K + k];
   }
   s = wave_sum(s);
@@ -372,10 +372,10 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(CsAttnParams p, int h
   const int kbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
   if (kbase >= p.Lk) return;
   const int key = kbase + lane;
-  const bf16_t* qp = p.Q + (size_t)bat * p.q_bs + (size_t)q * p.ldq + head * DH;
+  const h16_t* qp = p.Q + (size_t)bat * p.q_bs + (size_t)q * p.ldq + head * DH;
   const float lse = p.lse[((size_t)bat * p.heads + head) * p.Lq + q];
   if (key < p.Lk) {
-    const bf16_t* kp = p.K + (size_t)bat * p.k_bs + (size_t)key * p.ldk + head * DH;
+    const h16_t* kp = p.K + (size_t)bat * p.k_bs + (size_t)key * p.ldk + head * DH;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < DH / 8; ++c) {
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(CsAttnParams p, int h
       const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        s += __uint_as_float(kw[e] << 16) * __uint_as_float(qw[e] << 16);
-        s += __uint_as_float(kw[e] & 0xffff0000u) * __uint_as_float(qw[e] & 0xffff0000u);
+        s += h2f((h16_t)(kw[e] & 0xffffu)) * h2f((h16_t)(qw[e] & 0xffffu));
+        s += h2f((h16_t)(kw[e] >> 16)) * h2f((h16_t)(qw[e] >> 16));
       }
     }
     out[((size_t)bat * p.Lq + q) * p.Lk + key] = __builtin_amdgcn_exp2f(s * p.scale_log2e - lse);
@@ -415,10 +415,10 @@ hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipSt
 
 // pmean: [I*gh*gw][4] fp32 or nullptr.  With pmean the patches are mean-centred; when the gather fallback has to be used the
 // means are written as zeros (nothing removed, nothing to add back).
-hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, bf16_t* out, int I, int H, int W, int P, int Kp,
+hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, h16_t* out, int I, int H, int W, int P, int Kp,
                             float* pmean, hipStream_t st) {
   const int gh = H / P, gw = W / P;
-  const size_t lds = (size_t)gw * Kp * sizeof(bf16_t) + (pmean ? ((size_t)P * gw * P + gw + (size_t)gw * P) * sizeof(float) : 0);
+  const size_t lds = (size_t)gw * Kp * sizeof(h16_t) + (pmean ? ((size_t)P * gw * P + gw + (size_t)gw * P) * sizeof(float) : 0);
   if (P == 14 && Kp >= 3 * P * P && lds <= 156 * 1024 && (long long)I * gh < (1ll << 31) && gw <= 256) {
     static bool attr_done[16] = {};  // per device
     int dev = 0;
@@ -441,68 +441,29 @@ hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, b
   return hipGetLastError();
 }
 
-// -------------------------------------------------------------------------------------------------------
-// Split-bf16 operands for the precision-critical tail (the decoder's row-wise linears and the regression head):
-// x = hi + lo with hi = bf16(x), lo = bf16(x - hi).  A K-concatenated GEMM then computes
-//   [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]^T = a_hi.w_hi + a_lo.w_hi + a_hi.w_lo   (fp32-grade products, fp32 accumulation)
-// with the ordinary bf16 MFMA kernel.  src fp32 [M][ld] -> bf16 [M][3K]; wmode 0: activations [hi|lo|hi], 1: weights [hi|hi|lo];
-// act 0 none, 1 ReLU (transformer.py:59), 2 LeakyReLU 0.01 (cross_reference.py:47) applied before the split.
-// -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, long long M, int K, int ld, int act, int wmode,
-                                                      bf16_t* __restrict__ out) {
-  const int K4 = K / 4;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * K4) return;
-  const long long row = i / K4;
-  const int c = (int)(i - row * K4) * 4;
-  float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
-  float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (act == 1) e[k] = fmaxf(e[k], 0.f);
-    else if (act == 2) e[k] = e[k] >= 0.f ? e[k] : 0.01f * e[k];
-  }
-  bf16_t hi[4], lo[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    hi[k] = f2bf(e[k]);
-    lo[k] = f2bf(e[k] - bf2f(hi[k]));
-  }
-  const uint2 H = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
-  const uint2 L = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
-  bf16_t* o = out + row * 3 * K + c;
-  *reinterpret_cast<uint2*>(o) = H;
-  *reinterpret_cast<uint2*>(o + K) = wmode ? H : L;
-  *reinterpret_cast<uint2*>(o + 2 * K) = wmode ? L : H;
-}
 
-hipError_t cs_split3_launch(const float* src, long long M, int K, int ld, int act, int wmode, bf16_t* out, hipStream_t st) {
-  const long long total = M * (K / 4);
-  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, M, K, ld, act, wmode, out);
-  return hipGetLastError();
-}
 
 hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32,
-                               bf16_t* obf, hipStream_t st) {
+                               h16_t* obf, hipStream_t st) {
   hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, g, b, eps, of32, obf);
   return hipGetLastError();
 }
 
 hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
-                                    const float* pe, float* q_f32, bf16_t* q_bf, bf16_t* mem_bf, hipStream_t st) {
+                                    const float* pe, float* q_f32, h16_t* q_bf, h16_t* mem_bf, hipStream_t st) {
   const long long rows = (long long)I * Np;
   hipLaunchKernelGGL(final_ln_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, I, img0, Np, C, N, g, b, eps, pe,
                      q_f32, q_bf, mem_bf);
   return hipGetLastError();
 }
 
-hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, bf16_t* xb, float* stats, int sp,
+hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, h16_t* xb, float* stats, int sp,
                               hipStream_t st) {
   hipLaunchKernelGGL(cls_rows_kernel, dim3(I), dim3(64), 0, st, x, I, T, C, cls, pos, xb, stats, sp);
   return hipGetLastError();
 }
 
-hipError_t cs_ln_fold_consts_launch(const bf16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
+hipError_t cs_ln_fold_consts_launch(const h16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
                                     float* s_out, float* c_out, hipStream_t st) {
   hipLaunchKernelGGL(ln_fold_consts_kernel, dim3((N + 3) / 4), dim3(256), 0, st, wp, ldp, w, beta, bias, N, K, s_out, c_out);
   return hipGetLastError();
@@ -520,10 +481,10 @@ hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh,
   return hipGetLastError();
 }
 
-hipError_t cs_pack_bf16_launch(const float* w, int rows, int K, bf16_t* out, int ldo, const float* row_scale, const float* col_scale,
+hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
                                hipStream_t st) {
   const long long total = (long long)rows * ldo;
-  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, rows, K, out, ldo, row_scale,
+  hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, rows, K, out, ldo, row_scale,
                      col_scale);
   return hipGetLastError();
 }

@@ -152,9 +152,9 @@ __device__ __forceinline__ f32x4_t patch_dc(const CsGemmParams& p, int m, int n)
 }
 
 template <int EPI> struct EpiTraits {
-  static constexpr bool kLN = EPI == CS_EPI_LN_BF16 || EPI == CS_EPI_LN_GELU_BF16;           // LayerNorm-folded consumer
-  static constexpr bool kHalf = EPI == CS_EPI_BIAS_BF16 || EPI == CS_EPI_BIAS_GELU_BF16 || EPI == CS_EPI_BIAS_RELU_BF16 ||
-                                EPI == CS_EPI_BIAS_LEAKY_BF16 || kLN;
+  static constexpr bool kLN = EPI == CS_EPI_LN_F16 || EPI == CS_EPI_LN_GELU_F16;           // LayerNorm-folded consumer
+  static constexpr bool kHalf = EPI == CS_EPI_BIAS_F16 || EPI == CS_EPI_BIAS_GELU_F16 || EPI == CS_EPI_BIAS_RELU_F16 ||
+                                EPI == CS_EPI_BIAS_LEAKY_F16 || kLN;
   static constexpr bool kResid = EPI == CS_EPI_RESID_F32 || EPI == CS_EPI_RESID_F32_LN;
   static constexpr bool kLnOut = EPI == CS_EPI_RESID_F32_LN || EPI == CS_EPI_PATCH_F32;      // may emit bf16 copy + row partials
 };
@@ -392,16 +392,16 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaf(fmaf(-ln_mu, sc[0][r], v[r]), ln_rs, sc[1][r]);
         }
-        if constexpr (EPI == CS_EPI_BIAS_GELU_BF16 || EPI == CS_EPI_LN_GELU_BF16) {
+        if constexpr (EPI == CS_EPI_BIAS_GELU_F16 || EPI == CS_EPI_LN_GELU_F16) {
           gelu_erf4(v);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if constexpr (EPI == CS_EPI_BIAS_RELU_BF16) v[r] = fmaxf(v[r], 0.f);
-          if constexpr (EPI == CS_EPI_BIAS_LEAKY_BF16) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+          if constexpr (EPI == CS_EPI_BIAS_RELU_F16) v[r] = fmaxf(v[r], 0.f);
+          if constexpr (EPI == CS_EPI_BIAS_LEAKY_F16) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
         }
         if constexpr (kHalf) {
-          patch_write8<j * 32>(pw_addr, u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])});
+          patch_write8<j * 32>(pw_addr, u32x2_t{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3])});
         } else {
           patch_write16<j * 64>(pw_addr, f32x4_t{v[0], v[1], v[2], v[3]});
         }
@@ -433,14 +433,14 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
           for (int q = 0; q < NRD; ++q) {
             const int m = mrow0 + q * RPI;
             if constexpr (kHalf) {
-              *reinterpret_cast<f32x4_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n) = seg[q];
+              *reinterpret_cast<f32x4_t*>(reinterpret_cast<h16_t*>(p.out) + (size_t)m * p.ldc + n) = seg[q];
             } else {
               // CS_EPI_PATCH_F32: token row m of image img lands at row m + img + 1 (CLS rows interleaved)
               const size_t row = EPI == CS_EPI_PATCH_F32 ? (size_t)(m + m / p.Np + 1) : (size_t)m;
               *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + row * p.ldc + n) = seg[q];
               if constexpr (kLnOut)
                 *reinterpret_cast<u32x2_t*>(p.out_bf16 + row * p.ldc + n) =
-                    u32x2_t{pack_bf16x2(seg[q][0], seg[q][1]), pack_bf16x2(seg[q][2], seg[q][3])};
+                    u32x2_t{pack_h16x2(seg[q][0], seg[q][1]), pack_h16x2(seg[q][2], seg[q][3])};
             }
           }
         }
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
         [[maybe_unused]] size_t row = (size_t)m;
         if (ok) {
           if constexpr (kHalf) {
-            *reinterpret_cast<f32x4_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n) = seg[q];
+            *reinterpret_cast<f32x4_t*>(reinterpret_cast<h16_t*>(p.out) + (size_t)m * p.ldc + n) = seg[q];
           } else {
             if constexpr (kResid) {
               if (p.resid) seg[q] += *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m * p.ldr + n);
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
             if constexpr (kLnOut)
               if (p.out_bf16)
                 *reinterpret_cast<u32x2_t*>(p.out_bf16 + row * p.ldc + n) =
-                    u32x2_t{pack_bf16x2(seg[q][0], seg[q][1]), pack_bf16x2(seg[q][2], seg[q][3])};
+                    u32x2_t{pack_h16x2(seg[q][0], seg[q][1]), pack_h16x2(seg[q][2], seg[q][3])};
           }
         }
         if constexpr (kLnOut) {
@@ -536,15 +536,15 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
     if (!CS_ABL(2)) {
       const char* sa = smem + c_ring * STAGE_BYTES + frow * 64 + coff;
       const char* sw = smem + c_ring * STAGE_BYTES + A_BYTES + (wn * 16 * NSUB + frow) * 64 + coff;
-      bf16x8_t fw[NSUB], fa[8];
+      h16x8_t fw[NSUB], fa[8];
 #pragma unroll
-      for (int j = 0; j < NSUB; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(sw + j * 16 * 64);
+      for (int j = 0; j < NSUB; ++j) fw[j] = *reinterpret_cast<const h16x8_t*>(sw + j * 16 * 64);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 16 * 64);
+      for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const h16x8_t*>(sa + i * 16 * 64);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
       // W fragments + LOOK A fragments up front, then one A-fragment read per MFMA group, LOOK-1 groups ahead of its use
       // (the LN-folded consumers are at the 256-register limit: one fragment less in flight avoids spills)
       constexpr int LOOK = ((kLN || PIPE) && NSUB == 3) ? 2 : 3;
@@ -754,16 +754,16 @@ extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
   if (p->M <= 0 || p->N <= 0 || p->K <= 0) return "gemm: empty shape";
   if (p->K % 64) return "gemm: K must be a multiple of 64";
   if (p->N % 4 || p->ldc % 4) return "gemm: N and ldc must be multiples of 4";
-  if (epi <= CS_EPI_BIAS_LEAKY_BF16 && (p->N % 8 || p->ldc % 8)) return "gemm: bf16 outputs need N and ldc multiples of 8 (16-byte row stores)";
+  if (epi <= CS_EPI_BIAS_LEAKY_F16 && (p->N % 8 || p->ldc % 8)) return "gemm: bf16 outputs need N and ldc multiples of 8 (16-byte row stores)";
   if (p->lda % 8 || p->ldw % 8) return "gemm: lda/ldw must be multiples of 8 (16-byte rows)";
   if (p->lda < p->K || p->ldw < p->K) return "gemm: lda/ldw smaller than K";
   if (!p->A || !p->W || !p->out) return "gemm: null operand";
-  if (p->scale) return "gemm: a per-column scale is folded into the packed weights (cs_op_pack_bf16 row_scale), it is not an epilogue operand";
+  if (p->scale) return "gemm: a per-column scale is folded into the packed weights (cs_op_pack_f16 row_scale), it is not an epilogue operand";
   if ((epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN) && p->resid && p->ldr % 4) return "gemm: ldr must be a multiple of 4";
   if (epi == CS_EPI_RESID_F32_LN && (!p->out_bf16 || !p->stats_out)) return "gemm: RESID_F32_LN needs out_bf16 and stats_out";
   if ((epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32) && p->stats_out && p->stats_sp != 4 * cs_gemm_column_tiles(p->N))
     return "gemm: stats_sp must be 4 x the number of column tiles";
-  if ((epi == CS_EPI_LN_BF16 || epi == CS_EPI_LN_GELU_BF16) &&
+  if ((epi == CS_EPI_LN_F16 || epi == CS_EPI_LN_GELU_F16) &&
       (!p->ln_part || !p->col_s || !p->bias || (p->ln_sp != 4 && p->ln_sp != 8 && p->ln_sp != 16) || p->N % 8 || p->ldc % 8))
     return "gemm: LayerNorm-folded epilogue needs ln_part, col_s, bias (= c), ln_sp in {4,8,16}";
   if (epi == CS_EPI_PATCH_F32 && (!p->pos || p->Np <= 0 || p->M % p->Np)) return "gemm: bad patch epilogue params";
@@ -784,15 +784,15 @@ extern "C" hipError_t cs_gemm_launch(const CsGemmParams* p0, int epi, hipStream_
 #endif
   const CsGemmParams* p = &pp;
   switch (epi) {
-    case CS_EPI_BIAS_BF16: return launch<CS_EPI_BIAS_BF16>(*p, stream);
-    case CS_EPI_BIAS_GELU_BF16: return launch<CS_EPI_BIAS_GELU_BF16>(*p, stream);
-    case CS_EPI_BIAS_RELU_BF16: return launch<CS_EPI_BIAS_RELU_BF16>(*p, stream);
-    case CS_EPI_BIAS_LEAKY_BF16: return launch<CS_EPI_BIAS_LEAKY_BF16>(*p, stream);
+    case CS_EPI_BIAS_F16: return launch<CS_EPI_BIAS_F16>(*p, stream);
+    case CS_EPI_BIAS_GELU_F16: return launch<CS_EPI_BIAS_GELU_F16>(*p, stream);
+    case CS_EPI_BIAS_RELU_F16: return launch<CS_EPI_BIAS_RELU_F16>(*p, stream);
+    case CS_EPI_BIAS_LEAKY_F16: return launch<CS_EPI_BIAS_LEAKY_F16>(*p, stream);
     case CS_EPI_RESID_F32: return launch<CS_EPI_RESID_F32>(*p, stream);
     case CS_EPI_PATCH_F32: return launch<CS_EPI_PATCH_F32>(*p, stream);
     case CS_EPI_HEAD_SCORE: return launch<CS_EPI_HEAD_SCORE>(*p, stream);
-    case CS_EPI_LN_BF16: return launch<CS_EPI_LN_BF16>(*p, stream);
-    case CS_EPI_LN_GELU_BF16: return launch<CS_EPI_LN_GELU_BF16>(*p, stream);
+    case CS_EPI_LN_F16: return launch<CS_EPI_LN_F16>(*p, stream);
+    case CS_EPI_LN_GELU_F16: return launch<CS_EPI_LN_GELU_F16>(*p, stream);
     case CS_EPI_RESID_F32_LN: return launch<CS_EPI_RESID_F32_LN>(*p, stream);
   }
   return hipErrorInvalidValue;

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
     reinterpret_cast<f32x4_t*>(smem + LDS_B1)[i] = reinterpret_cast<const f32x4_t*>(p.b1)[i];
 
   f32x4_t acc2[NT][2];  // residual rows / fc2 accumulators: tile nt = features 16nt.., row tile mt
-  bf16x8_t xf[2][KS];   // B fragments of the current GEMM input (attention output, then norm2(x))
+  h16x8_t xf[2][KS];   // B fragments of the current GEMM input (attention output, then norm2(x))
 
   // ---- unit / batch machinery -----------------------------------------------------------------------------------------------
   // A unit is consumed as 4 batches of 6 weight fragments (12 MFMAs per batch).  The wave is alone on its SIMD, so LDS latency
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
     return sl;
   };
 #define CS_SB() __builtin_amdgcn_sched_barrier(0)  /* nothing crosses (any other mask let hipcc move MFMAs over the asm waits) */
-  auto read6 = [&](unsigned sl, auto B_, bf16x8_t (&w)[6]) {
+  auto read6 = [&](unsigned sl, auto B_, h16x8_t (&w)[6]) {
     constexpr int O = decltype(B_)::value * 6 * 1024;
     asm volatile("ds_read_b128 %0, %6 offset:%7\n\tds_read_b128 %1, %6 offset:%8\n\tds_read_b128 %2, %6 offset:%9\n\t"
                  "ds_read_b128 %3, %6 offset:%10\n\tds_read_b128 %4, %6 offset:%11\n\tds_read_b128 %5, %6 offset:%12"
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
   };
 #define CS_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); CS_SB(); } while (0)
   // fc1-type batch B: pieces 6B..6B+5 = (jt, ks) pairs; D tile (jt, mt) += W piece x xf[mt][ks]
-  auto mm_fc1 = [&](auto B_, auto INIT_, const bf16x8_t (&w)[6], f32x4_t (&a0)[2], f32x4_t (&a1)[2], const f32x4_t (&bb)[2]) {
+  auto mm_fc1 = [&](auto B_, auto INIT_, const h16x8_t (&w)[6], f32x4_t (&a0)[2], f32x4_t (&a1)[2], const f32x4_t (&bb)[2]) {
     constexpr int B = decltype(B_)::value;
     constexpr bool INIT = decltype(INIT_)::value;  // the accumulators start at bb (fc1 bias); else they keep accumulating
 #pragma unroll
@@ -145,18 +145,18 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         f32x4_t& d = jt == 0 ? a0[mt] : a1[mt];
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i], xf[mt][ks], (INIT && ks == 0) ? bb[jt] : d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], xf[mt][ks], (INIT && ks == 0) ? bb[jt] : d, 0, 0, 0);
       }
     }
     CS_SB();
   };
-  auto mm_fc2 = [&](auto B_, const bf16x8_t (&w)[6], const bf16x8_t (&hb)[2]) {
+  auto mm_fc2 = [&](auto B_, const h16x8_t (&w)[6], const h16x8_t (&hb)[2]) {
     constexpr int B = decltype(B_)::value;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        acc2[6 * B + i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i], hb[mt], acc2[6 * B + i][mt], 0, 0, 0);
+        acc2[6 * B + i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], hb[mt], acc2[6 * B + i][mt], 0, 0, 0);
     CS_SB();
   };
   using B0 = std::integral_constant<int, 0>;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const bf16x8_t*>(p.attn_o + r_mt[mt] * PC + 32 * ks + 8 * g);
+      for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const h16x8_t*>(p.attn_o + r_mt[mt] * PC + 32 * ks + 8 * g);
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
 
   // (inline-asm read results must never stay in flight across compiler-scheduled code such as the LayerNorm below: hipcc counts
   //  them as written at the end of the asm statement and copies / spills them before the data has landed)
-  bf16x8_t wa[6], wb[6];  // the two fragment batches in flight
+  h16x8_t wa[6], wb[6];  // the two fragment batches in flight
   unsigned sl = transition(NotLast{});
 
   // ---- attention output projection: 12 units of 32 output features, accumulated straight onto the residual rows ----
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const f32x4_t a = (acc2[2 * ks][mt] - mean[mt]) * rstd[mt], b = (acc2[2 * ks + 1][mt] - mean[mt]) * rstd[mt];
-        const uint4 pk = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
-        xf[mt][ks] = __builtin_bit_cast(bf16x8_t, pk);
+        const uint4 pk = {pack_h16x2(a[0], a[1]), pack_h16x2(a[2], a[3]), pack_h16x2(b[0], b[1]), pack_h16x2(b[2], b[3])};
+        xf[mt][ks] = __builtin_bit_cast(h16x8_t, pk);
       }
   }
   // the fc2 accumulators start at residual + bias: the residual add and the bias add are free
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
   //      independent, so the GELU arithmetic of slice i-1 (16 values per lane) is cut into 8 pieces of 2 values, one per step of
   //      the two units of an iteration, and fills VALU issue slots between the MFMAs of the other two. ----
   f32x4_t ac0[2][2], ac1[2][2], bb0[2], bb1[2];
-  bf16x8_t hb0[2], hb1[2];
+  h16x8_t hb0[2], hb1[2];
   float gt[8];  // GELU results of the row tile in progress
   using Q0 = std::integral_constant<int, 0>;
   using Q1 = std::integral_constant<int, 1>;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
   using QC = std::integral_constant<int, 12>;
   using QD = std::integral_constant<int, 13>;
   // piece Q (0..3) of row tile MT: values (jt = Q/2, r = 2(Q%2), +1) of ac[.][MT]; the last piece packs the B fragment
-  auto gelu_piece = [&](auto Q_, auto MT_, const f32x4_t (&ac)[2][2], bf16x8_t (&hb)[2]) {
+  auto gelu_piece = [&](auto Q_, auto MT_, const f32x4_t (&ac)[2][2], h16x8_t (&hb)[2]) {
     constexpr int Q = decltype(Q_)::value, MT = decltype(MT_)::value;
     if constexpr (Q >= 10) {  // a whole slice inside one unit (first and last slice): pieces 2(Q-10), 2(Q-10)+1 over both row tiles
       constexpr int H = Q - 10;
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
         gt[2 * P1] = gelu_erf1(ac[P1 / 2][MM][2 * (P1 % 2)]);
         gt[2 * P1 + 1] = gelu_erf1(ac[P1 / 2][MM][2 * (P1 % 2) + 1]);
         if constexpr (P1 == 3) {
-          const uint4 pk = {pack_bf16x2(gt[0], gt[1]), pack_bf16x2(gt[2], gt[3]), pack_bf16x2(gt[4], gt[5]), pack_bf16x2(gt[6], gt[7])};
-          hb[MM] = __builtin_bit_cast(bf16x8_t, pk);
+          const uint4 pk = {pack_h16x2(gt[0], gt[1]), pack_h16x2(gt[2], gt[3]), pack_h16x2(gt[4], gt[5]), pack_h16x2(gt[6], gt[7])};
+          hb[MM] = __builtin_bit_cast(h16x8_t, pk);
         }
       };
       if constexpr (H == 0) two(Q0{}, Q1{}, Q0{});
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
       gt[2 * Q] = gelu_erf1(ac[Q / 2][MT][2 * (Q % 2)]);
       gt[2 * Q + 1] = gelu_erf1(ac[Q / 2][MT][2 * (Q % 2) + 1]);
       if constexpr (Q == 3) {
-        const uint4 pk = {pack_bf16x2(gt[0], gt[1]), pack_bf16x2(gt[2], gt[3]), pack_bf16x2(gt[4], gt[5]), pack_bf16x2(gt[6], gt[7])};
-        hb[MT] = __builtin_bit_cast(bf16x8_t, pk);
+        const uint4 pk = {pack_h16x2(gt[0], gt[1]), pack_h16x2(gt[2], gt[3]), pack_h16x2(gt[4], gt[5]), pack_h16x2(gt[6], gt[7])};
+        hb[MT] = __builtin_bit_cast(h16x8_t, pk);
       }
     }
   };
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const f32x4_t a = (acc2[nt][mt] - mean[mt]) * rstd[mt];
-          *reinterpret_cast<uint2*>(p.u_out + (size_t)row * PC + 16 * nt + 4 * g) = make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+          *reinterpret_cast<uint2*>(p.u_out + (size_t)row * PC + 16 * nt + 4 * g) = make_uint2(pack_h16x2(a[0], a[1]), pack_h16x2(a[2], a[3]));
         }
       }
     }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
 __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restrict__ wo, const float* __restrict__ ls1,
                                                             const float* __restrict__ w1, const float* __restrict__ g2,
                                                             const float* __restrict__ w2, const float* __restrict__ ls2,
-                                                            bf16_t* __restrict__ img) {
+                                                            h16_t* __restrict__ img) {
   const int nu = (wo ? OUT_UNITS : 0) + MLP_UNITS;
   const int gi = blockIdx.x * blockDim.x + threadIdx.x;
   if (gi >= (nu + AHEAD) * (UNIT / 16)) return;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restr
       }
     }
   }
-  const uint4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  const uint4 o = {pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7])};
   reinterpret_cast<uint4*>(img)[gi] = o;
 }
 
@@ -406,7 +406,7 @@ int cs_panel_supported(int C, int mlp_ratio) { return C == PC && mlp_ratio * C =
 size_t cs_panel_image_bytes(int with_outproj) { return (size_t)((with_outproj ? OUT_UNITS : 0) + MLP_UNITS + AHEAD) * UNIT; }
 
 hipError_t cs_panel_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
-                                bf16_t* img, hipStream_t st) {
+                                h16_t* img, hipStream_t st) {
   const int total = ((wo ? OUT_UNITS : 0) + MLP_UNITS + AHEAD) * (UNIT / 16);
   hipLaunchKernelGGL(cs_panel_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, wo, ls1, w1, g2, w2, ls2, img);
   return hipGetLastError();

@@ -100,7 +100,6 @@ class CrossScoreNet(torch.nn.Module):
         self._dirty = True
         self.enc_chunk_images = 0  # 0 = library default
         self.lanes = 0             # 0 = library default (2 concurrent lanes); 1 = serial
-        self.tail_precision = 0    # split-bf16 operands: 0 = head + decoder FFN (default), 2 = + decoder in/Q/out-projections, 1 = plain bf16
         self.enc_fused = 0         # 0 = token-panel kernel per encoder layer where supported (hidden 384), 1 = unfused kernels
         self.ln_fold = 0           # 1 = fold the encoder LayerNorms into the QKV / fc1 GEMM epilogues (opt-in; slower so far)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
@@ -133,7 +132,7 @@ class CrossScoreNet(torch.nn.Module):
         cc = _lib.CsConfig(hidden=a.hidden, enc_layers=a.enc_layers, enc_heads=a.enc_heads, mlp_ratio=a.mlp_ratio, patch=a.patch,
                            pos_grid=a.pos_grid, pe_h=a.pe_h, pe_w=a.pe_w, dec_layers=a.dec_layers, dec_heads=a.dec_heads,
                            do_self_attn=int(bool(m.decoder_do_self_attn)), do_short_cut=int(bool(m.decoder_do_short_cut)),
-                           act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold), tail_precision=int(self.tail_precision),
+                           act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold),
                            lanes=int(self.lanes), enc_fused=int(self.enc_fused))
         with torch.cuda.device(device):
             h = lib.cs_create(C.byref(cc))
@@ -221,7 +220,7 @@ class CrossScoreNet(torch.nn.Module):
         P = self.arch.patch
         handle = self._ensure_handle(dev)
         with torch.cuda.device(dev):
-            tok = torch.empty((R, (H // P) * (W // P), self.arch.hidden), dtype=torch.bfloat16, device=dev)
+            tok = torch.empty((R, (H // P) * (W // P), self.arch.hidden), dtype=torch.float16, device=dev)
             _lib.check(_lib.load().cs_encode_references(handle, C.c_void_p(x.data_ptr()), R, H, W, C.c_void_p(tok.data_ptr()),
                                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return tok
@@ -235,7 +234,7 @@ class CrossScoreNet(torch.nn.Module):
             raise _lib.CrossScoreHipError("forward_cached needs CUDA(HIP) tensors on one device: the hot path has no CPU fallback")
         dev = query_img.device
         q = query_img.to(torch.float32).contiguous()
-        t = ref_tokens.to(torch.bfloat16).contiguous()
+        t = ref_tokens.to(torch.float16).contiguous()
         B, _, H, W = q.shape
         N = t.shape[1]
         P = self.arch.patch

@@ -60,11 +60,6 @@ typedef struct cs_config {
   int ln_fold;       /* 1: encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass; opt-in, measured
                       * slower on MI355X); 0: separate LayerNorm kernels (default) */
   int lanes;         /* internal streams that run independent image chunks / batch groups concurrently: 0 = default (2), 1 = serial, up to 4 */
-  int tail_precision; /* split-bf16 (hi + lo, three-term) operands = fp32-grade products with the bf16 MFMA kernel, for the linears that
-                       * carry most of the bf16 error of the score map: 0 = default: regression head + decoder FFN (score-map MAE 8.4e-4 ->
-                       * ~6.1e-4 on cfg-2 at < 2 % time), 2 = also the decoder's self-attention in-proj, cross-attention Q-proj and both
-                       * out-projections (attention writes its output as hi | lo | hi): 5.0e-4 at a further 1.8 %,
-                       * 1 = plain bf16 everywhere */
   int enc_fused;      /* encoder layer structure: 0 = default: with hidden == 384 (ViT-S) each layer is QKV GEMM + attention + ONE
                        * token-panel kernel (out-projection, residual, norm2, fc1, GELU, fc2, residual and the next layer's norm1; the 4C
                        * hidden activations stay in registers), else the unfused kernels; 1 = always the unfused kernels */
@@ -148,7 +143,7 @@ int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
 /* fp32 [rows][K] -> bf16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
  * rows of a projection, LayerNorm gamma into its columns */
-int cs_op_pack_bf16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
+int cs_op_pack_f16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
                     cs_stream stream);
 /* LayerNorm fold constants of a projection: s[n] = sum_k packed W'[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] */
 int cs_op_ln_fold_consts(const uint16_t* w_packed, int ldp, const float* w, const float* beta, const float* bias, int N, int K,

@@ -292,7 +292,7 @@ DEFAULT_CFG = dict(
 
 def forward(Wt: Dict[str, Tensor], cfg: dict, query_img: Tensor, ref_cross_imgs: Tensor,
             need_attn_weights: bool = False, need_attn_weights_head_id: int = 0,
-            emulate_bf16: bool = False, taps: Optional[dict] = None) -> Dict[str, Optional[Tensor]]:
+            emulate_bf16=False, taps: Optional[dict] = None) -> Dict[str, Optional[Tensor]]:
     """CrossScoreNet.forward (task/core.py:58-117) with norm_img=False.
 
     emulate_bf16=True rounds every matmul operand to bf16 (fp32 accumulate) -- the precision policy of the
@@ -300,7 +300,10 @@ def forward(Wt: Dict[str, Tensor], cfg: dict, query_img: Tensor, ref_cross_imgs:
     """
     c = dict(DEFAULT_CFG)
     c.update(cfg)
-    rnd = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if emulate_bf16 else (lambda t: t)
+    if emulate_bf16 == "f16":  # budget of an fp16-operand forward (same rule: operands rounded, fp32 accumulate)
+        rnd = lambda t: t.to(torch.float16).to(torch.float32)  # noqa: E731
+    else:
+        rnd = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if emulate_bf16 else (lambda t: t)
     P = c["patch"]
     B, _, H, W = query_img.shape
     N = ref_cross_imgs.shape[1]

@@ -14,7 +14,7 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_BF16, resid=None, out=None, pos=None, Np=0, gw=0, P=0, act=0, powp=1.0,
+def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_F16, resid=None, out=None, pos=None, Np=0, gw=0, P=0, act=0, powp=1.0,
          K=None, ldc=None, out_bf16=None, stats_out=None, ln_part=None, col_s=None, ln_eps=1e-6):
     """A:(M,lda) bf16, W:(N,ldw) bf16 -> out (allocated here unless given)."""
     lib = _lib.load()
@@ -22,7 +22,7 @@ def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_BF16, resid=None, out=None, pos=None
     N, ldw = W.shape
     K = K or lda
     if out is None:
-        dt = torch.bfloat16 if (epi <= _lib.EPI_BIAS_LEAKY_BF16 or epi in (_lib.EPI_LN_BF16, _lib.EPI_LN_GELU_BF16)) else torch.float32
+        dt = torch.float16 if (epi <= _lib.EPI_BIAS_LEAKY_F16 or epi in (_lib.EPI_LN_F16, _lib.EPI_LN_GELU_F16)) else torch.float32
         out = torch.zeros((M, N), dtype=dt, device=A.device)
     ldc = ldc or out.shape[-1]
     rc = lib.cs_op_gemm(_p(A), lda, _p(W), ldw, M, N, K, _p(bias), _p(resid), resid.shape[-1] if resid is not None else 0,
@@ -38,7 +38,7 @@ def attention(Q, K, V, heads, dh, lse=False):
     lib = _lib.load()
     B, Lq, Cq = Q.shape
     Lk = K.shape[1]
-    O = torch.zeros((B, Lq, heads * dh), dtype=torch.bfloat16, device=Q.device)
+    O = torch.zeros((B, Lq, heads * dh), dtype=torch.float16, device=Q.device)
     L = torch.zeros((B, heads, Lq), dtype=torch.float32, device=Q.device) if lse else None
     rc = lib.cs_op_attention(_p(Q), _p(K), _p(V), _p(O), Q.stride(1), K.stride(1), V.stride(1), O.stride(1), Q.stride(0), K.stride(0),
                              V.stride(0), O.stride(0), B, heads, Lq, Lk, dh, _p(L), _stream())
@@ -61,7 +61,7 @@ def layernorm(x, g, b, eps, want_f32=True, want_bf16=True):
     lib = _lib.load()
     M, Cc = x.shape
     of = torch.zeros_like(x) if want_f32 else None
-    ob = torch.zeros((M, Cc), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    ob = torch.zeros((M, Cc), dtype=torch.float16, device=x.device) if want_bf16 else None
     _lib.check(lib.cs_op_layernorm(_p(x), M, Cc, _p(g), _p(b), eps, _p(of), _p(ob), _stream()))
     return of, ob
 
@@ -69,7 +69,7 @@ def layernorm(x, g, b, eps, want_f32=True, want_bf16=True):
 def im2col(x, P, Kp):
     lib = _lib.load()
     I, _, H, W = x.shape
-    out = torch.zeros((I * (H // P) * (W // P), Kp), dtype=torch.bfloat16, device=x.device)
+    out = torch.zeros((I * (H // P) * (W // P), Kp), dtype=torch.float16, device=x.device)
     _lib.check(lib.cs_op_im2col(_p(x), _p(out), I, H, W, P, Kp, _stream()))
     return out
 
@@ -90,12 +90,12 @@ def pe_bilinear(pe, gh, gw):
     return out
 
 
-def pack_bf16(w, ldo=None, row_scale=None, col_scale=None):
+def pack_f16(w, ldo=None, row_scale=None, col_scale=None):
     lib = _lib.load()
     rows, K = w.shape
     ldo = ldo or K
-    out = torch.zeros((rows, ldo), dtype=torch.bfloat16, device=w.device)
-    _lib.check(lib.cs_op_pack_bf16(_p(w), rows, K, _p(out), ldo, _p(row_scale), _p(col_scale), _stream()))
+    out = torch.zeros((rows, ldo), dtype=torch.float16, device=w.device)
+    _lib.check(lib.cs_op_pack_f16(_p(w), rows, K, _p(out), ldo, _p(row_scale), _p(col_scale), _stream()))
     return out
 
 
@@ -125,6 +125,6 @@ def encoder_panel(x, attn_o, img, bo, b1, b2, want_u=True, eps=1e-6):
     """In place on x (M,384) fp32; returns u (M,384) bf16 or None."""
     lib = _lib.load()
     M = x.shape[0]
-    u = torch.zeros((M, x.shape[1]), dtype=torch.bfloat16, device=x.device) if want_u else None
+    u = torch.zeros((M, x.shape[1]), dtype=torch.float16, device=x.device) if want_u else None
     _lib.check(lib.cs_op_encoder_panel(_p(x), _p(attn_o), _p(img), _p(bo), _p(b1), _p(b2), _p(u), M, eps, _stream()))
     return u

@@ -1,0 +1,135 @@
+"""Every BASELINE.json configuration at its full size on the GPU: cfg-1 through the predict driver, cfg-3 at B=8,
+cfg-4 at 16 items per GPU and at B=2 against the oracle, cfg-5 at B=2.  Where the fp32 oracle would take minutes the checks are
+the size-independent properties of the path: batch items never interact (task/core.py:134-161 keeps B outermost, attention is
+per sample), so (a) an item's score map is bit-identical whatever batch it sits in, (b) permuting the items permutes the outputs,
+and item 0 of the seeded batch is the committed golden of the reference itself (tests/golden/g2, g3: same seed, same item)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from crossscore_amd import synth  # noqa: E402
+from crossscore_amd.config import load_config, model_config  # noqa: E402
+from crossscore_amd.model import CrossScoreNet  # noqa: E402
+from oracle import crossscore_oracle as orc  # noqa: E402
+from test_hip_forward import MAE_TOL, MAX_TOL, _check_compact, _net  # noqa: E402
+
+VITS, VITB = "facebook/dinov2-small", "facebook/dinov2-base"
+
+
+def _run(net, q, r):
+    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    return out
+
+
+def _properties(net, q, r, score):
+    """finite, in the sigmoid range, deterministic, permutation-equivariant over the batch (bitwise)."""
+    assert torch.isfinite(score).all() and float(score.min()) >= 0.0 and float(score.max()) <= 1.0
+    B = q.shape[0]
+    perm = np.roll(np.arange(B), 1)
+    again = _run(net, q[perm].copy(), r[perm].copy())
+    assert torch.equal(again, score[torch.from_numpy(perm).cuda()])
+
+
+def test_cfg3_vitb_10refs_batch8(golden_dir):
+    """BASELINE configs[2]: ViT-B/14, 518x518, 10 refs, bs=8 (I = 88 images, cross-attention Lk = 13 690, decoder dh = 96)."""
+    g = np.load(os.path.join(golden_dir, "g2_vitb_518_n10.npz"))
+    seed = int(g["seed"])
+    net, arch, sd = _net(VITB, seed)
+    q, r = synth.make_inputs_shard(0, 8, 10, 518, 518, seed)
+    score = _run(net, q, r)
+    assert score.shape == (8, 518, 518)
+    mae_rows, mae_grid, dmean = _check_compact(g, score[:1])  # item 0 = the reference's own golden
+    assert mae_rows < MAE_TOL and mae_grid < MAE_TOL and dmean < 5e-4, (mae_rows, mae_grid, dmean)
+    one = _run(net, q[:1], r[:1])
+    assert torch.equal(one[0], score[0])  # the same item alone: bitwise
+    _properties(net, q, r, score)
+
+
+def test_cfg4_vitb_5refs_vs_oracle_and_16_per_gpu():
+    """BASELINE configs[3]: ViT-B/14, 518x518, 5 refs, global bs=128 = 16 items per GPU.  B=2 against the fp32 oracle on the host,
+    then one rank's 16 items: the first two must be bit-identical to the B=2 forward (shard-equivalence: concatenated shard outputs
+    == single-GPU output), and the batch is permutation-equivariant."""
+    seed = 4
+    net, arch, sd = _net(VITB, seed)
+    q, r = synth.make_inputs_shard(0, 16, 5, 518, 518, seed)
+    s2 = _run(net, q[:2], r[:2])
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads), torch.from_numpy(q[:2]), torch.from_numpy(r[:2]))["score_map_ref_cross"]
+    d = (s2.cpu() - ref).abs()
+    print(f"cfg4 B=2 vs oracle: MAE {float(d.mean()):.2e} max {float(d.max()):.2e}")
+    assert float(d.mean()) < MAE_TOL and float(d.max()) < MAX_TOL
+    s16 = _run(net, q, r)
+    assert s16.shape == (16, 518, 518)
+    assert torch.equal(s16[:2], s2)
+    # a rank's shard inside the global batch: items [8, 16) scored alone == the same items of the 16-item forward
+    s8 = _run(net, q[8:], r[8:])
+    assert torch.equal(s8, s16[8:])
+    _properties(net, q, r, s16)
+
+
+def test_cfg5_1036_batch2(golden_dir):
+    """BASELINE configs[4]: 1036x1036 query, 5 refs, bs=2 (T = 5477 encoder tokens per image, cross-attention 5476 x 27 380)."""
+    g = np.load(os.path.join(golden_dir, "g3_vits_1036_n5.npz"))
+    seed = int(g["seed"])
+    net, arch, sd = _net(VITS, seed)
+    q, r = synth.make_inputs_shard(0, 2, 5, 1036, 1036, seed)
+    score = _run(net, q, r)
+    assert score.shape == (2, 1036, 1036)
+    mae_rows, mae_grid, dmean = _check_compact(g, score[:1])
+    assert mae_rows < MAE_TOL and mae_grid < MAE_TOL and dmean < 5e-4, (mae_rows, mae_grid, dmean)
+    assert torch.equal(_run(net, q[1:], r[1:])[0], score[1])
+    _properties(net, q, r, score)
+
+
+def test_cfg1_predict_plumbing_518(tmp_path):
+    """BASELINE configs[0]: task/predict.py on a checkpoint, 1 query + 5 refs, short side 518 -- as a plumbing run of THIS build's
+    predict driver (540x720 PNGs -> 518x690 like MFR_subset_demo frames; image directory -> GPU input stage -> forward -> PNG / CSV)
+    checked against the oracle pipeline (oracle transforms + fp32 oracle forward on the host).  Seeded synthetic ViT-S weights in a
+    Lightning-layout checkpoint: the released checkpoint is a git-LFS pointer and MFR_subset_demo is not in the image."""
+    from PIL import Image
+
+    from crossscore_amd.predict import predict
+    from oracle import preprocess_oracle as po
+
+    base = tmp_path / "data" / "gaussian" / "mfr" / "res_540" / "s00000" / "test" / "ours_1000"
+    qd, rd = base / "renders", base / "gt"
+    qd.mkdir(parents=True)
+    rd.mkdir(parents=True)
+    rng = np.random.Generator(np.random.PCG64(1))
+    yy, xx = np.mgrid[0:540, 0:720]
+
+    def img(i):
+        a = np.stack([127 + 100 * np.sin(xx / (17.0 + i) + i), 127 + 100 * np.cos(yy / (23.0 + i)), (xx + yy + 31 * i) % 256], axis=2)
+        return (a + rng.normal(0, 8, a.shape)).clip(0, 255).astype(np.uint8)
+
+    Image.fromarray(img(0)).save(qd / "frame_00000.png")
+    for i in range(5):
+        Image.fromarray(img(i + 1)).save(rd / f"frame_{i:05}.png")
+    arch = CrossScoreNet(model_config()).arch
+    sd = synth.make_state_dict(arch, 1)
+    ckpt = tmp_path / "run" / "ckpt" / "synthetic.ckpt"
+    ckpt.parent.mkdir(parents=True)
+    torch.save({"state_dict": {"model." + k: torch.from_numpy(v) for k, v in sd.items()}}, ckpt)
+    cfg = load_config("default_predict", [f"data.dataset.query_dir={qd}", f"data.dataset.reference_dir={rd}", f"trainer.ckpt_path_to_load={ckpt}",
+                                          "data.neighbour_config.deterministic=True", "logger.predict.write.config.score_map_colour_mode=gray"])
+    t0 = time.perf_counter()
+    res = predict(cfg, now="RUN")
+    t_run = time.perf_counter() - t0
+    png = [f for f in res["files"] if "/score_map_ref_cross/" in f][0]
+    got = np.array(Image.open(png)).astype(np.float64) / 32767 - 1
+    assert got.shape == (518, 686)  # 690 // 14 * 14: trailing pixels dropped (HF modeling_dinov2.py:141-149)
+    q = po.preprocess_u8(np.array(Image.open(qd / "frame_00000.png")), (518, 690))[None]
+    r = np.stack([po.preprocess_u8(np.array(Image.open(rd / f"frame_{i:05}.png")), (518, 690)) for i in range(5)])[None]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), False, 0)["score_map_ref_cross"][0].numpy()
+    mae = float(np.abs(got - ref).mean())
+    print(json.dumps({"cfg1_score_map_mae_vs_oracle_pipeline": mae, "driver_wall_s": round(t_run, 2), "csv_row": res["rows"][0]}))
+    assert mae < MAE_TOL
+    assert abs(float(res["rows"][0][-1]) - float(ref.mean())) < 1e-3  # the per-image mean the CSV row carries

@@ -1,6 +1,7 @@
 """End-to-end parity of the HIP forward (CrossScoreNet -> C ABI -> gfx950 kernels) against the fp32 oracle and
 the committed golden vectors generated from the reference.  Tolerance (BASELINE.json north_star): score-map
-MAE < 1e-3 vs the fp32 reference (bf16 MFMA operands, fp32 accumulation / softmax / LayerNorm / output)."""
+MAE < 1e-3 vs the fp32 reference; SURVEY.md 8c's target for an fp32-output path is 2e-4, which the fp16-operand MFMA path
+(fp32 accumulation / softmax / LayerNorm / residual stream / output) meets with margin (measured 0.9e-4 - 1.2e-4)."""
 import dataclasses
 import os
 
@@ -15,8 +16,9 @@ from crossscore_amd.config import model_config  # noqa: E402
 from crossscore_amd.model import CrossScoreNet  # noqa: E402
 from oracle import crossscore_oracle as orc  # noqa: E402
 
-MAE_TOL = 1e-3
-MAX_TOL = 2.5e-2  # single-pixel worst case of a bf16-operand forward on peaky synthetic weights
+MAE_TOL = 1e-3     # the north-star bound
+MAE_TARGET = 2e-4  # SURVEY.md 8c target, asserted on the reference's own goldens and the real backbones
+MAX_TOL = 5e-3     # single-pixel worst case of an fp16-operand forward on peaky synthetic weights (measured 6e-4 - 8e-4)
 TINY = "synthetic/dinov2-tiny"
 
 
@@ -73,11 +75,8 @@ def test_tiny_flag_variants_vs_golden(golden_dir, name, over, cfgover):
     out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)
     torch.cuda.synchronize()
     mae, mx = _compare(out["score_map_ref_cross"], torch.from_numpy(g[name]))
-    # The 1e-3 bound is stated for the sigmoid (ssim, min=0) map of the real backbones.  d tanh/dx = 1 at 0 against 1/4 for
-    # the sigmoid, so the same pre-activation error (~4e-3 with bf16 operands) is 4x larger on the tanh map; without the
-    # short cut LayerNorm renormalises the raw attention output, which amplifies its bf16 error (measured 1.03e-3).
-    tol = {"tanh": 4e-3, "no_short_cut": 1.5e-3}.get(name, MAE_TOL)
-    assert mae < tol and mx < 2 * MAX_TOL, (name, mae, mx)
+    print(f"{name}: MAE {mae:.2e} max {mx:.2e}")
+    assert mae < MAE_TOL and mx < 2 * MAX_TOL, (name, mae, mx)  # one bound for every variant (tanh has 4x the sigmoid's slope)
 
 
 def _check_compact(g, score):
@@ -107,7 +106,7 @@ def test_full_size_vs_reference_goldens(golden_dir, name, backbone):
     torch.cuda.synchronize()
     mae_rows, mae_grid, dmean = _check_compact(g, out["score_map_ref_cross"])
     print(f"{name}: MAE(rows)={mae_rows:.2e} MAE(patch means)={mae_grid:.2e} |dmean|={dmean:.2e}")
-    assert mae_rows < MAE_TOL and mae_grid < MAE_TOL and dmean < 5e-4
+    assert mae_rows < MAE_TARGET and mae_grid < MAE_TARGET and dmean < 1e-4
     # fused per-image mean == mean of the map (the value the CSV writer consumes)
     assert (out["score_mean_ref_cross"] - out["score_map_ref_cross"].mean(dim=(-1, -2))).abs().max() < 1e-5
 
@@ -124,7 +123,7 @@ def test_tiny_shape_sweep_vs_oracle(B, N, H, W):
     ref = _oracle(arch, sd, q, r)["score_map_ref_cross"]
     assert tuple(out.shape) == tuple(ref.shape) == (B, 14 * (H // 14), 14 * (W // 14))
     mae, mx = _compare(out, ref)
-    assert mae < 1.5e-3 and mx < 2 * MAX_TOL, (mae, mx)  # tiny-backbone bound, see __graft_entry__.smoke
+    assert mae < MAE_TOL and mx < 2 * MAX_TOL, (mae, mx)
     again = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
     assert torch.equal(out, again)
 
@@ -150,7 +149,7 @@ def test_structured_images_vs_oracle():
     ref = _oracle(arch, sd, q, r)["score_map_ref_cross"]
     mae, mx = _compare(out, ref)
     print(f"structured images: score-map MAE {mae:.3e} max {mx:.3e}")
-    assert mae < 8e-4 and mx < MAX_TOL, (mae, mx)
+    assert mae < MAE_TARGET and mx < MAX_TOL, (mae, mx)
 
 
 def test_attention_weights_full_size_vs_oracle():
@@ -210,23 +209,31 @@ def test_calls_alternating_between_two_streams_do_not_race():
         assert torch.equal(g, want[k])
 
 
-def test_tail_precision_levels(golden_dir):
-    """Split-bf16 operands for the head + decoder FFN (default) must lower the error against the reference golden; every level
-    stays inside the 1e-3 bound and the plain-bf16 level keeps working."""
-    g = np.load(os.path.join(golden_dir, "g1_vits_518_n5.npz"))
-    net, arch, sd = _net("facebook/dinov2-small", int(g["seed"]))
-    q, r = synth.make_inputs(1, 5, 518, 518, int(g["seed"]))
-    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
-    mae = {}
-    for level in (0, 1, 2):
-        net.tail_precision = level
-        net._mark_dirty()
-        out = net(tq, tr, False, 0, False)["score_map_ref_cross"]
-        torch.cuda.synchronize()
-        mae[level] = _check_compact(g, out)[0]
-        assert mae[level] < MAE_TOL
-    print("score-map MAE by tail_precision:", mae)
-    assert mae[0] < 0.85 * mae[1] and mae[2] <= mae[0] * 1.05
+def test_fp16_operand_range_on_scaled_up_weights():
+    """16-bit MFMA operands are IEEE half: 11 significant bits, but finite only up to 65504.  What is stored as fp16 on this
+    path: LayerNorm outputs (bounded by sqrt(C)), q / k / v and the other projections' outputs, softmax probabilities, attention
+    outputs (convex combinations of v) and the MLP hidden (GELU output).  Scale the weights that feed the unbounded ones -- the
+    q/k/v projections x8 and fc1 x64, inputs x4 -- far beyond trained-model magnitudes (the oracle's hidden activations then
+    reach ~1e3..1e4, q/k ~1e2): the score map must stay finite and inside the parity bound against the fp32 oracle."""
+    net, arch, sd = _net(TINY, 21)
+    sd = {k: v.copy() for k, v in sd.items()}
+    for k in sd:
+        if k.startswith("backbone.encoder.layer."):
+            if ".attention.attention." in k:
+                sd[k] = sd[k] * 8.0
+            if ".mlp.fc1." in k:
+                sd[k] = sd[k] * 64.0
+    net.load_numpy_state_dict(sd)
+    q, r = synth.make_inputs(2, 3, 70, 84, 5)
+    q, r = q * 4.0, r * 4.0
+    taps = {}
+    ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), taps=taps)["score_map_ref_cross"]
+    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    mae, mx = _compare(out, ref)
+    print(f"scaled-up weights: MAE {mae:.2e} max {mx:.2e}")
+    assert mae < MAE_TOL, (mae, mx)
 
 
 def test_batch8_vits_matches_oracle_per_item_and_is_batch_invariant():
@@ -270,7 +277,7 @@ def test_reference_token_cache_is_bit_identical():
     full = net(tq, tr, True, 5, False)
     pool = torch.stack([tr[0, 0], tr[0, 1], tr[1, 0], tr[1, 1], tr[2, 1]])     # 5 distinct reference images
     tok = net.encode_references(pool)
-    assert tok.shape == (5, 5 * 7, arch.hidden) and tok.dtype == torch.bfloat16
+    assert tok.shape == (5, 5 * 7, arch.hidden) and tok.dtype == torch.float16
     idx = torch.tensor([[0, 1], [2, 3], [1, 4]], device="cuda")
     cached = net.forward_cached(tq, tok[idx], True, 5)
     torch.cuda.synchronize()

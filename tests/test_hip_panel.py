@@ -10,7 +10,7 @@ C, F = 384, 1536
 
 
 def _bf(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(torch.float16).to(torch.float32)
 
 
 def _norm(x, eps=1e-6):
@@ -24,7 +24,7 @@ def _make(M, seed, dev):
     rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
     x = rn(M, C, sc=2.0)
     x[:, 7] += 3.0  # a feature with a large mean, as DINOv2 residual streams have
-    o = rn(M, C).to(torch.bfloat16)
+    o = rn(M, C).to(torch.float16)
     w = dict(wo=rn(C, C, sc=C ** -0.5), ls1=rn(C, sc=0.3) + 1.0, bo=rn(C, sc=0.1), w1=rn(F, C, sc=C ** -0.5), g2=rn(C, sc=0.2) + 1.0,
              b1=rn(F, sc=0.5), w2=rn(C, F, sc=F ** -0.5), ls2=rn(C, sc=0.3) + 1.0, b2=rn(C, sc=0.1))
     return x, o, w

@@ -11,11 +11,10 @@ def t(fn, n=20):
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.time() - t0) / n * 1e3
-for tp in (0, 1):
-    net.tail_precision = tp; net._mark_dirty()
+for tp in (1,):
     tok = net.encode_references(tr.reshape(-1, 3, 518, 518)).reshape(8, 5, -1, net.arch.hidden)
     full = t(lambda: net(tq, tr, False, 0, False))
     cached = t(lambda: net.forward_cached(tq, tok))
     enc8 = t(lambda: net.encode_references(tq))
     enc40 = t(lambda: net.encode_references(tr.reshape(-1, 3, 518, 518)))
-    print(f"tail_precision={tp}: full {full:.2f} ms | cached (enc 8 + decoder) {cached:.2f} | encoder of 8 images {enc8:.2f} | of 40 {enc40:.2f} -> decoder+head ~ {cached - enc8:.2f} ms", flush=True)
+    print(f"full {full:.2f} ms | cached (enc 8 + decoder) {cached:.2f} | encoder of 8 images {enc8:.2f} | of 40 {enc40:.2f} -> decoder+head ~ {cached - enc8:.2f} ms", flush=True)

@@ -15,8 +15,8 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 import hip_helpers as hh
 dev = "cuda"
 MM = int(os.environ.get("CS_ABL_M", "65760"))
-shapes = {"qkv": (MM, 1152, 384, _lib.EPI_BIAS_BF16), "outproj": (MM, 384, 384, _lib.EPI_RESID_F32),
-          "fc1": (MM, 1536, 384, _lib.EPI_BIAS_GELU_BF16), "fc2": (MM, 384, 1536, _lib.EPI_RESID_F32)}
+shapes = {"qkv": (MM, 1152, 384, _lib.EPI_BIAS_F16), "outproj": (MM, 384, 384, _lib.EPI_RESID_F32),
+          "fc1": (MM, 1536, 384, _lib.EPI_BIAS_GELU_F16), "fc2": (MM, 384, 1536, _lib.EPI_RESID_F32)}
 names = {0: "full", 1: "no-epilogue", 2: "no-mfma", 4: "no-dma", 3: "dma-only", 6: "epilogue-only", 5: "mfma-only", 7: "empty"}
 only = os.environ.get("CS_ABL_SHAPES")
 if only: shapes = {k: v for k, v in shapes.items() if k in only.split(",")}
@@ -25,7 +25,7 @@ for sn, (M, N, K, epi) in shapes.items():
     A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
     b = torch.randn(N, device=dev)
     resid = torch.randn(M, N, device=dev) if epi == _lib.EPI_RESID_F32 else None
-    o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.bfloat16)
+    o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.float16)
     line = [f"{sn:8s} M={M} N={N} K={K}:"]
     for tall in [int(x) for x in os.environ.get("CS_ABL_NSUB", "3").split(",")]:
         os.environ["CS_GEMM_NSUB"] = str(tall)

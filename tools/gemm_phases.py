@@ -15,8 +15,8 @@ lib = _lib.load()
 lib.cs_gemm_dbg_set.argtypes = [C.c_void_p]; lib.cs_gemm_dbg_set.restype = C.c_int
 dev = "cuda"
 MM = int(os.environ.get("CS_ABL_M", "65536"))
-shapes = {"qkv": (MM, 1152, 384, _lib.EPI_BIAS_BF16), "outproj": (MM, 384, 384, _lib.EPI_RESID_F32),
-          "fc1": (MM, 1536, 384, _lib.EPI_BIAS_GELU_BF16), "fc2": (MM, 384, 1536, _lib.EPI_RESID_F32)}
+shapes = {"qkv": (MM, 1152, 384, _lib.EPI_BIAS_F16), "outproj": (MM, 384, 384, _lib.EPI_RESID_F32),
+          "fc1": (MM, 1536, 384, _lib.EPI_BIAS_GELU_F16), "fc2": (MM, 384, 1536, _lib.EPI_RESID_F32)}
 only = os.environ.get("CS_ABL_SHAPES")
 if only: shapes = {k: v for k, v in shapes.items() if k in only.split(",")}
 dbg = torch.zeros(512 * 4 * 8, dtype=torch.int64, device=dev)
@@ -26,7 +26,7 @@ for sn, (M, N, K, epi) in shapes.items():
     A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
     b = torch.randn(N, device=dev)
     resid = torch.randn(M, N, device=dev) if epi == _lib.EPI_RESID_F32 else None
-    o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.bfloat16)
+    o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.float16)
     for ab in [int(x) for x in os.environ.get("CS_ABL_MODES", "0").split(",")]:
         os.environ["CS_GEMM_ABLATE"] = str(ab)
         for _ in range(3):

@@ -14,16 +14,16 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
 for Mimgs in (48, 12):
     M = Mimgs * 1370
-    shapes = {"qkv": (M, 1152, 384, _lib.EPI_BIAS_BF16), "outproj": (M, 384, 384, _lib.EPI_RESID_F32),
-              "fc1": (M, 1536, 384, _lib.EPI_BIAS_GELU_BF16), "fc2": (M, 384, 1536, _lib.EPI_RESID_F32)}
+    shapes = {"qkv": (M, 1152, 384, _lib.EPI_BIAS_F16), "outproj": (M, 384, 384, _lib.EPI_RESID_F32),
+              "fc1": (M, 1536, 384, _lib.EPI_BIAS_GELU_F16), "fc2": (M, 384, 1536, _lib.EPI_RESID_F32)}
     for sn, (M, N, K, epi) in shapes.items():
         A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
         b = torch.randn(N, device=dev)
         resid = torch.randn(M, N, device=dev) if epi == _lib.EPI_RESID_F32 else None
-        o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.bfloat16)
+        o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.float16)
         t_us = timeit(lambda: hh.gemm(A, W, b, epi, resid=resid, out=o))
-        t_plain = timeit(lambda: hh.gemm(A, W, b, _lib.EPI_BIAS_BF16, out=o if o.dtype == torch.bfloat16 else None)) if False else 0
-        Wt = W.t().contiguous(); ob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        t_plain = timeit(lambda: hh.gemm(A, W, b, _lib.EPI_BIAS_F16, out=o if o.dtype == torch.float16 else None)) if False else 0
+        Wt = W.t().contiguous(); ob = torch.empty(M, N, device=dev, dtype=torch.float16)
         t_blas = timeit(lambda: torch.matmul(A, W.t(), out=ob))
         t_blas2 = timeit(lambda: torch.matmul(A, Wt, out=ob))
         fl = 2.0 * M * N * K
