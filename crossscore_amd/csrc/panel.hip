@@ -1,60 +1,72 @@
 // Encoder token-panel kernel for gfx950 (ViT-S: C = 384, MLP 4C = 1536): everything a DINOv2 layer does between its attention
-// and the next layer's QKV projection, in ONE launch, with the 4C hidden activations never leaving the register file.
+// and the next layer's QKV projection, in ONE launch, with the 4C hidden activations never leaving the CU.
 //
 //   x   += attn_o Wo'^T + bo'                       Dinov2SelfOutput + layer_scale1 + residual   (HF modeling_dinov2.py:249-252,365-370)
 //   x   += GELU(LN2(x) W1'^T + b1') W2'^T + b2'     norm2 + Dinov2MLP + layer_scale2 + residual  (HF:373-378, 293-297)
-//   u    = bf16((x - mean(x)) * rstd(x))            norm1 of the next layer (its gamma/beta live in that layer's packed Wqkv / bias)
+//   u    = f16((x - mean(x)) * rstd(x))             norm1 of the next layer (its gamma/beta live in that layer's packed Wqkv / bias)
 //
-// Replaces five launches of round 1 (out-proj GEMM, LayerNorm, fc1+GELU GEMM, fc2 GEMM, LayerNorm) and their HBM round trips:
-// per 65 760-row pass the 202 MB hidden write + 202 MB re-read, two fp32 LayerNorm re-reads and one fp32 read-modify-write go.
+// Replaces five launches of round 1 (out-proj GEMM, LayerNorm, fc1+GELU GEMM, fc2 GEMM, LayerNorm) and their HBM round trips.
 //
-// Structure ("flash-MLP"): a workgroup = 4 waves = 128 token rows, one wave per SIMD with the whole 512-register budget; a wave
-// owns 32 rows for the entire kernel.  MFMA v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand and the
-// activation fragment as the B operand, so D[n][m]: a lane (g = lane/16, m = lane%16) holds 4 consecutive output features
-// 16t+4g.. of token row m.  Because the C/D layout of one product is the B-operand layout of the next up to a permutation of the
-// contraction index (the weights are pre-packed with that permutation), the chain
-//      acc2 (x, fp32, 24x2 tiles) --LN--> xf (bf16 B fragments) --fc1--> acc1 --GELU--> hb (bf16 B fragment) --fc2--> acc2
-// needs no LDS traffic and no cross-lane movement at all: only weight fragments are read from LDS.
-// Weights stream HBM/L2 -> LDS by global_load_lds_dwordx4 as 24-KiB "units" (one unit = 48 MFMAs per wave) from an image that
-// was packed at finalize in exactly the LDS layout and consumption order (linear 1-KiB pieces: full-line requests), through a
-// 4-slot ring, two units in flight, counted s_waitcnt vmcnt + one raw s_barrier per unit.
-// The fc2 accumulators are INITIALISED with the residual rows (+ bias), so the residual add costs nothing and x is read once.
+// Structure: a workgroup = 8 waves = 128 token rows = 4 wave PAIRS; the two waves of a pair sit on the same SIMD (waves w and w+4)
+// and share 32 rows, with different roles:
+//   * the A wave (waves 0-3) owns fc1: it keeps norm2(x) of its 32 rows as 24 MFMA B fragments in registers, multiplies one
+//     32-wide hidden slice per "tick" (24 MFMAs) and runs the GELU of the PREVIOUS slice on the VALU between those MFMAs; the
+//     activated slice goes to its partner through a 2-KiB LDS slot as two ready-made B fragments;
+//   * the B wave (waves 4-7) owns the residual rows: 32 x 384 fp32 accumulators (192 registers).  It does the attention output
+//     projection onto them, LayerNorm (hands norm2(x) to the A wave through LDS), then one fc2 slice per tick (24 MFMAs),
+//     two ticks behind the A wave, and finally writes x and the next layer's normalised rows.
+// So every SIMD has one VALU-heavy and one MFMA/LDS-only instruction stream feeding the same matrix pipe (the one-wave-per-SIMD
+// version of this kernel was issue-bound: MFMA issue + GELU + LDS-DMA issue of ONE wave exceeded the MFMA pipe time 1.6x).
+// MFMA v_mfma_f32_32x32x16_f16, WEIGHT fragment = A operand (32 output features x 16 k), activation fragment = B operand
+// (16 k x 32 token rows): D[feature][row], a lane (j = lane & 31, h = lane >> 5) holds, for token row j, the 16 features
+// rho(h, r) = (r & 3) + 8 (r >> 2) + 4 h.  A D tile is the B operand of the next product up to the fixed permutation
+// kappa(h, e) = (e & 3) + 8 (e >> 2) + 4 h of the contraction index inside a 16-wide k-step, which the packed weights carry, so
+// LN output -> fc1 and GELU output -> fc2 need no cross-lane movement.
+// Weights stream L2 -> LDS by global_load_lds_dwordx4 as 24-KiB chunks (= 24 fragments of 1 KiB, stored in the order and the
+// lane-linear layout they are read in: every ds_read_b128 / LDS-DMA piece is 64 lanes x 16 contiguous bytes, no swizzle needed)
+// through a 3-slot ring, two chunks in flight, counted s_waitcnt vmcnt + one raw s_barrier per chunk.  A chunk is one half tick:
+// [12 fragments for the A waves (half the K range of an fc1 slice) | 12 for the B waves (6 of the 12 output tiles of an fc2 slice)].
 #include "cs_common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
 namespace {
 
-constexpr int PC = 384;             // hidden size
-constexpr int PF = 1536;            // MLP hidden
-constexpr int NT = PC / 16;         // 24 output tiles of 16 features
-constexpr int KS = PC / 32;         // 12 k-steps over C
-constexpr int NSL = PF / 32;        // 48 hidden slices of 32
-constexpr int UNIT = 24 * 1024;     // bytes per weight unit: 24 pieces of 16 rows x 64 B
-constexpr int NSLOT = 4;            // ring slots
-constexpr int AHEAD = 2;            // units in flight; slot (u+AHEAD)%4 was last read two barriers ago
-constexpr int DPW = 6;              // LDS-DMA instructions per wave per unit
-constexpr int LDS_B1 = NSLOT * UNIT;
-constexpr int LDS_BYTES = LDS_B1 + PF * 4;  // 102 KiB: one workgroup per CU (the register file admits only one anyway)
+constexpr int PC = 384;               // hidden size
+constexpr int PF = 1536;              // MLP hidden
+constexpr int NT = PC / 32;           // 12 output tiles of 32 features
+constexpr int KS = PC / 16;           // 24 k-steps over C
+constexpr int NSL = PF / 32;          // 48 hidden slices of 32
+constexpr int FRAG = 1024;            // bytes of one MFMA operand fragment (64 lanes x 16 B)
+constexpr int CHUNK = 24 * FRAG;      // ring chunk
+constexpr int NSLOT = 3;
+constexpr int OUT_CHUNKS = KS / 2;    // out-projection: 12 chunks of two k-steps x 12 tiles
+constexpr int LAG = 4;                // half ticks the fc2 side runs behind the fc1 side
+constexpr int MLP_CHUNKS = 2 * NSL + LAG;  // 100 half ticks
+constexpr int PAD_CHUNKS = 2;         // fetched by the last transitions, never read
 constexpr int PANEL_ROWS = 128;
-constexpr int OUT_UNITS = KS;       // out-projection: 12 units of 32 output features
-constexpr int MLP_UNITS = 2 * NSL;  // 96
+// LDS map
+constexpr int LDS_RING = 0;
+constexpr int LDS_R = NSLOT * CHUNK;                 // 48 KiB: norm2(x) hand-off, 12 fragments per pair at a time
+constexpr int LDS_HB = LDS_R + 4 * 12 * FRAG;        // 2 slots x 4 pairs x 2 fragments
+constexpr int LDS_B1 = LDS_HB + 2 * 4 * 2 * FRAG;    // fc1 bias, fp32
+constexpr int LDS_BYTES = LDS_B1 + PF * 4;           // 142 KiB
 
 #define CS_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define CS_SB() __builtin_amdgcn_sched_barrier(0) /* nothing crosses (any other mask let hipcc move MFMAs over the asm waits) */
+#define CS_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); CS_SB(); } while (0)
 
+template <int V> using IC = std::integral_constant<int, V>;
 template <int... Js, class F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F&& f) {
-  (f(std::integral_constant<int, Js>{}), ...);
+  (f(IC<Js>{}), ...);
 }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { static_for(std::make_integer_sequence<int, N>{}, f); }
 
-__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes (g = 0..3) that share a token row
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
-
-// exact-erf GELU, same degree-7 minimax fit of Phi as gelu_erf4 (cs_common.h), one value per call in plain fma form: in this
-// kernel the VALU work shares ONE wave's issue stream with the MFMAs, so it must be schedulable instruction by instruction
+// exact-erf GELU, the degree-7 minimax fit of Phi of cs_common.h (gelu_erf4), one value per call in plain fma form: in the A wave the
+// VALU work shares the wave's issue stream with its MFMAs, so it must be schedulable instruction by instruction
 __device__ __forceinline__ float gelu_erf1(float x) {
   const float c = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f);
   const float t = c * c;
@@ -68,329 +80,429 @@ __device__ __forceinline__ float gelu_erf1(float x) {
   return x * fmaf(c, q, 0.5f);
 }
 
-template <bool OUTPROJ>
-__global__ __launch_bounds__(256, 1) void cs_panel_kernel(CsPanelParams p) {
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t pack8(const float (&v)[8]) {
+  return u32x4_t{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7])};
+}
+
+// ---- inline-asm LDS access of the regions the LDS-DMA also writes or that cross waves (hipcc would order every compiler-visible LDS
+//      access against the DMA with vmcnt(0)); results are retired by the counted CS_LGKM waits of the callers ----
+__device__ __forceinline__ void keep_alive(const h16x8_t& w) { asm volatile("" ::"v"(w)); }  // (ablation builds: rule 17)
+template <int OFF, bool SKIP = false>
+__device__ __forceinline__ void lds_read3(unsigned addr, h16x8_t (&w)[3]) {
+  if constexpr (SKIP) { asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : "v"(addr)); return; }
+  asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6"
+               : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]) : "v"(addr), "n"(OFF), "n"(OFF + FRAG), "n"(OFF + 2 * FRAG) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read1(unsigned addr, h16x8_t& w) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_f4(unsigned addr, f32x4_t& w) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write16(unsigned addr, u32x4_t v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
+// One LDS-DMA piece = one fragment: 64 lanes x 16 B from `src + OFF` (this lane's address) to the wave-uniform LDS address `dst + OFF`
+// (the instruction's immediate offset applies to both addresses)
+template <int OFF>
+__device__ __forceinline__ void dma_piece(const char* src, unsigned dst) {
+  __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(src), (__attribute__((address_space(3))) void*)(size_t)dst, 16, OFF, 0);
+}
+
+// ABL: timing-only ablations (tools/panel_ablate.py builds them with -DCS_PANEL_ABLATE; results are wrong by design):
+//   1 no GELU arithmetic, 2 no LDS-DMA after the prologue, 4 A waves skip their MFMAs, 8 B waves skip theirs, 16 no s_barrier per chunk,
+//   32 no weight-fragment LDS reads
+template <bool OUTPROJ, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, m = lane & 15;
-  const int row0 = blockIdx.x * PANEL_ROWS + wv * 32;
-  constexpr int NU = (OUTPROJ ? OUT_UNITS : 0) + MLP_UNITS;
+  const bool is_a = wv < 4;
+  const int pair = wv & 3;
+  const int j = lane & 31, h = lane >> 5;
+  const int row0 = blockIdx.x * PANEL_ROWS + pair * 32;
+  constexpr int NOUT = OUTPROJ ? OUT_CHUNKS : 0;
+  // Chunks below SOLO are copied by the A waves alone (6 pieces each): during the out-projection the B waves have ordinary global
+  // loads in flight, which share the vmcnt queue with LDS-DMA.  From SOLO on: A waves 2 pieces, B waves 4.
+  constexpr int SOLO = NOUT + 3;
+  const unsigned lds0 = (unsigned)(size_t)CS_LDS_PTR(smem);
+  const unsigned lane16 = lane * 16;
+  const char* img = reinterpret_cast<const char*>(p.img) + lane16;
 
-  // ---- weight stream: wave w copies pieces w, w+4, .. of each unit; the image is linear, so lane i moves bytes [16i, 16i+16)
-  //      of its piece to the same offset of the slot (whole 1-KiB requests) ----
-  const char* img = reinterpret_cast<const char*>(p.img) + wv * 1024 + lane * 16;
-  auto issue = [&](int u) {
-    const char* src = img + (size_t)u * UNIT;
-    char* dst = smem + (u & (NSLOT - 1)) * UNIT + wv * 1024;
-#pragma unroll
-    for (int q = 0; q < DPW; ++q)
-      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(src + q * 4096), CS_LDS_PTR(dst + q * 4096), 16, 0, 0);
+  int c_next = 0;    // next chunk to make current
+  int slot_cur = 0;  // ring slot of chunk c_next
+  auto ring_issue = [&](auto ISA_, int c, int slot) {
+    constexpr bool ISA = decltype(ISA_)::value;
+    const unsigned dst = lds0 + LDS_RING + slot * CHUNK;
+    const char* s = img + (size_t)c * CHUNK;
+    if (c < SOLO) {
+      if constexpr (ISA) {
+        const char* s6 = s + pair * 6 * FRAG;
+        const unsigned d6 = dst + pair * 6 * FRAG;
+        dma_piece<0>(s6, d6); dma_piece<FRAG>(s6, d6); dma_piece<2 * FRAG>(s6, d6); dma_piece<3 * FRAG>(s6, d6);
+        dma_piece<0>(s6 + 4 * FRAG, d6 + 4 * FRAG); dma_piece<FRAG>(s6 + 4 * FRAG, d6 + 4 * FRAG);
+      }
+    } else if constexpr (ISA) {
+      dma_piece<0>(s + pair * 2 * FRAG, dst + pair * 2 * FRAG);
+      dma_piece<FRAG>(s + pair * 2 * FRAG, dst + pair * 2 * FRAG);
+    } else {
+      const char* s4 = s + (8 + pair * 4) * FRAG;
+      const unsigned d4 = dst + (8 + pair * 4) * FRAG;
+      dma_piece<0>(s4, d4); dma_piece<FRAG>(s4, d4); dma_piece<2 * FRAG>(s4, d4); dma_piece<3 * FRAG>(s4, d4);
+    }
   };
-  issue(0);
-  issue(1);
-
-  // fc1 bias (LN2 beta folded in) -> LDS once per workgroup
-  for (int i = tid; i < PF / 4; i += 256)
-    reinterpret_cast<f32x4_t*>(smem + LDS_B1)[i] = reinterpret_cast<const f32x4_t*>(p.b1)[i];
-
-  f32x4_t acc2[NT][2];  // residual rows / fc2 accumulators: tile nt = features 16nt.., row tile mt
-  h16x8_t xf[2][KS];   // B fragments of the current GEMM input (attention output, then norm2(x))
-
-  // ---- unit / batch machinery -----------------------------------------------------------------------------------------------
-  // A unit is consumed as 4 batches of 6 weight fragments (12 MFMAs per batch).  The wave is alone on its SIMD, so LDS latency
-  // is hidden by the wave itself: the reads of batch k+1 are issued before the MFMAs of batch k, and waited for with a COUNTED
-  // lgkmcnt one batch (>= 192 MFMA cycles) later.  hipcc only ever emits lgkmcnt(0) around LDS-DMA kernels, so the ring reads
-  // and their waits are inline asm (form (iii) of the guide: "=&v" loads, a wait-only statement, then sched_barrier(0) that keeps
-  // the consuming MFMAs below the wait).  Every step is therefore its own scheduling region [12 MFMAs + a slice of the GELU
-  // arithmetic], inside which hipcc interleaves VALU and MFMA.
-  // The transition to the next unit (counted vmcnt, barrier, LDS-DMA of the unit two ahead) happens before the LAST batch of the
-  // current unit is multiplied, so the first reads of a unit are also a batch ahead of their use.
-  // per-lane address of its weight-fragment row inside a unit: row m of a 16-row x 64-B piece, 16-byte chunk g XOR-swizzled
-  // exactly as the packed image is (conflict-free ds_read_b128, see cs_panel_pack_kernel)
-  const unsigned lane_base = (unsigned)(size_t)CS_LDS_PTR(smem) + m * 64 + ((g ^ (((m >> 2) & 1) << 1)) << 4);
-  const unsigned bias_base = (unsigned)(size_t)CS_LDS_PTR(smem) + LDS_B1 + 16 * g;
-  int u_next = 0;  // next unit to make current
-  auto transition = [&](auto LAST_) -> unsigned {
-    CS_VMCNT(DPW * (AHEAD - 1));
-    __builtin_amdgcn_s_barrier();  // every wave's pieces of unit u_next landed; everyone finished reading unit u_next-2
+  // transition into chunk c_next: this wave's LDS reads of the previous chunk are complete (its slot is about to be refilled) and its
+  // own LDS-DMA pieces of chunk c_next have landed; barrier (the same holds for every wave); then the chunk two ahead goes into the slot
+  // of the previous chunk.  Returns this lane's LDS address of fragment 0 of the now-current chunk.
+  auto transition = [&](auto ISA_) -> unsigned {
+    constexpr bool ISA = decltype(ISA_)::value;
+    CS_SB();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (ISA) {
+      if (c_next <= SOLO - 2) CS_VMCNT(6); else CS_VMCNT(2);
+    } else {
+      CS_VMCNT(4);
+    }
+    if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue(u_next + AHEAD);  // the image ends with AHEAD padding units, so the stream never needs a tail case
-    const unsigned sl = lane_base + (u_next & (NSLOT - 1)) * UNIT;
-    ++u_next;
-    return sl;
+    int s2 = slot_cur + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2;
+    if constexpr (!(ABL & 2)) ring_issue(ISA_, c_next + 2, s2);  // the image ends with PAD_CHUNKS, so the stream needs no tail case
+    const unsigned base = lds0 + LDS_RING + slot_cur * CHUNK + lane16;
+    ++c_next;
+    slot_cur = slot_cur + 1 >= NSLOT ? 0 : slot_cur + 1;
+    CS_SB();  // (rule: register-only MFMAs must not be scheduled above the waits of this statement)
+    return base;
   };
-#define CS_SB() __builtin_amdgcn_sched_barrier(0)  /* nothing crosses (any other mask let hipcc move MFMAs over the asm waits) */
-  auto read6 = [&](unsigned sl, auto B_, h16x8_t (&w)[6]) {
-    constexpr int O = decltype(B_)::value * 6 * 1024;
-    asm volatile("ds_read_b128 %0, %6 offset:%7\n\tds_read_b128 %1, %6 offset:%8\n\tds_read_b128 %2, %6 offset:%9\n\t"
-                 "ds_read_b128 %3, %6 offset:%10\n\tds_read_b128 %4, %6 offset:%11\n\tds_read_b128 %5, %6 offset:%12"
-                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
-                 : "v"(sl), "n"(O), "n"(O + 1024), "n"(O + 2048), "n"(O + 3072), "n"(O + 4096), "n"(O + 5120)
-                 : "memory");
-  };
-  auto read_bias = [&](int slice, f32x4_t (&bb)[2]) {
-    const unsigned a = bias_base + slice * 128;
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(bb[0]), "=&v"(bb[1]) : "v"(a) : "memory");
-  };
-#define CS_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); CS_SB(); } while (0)
-  // fc1-type batch B: pieces 6B..6B+5 = (jt, ks) pairs; D tile (jt, mt) += W piece x xf[mt][ks]
-  auto mm_fc1 = [&](auto B_, auto INIT_, const h16x8_t (&w)[6], f32x4_t (&a0)[2], f32x4_t (&a1)[2], const f32x4_t (&bb)[2]) {
-    constexpr int B = decltype(B_)::value;
-    constexpr bool INIT = decltype(INIT_)::value;  // the accumulators start at bb (fc1 bias); else they keep accumulating
+  using TA = std::true_type;
+  using TB = std::false_type;
+
+  if (is_a) {
+    // =====================================================================================================================
+    // A wave: LDS-DMA for the out-projection phase, then fc1 + GELU
+    // =====================================================================================================================
+    // fc1 bias (LN2 beta folded in) -> LDS once per workgroup (the A waves are idle here)
+    for (int i = tid; i < PF / 4; i += 256)
+      reinterpret_cast<f32x4_t*>(smem + LDS_B1)[i] = reinterpret_cast<const f32x4_t*>(p.b1)[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ring_issue(TA{}, 0, 0);
+    ring_issue(TA{}, 1, 1);
+    unsigned cur = transition(TA{});                       // chunk 0
+    for (int c = 0; c < NOUT; ++c) cur = transition(TA{});  // the B waves multiply chunks 0 .. NOUT-1; `cur` ends at chunk NOUT
+    // ---- norm2(x) from the partner: two halves of 12 fragments through the R region ----
+    h16x8_t xf[KS];
+    const unsigned r_addr = lds0 + LDS_R + pair * 12 * FRAG + lane16;
+    __builtin_amdgcn_s_barrier();  // H1: first half written
+    sfor<12>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(r_addr, xf[decltype(F_)::value]); });
+    CS_LGKM(0);
+    __builtin_amdgcn_s_barrier();  // H2: first half read
+    __builtin_amdgcn_s_barrier();  // H3: second half written
+    sfor<12>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(r_addr, xf[12 + decltype(F_)::value]); });
+    CS_LGKM(0);
+
+    // ---- fc1 ticks.  Tick t: acc(t & 1) = b1 + W1[slice t] . xf (two half ticks = two chunks of 12 fragments); GELU of slice t-1
+    //      (the other accumulator) rides between the MFMAs and leaves as two B fragments in hb slot (t-1) & 1 ----
+    f32x16_t acE, acO;  // even / odd slices
+    const unsigned bias_addr = lds0 + LDS_B1 + 16 * h;
+    const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
+    float gv[8];
+    h16x8_t wa[3], wb[3];
+    auto gelu2 = [&](auto V0_, const f32x16_t& src) {  // values V0, V0+1 of the slice being activated
+      constexpr int V0 = decltype(V0_)::value;
+      gv[V0 & 7] = (ABL & 1) ? src[V0] : gelu_erf1(src[V0]);
+      gv[(V0 + 1) & 7] = (ABL & 1) ? src[V0 + 1] : gelu_erf1(src[V0 + 1]);
+    };
+    auto hb_store = [&](int slot, auto S_) { lds_write16<decltype(S_)::value * FRAG>(hb_addr + slot * (4 * 2 * FRAG), pack8(gv)); };
+    auto mm3 = [&](auto K0_, const h16x8_t (&w)[3], f32x16_t& acc) {
+      constexpr int K0 = decltype(K0_)::value;
+      if constexpr (ABL & 4) { keep_alive(w[0]); keep_alive(w[1]); keep_alive(w[2]); return; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int pc = 6 * B + i, jt = pc / KS, ks = pc % KS;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        f32x4_t& d = jt == 0 ? a0[mt] : a1[mt];
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], xf[mt][ks], (INIT && ks == 0) ? bb[jt] : d, 0, 0, 0);
+      for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i], xf[K0 + i], acc, 0, 0, 0);
+    };
+    // One half tick: 12 fragments in 4 batches of 3; the reads of batch k+1 are in flight under the MFMAs of batch k, the transition to
+    // the next chunk (and the first reads of it) happens before the last batch.  P = 0: k-steps 0..11, GELU values 0..7 (-> hb fragment
+    // 0); P = 1: k-steps 12..23, values 8..15 in the first two batches, hb fragment 1 before the transition (the partner reads it after).
+    auto half_tick = [&](auto P_, auto FC1_, f32x16_t& acc, const f32x16_t& act, int hb_slot) {
+      constexpr int P = decltype(P_)::value;
+      constexpr bool FC1 = decltype(FC1_)::value;
+      if constexpr (FC1) { lds_read3<3 * FRAG, (ABL & 32) != 0>(cur, wb); CS_LGKM(3); }
+      if constexpr (P == 0) { gelu2(IC<0>{}, act); gelu2(IC<2>{}, act); }
+      else { gelu2(IC<8>{}, act); gelu2(IC<10>{}, act); gelu2(IC<12>{}, act); }
+      if constexpr (FC1) mm3(IC<12 * P + 0>{}, wa, acc);
+      CS_SB();
+      if constexpr (FC1) { lds_read3<6 * FRAG, (ABL & 32) != 0>(cur, wa); CS_LGKM(3); }
+      if constexpr (P == 0) { gelu2(IC<4>{}, act); }
+      else { gelu2(IC<14>{}, act); }
+      if constexpr (FC1) mm3(IC<12 * P + 3>{}, wb, acc);
+      CS_SB();
+      if constexpr (FC1) { lds_read3<9 * FRAG, (ABL & 32) != 0>(cur, wb); CS_LGKM(3); }
+      if constexpr (P == 0) { gelu2(IC<6>{}, act); hb_store(hb_slot, IC<0>{}); }
+      else { hb_store(hb_slot, IC<1>{}); }
+      if constexpr (FC1) mm3(IC<12 * P + 6>{}, wa, acc);
+      CS_SB();
+      cur = transition(TA{});  // waits for every LDS operation of this wave first (batch 3's fragments, the hb store)
+      if constexpr (FC1) {
+        lds_read3<0, (ABL & 32) != 0>(cur, wa);
+        mm3(IC<12 * P + 9>{}, wb, acc);
+        CS_SB();
       }
+    };
+    auto bias_init = [&](f32x16_t& acc, int t) {
+      f32x4_t b4[4];
+      const unsigned a = bias_addr + t * 128;
+      lds_read_f4<0>(a, b4[0]); lds_read_f4<32>(a, b4[1]); lds_read_f4<64>(a, b4[2]); lds_read_f4<96>(a, b4[3]);
+      CS_LGKM(0);  // (also retires the first fragments of the chunk: they are older)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q + i] = b4[q][i];
+    };
+    lds_read3<0, (ABL & 32) != 0>(cur, wa);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acO[i] = 0.f;  // tick 0 "activates" this (slice -1: never read by the partner)
+    for (int t = 0; t < NSL; t += 2) {
+      bias_init(acE, t);
+      half_tick(IC<0>{}, std::true_type{}, acE, acO, 1);
+      half_tick(IC<1>{}, std::true_type{}, acE, acO, 1);
+      bias_init(acO, t + 1);
+      half_tick(IC<0>{}, std::true_type{}, acO, acE, 0);
+      half_tick(IC<1>{}, std::true_type{}, acO, acE, 0);
     }
-    CS_SB();
-  };
-  auto mm_fc2 = [&](auto B_, const h16x8_t (&w)[6], const h16x8_t (&hb)[2]) {
-    constexpr int B = decltype(B_)::value;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        acc2[6 * B + i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], hb[mt], acc2[6 * B + i][mt], 0, 0, 0);
-    CS_SB();
-  };
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  using B2 = std::integral_constant<int, 2>;
-  using B3 = std::integral_constant<int, 3>;
-  using NotLast = std::false_type;
-  using Last = std::true_type;
-
-  // ---- prologue: this wave's 32 rows of the residual stream into the fc2 accumulator layout ----
-  const size_t r_mt[2] = {(size_t)min(row0 + m, p.M - 1), (size_t)min(row0 + 16 + m, p.M - 1)};
-  if constexpr (OUTPROJ) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const h16x8_t*>(p.attn_o + r_mt[mt] * PC + 32 * ks + 8 * g);
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (OUTPROJ) b4 = *reinterpret_cast<const f32x4_t*>(p.bo + 16 * nt + 4 * g);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = *reinterpret_cast<const f32x4_t*>(p.x + r_mt[mt] * PC + 16 * nt + 4 * g) + b4;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's b1 writes are in LDS before the first barrier
-
-  // (inline-asm read results must never stay in flight across compiler-scheduled code such as the LayerNorm below: hipcc counts
-  //  them as written at the end of the asm statement and copies / spills them before the data has landed)
-  h16x8_t wa[6], wb[6];  // the two fragment batches in flight
-  unsigned sl = transition(NotLast{});
-
-  // ---- attention output projection: 12 units of 32 output features, accumulated straight onto the residual rows ----
-  if constexpr (OUTPROJ) {
-    const f32x4_t nob[2] = {};
-    read6(sl, B0{}, wa);
-    static_for(std::make_integer_sequence<int, OUT_UNITS>{}, [&](auto U_) {
-      constexpr int U = decltype(U_)::value;
-      read6(sl, B1{}, wb); CS_LGKM(6); mm_fc1(B0{}, NotLast{}, wa, acc2[2 * U], acc2[2 * U], nob);   // batches 0,1 are tile jt = 0
-      read6(sl, B2{}, wa); CS_LGKM(6); mm_fc1(B1{}, NotLast{}, wb, acc2[2 * U], acc2[2 * U], nob);
-      read6(sl, B3{}, wb); CS_LGKM(6); mm_fc1(B2{}, NotLast{}, wa, acc2[2 * U + 1], acc2[2 * U + 1], nob);  // batches 2,3 are tile jt = 1
-      sl = transition(NotLast{});
-      if constexpr (U + 1 < OUT_UNITS) { read6(sl, B0{}, wa); CS_LGKM(6); }
-      else CS_LGKM(0);
-      mm_fc1(B3{}, NotLast{}, wb, acc2[2 * U + 1], acc2[2 * U + 1], nob);
-    });
+    // tick NSL: only the GELU of the last slice (odd)
+    CS_LGKM(0);
+    half_tick(IC<0>{}, std::false_type{}, acE, acO, 1);
+    half_tick(IC<1>{}, std::false_type{}, acE, acO, 1);
+    // the B waves' last tick
+    cur = transition(TA{});
+    CS_VMCNT(0);  // the padding chunks' LDS-DMA has landed before the workgroup can end
+    return;
   }
 
-  // ---- LayerNorm statistics of the rows held in acc2 (two-pass, fp32, in registers) ----
-  auto row_stats = [&](float (&mean)[2], float (&rstd)[2]) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float s = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) s += (acc2[nt][mt][0] + acc2[nt][mt][1]) + (acc2[nt][mt][2] + acc2[nt][mt][3]);
-      mean[mt] = quad_sum(s) * (1.0f / PC);
-      float q = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const f32x4_t d = acc2[nt][mt] - mean[mt];
-        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-      }
-      rstd[mt] = 1.0f / sqrtf(quad_sum(q) * (1.0f / PC) + p.eps);
-    }
-  };
-
-  // ---- norm2 -> fc1 B fragments.  k-slot j of k-step ks is feature 32ks + 4g + j (j < 4) or 32ks + 16 + 4g + j-4: the packed
-  //      W1 uses the same order, so the accumulator registers ARE the fragment (no data movement) ----
+  // =======================================================================================================================
+  // B wave: residual rows; out-projection, LayerNorm hand-off, fc2, epilogue
+  // =======================================================================================================================
+  f32x16_t acc2[NT];
+  const size_t row = (size_t)min(row0 + j, p.M - 1);
+  const bool row_ok = row0 + j < p.M;
   {
-    float mean[2], rstd[2];
-    row_stats(mean, rstd);
+    const float* xr = p.x + row * PC + 4 * h;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int T = 0; T < NT; ++T)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const f32x4_t a = (acc2[2 * ks][mt] - mean[mt]) * rstd[mt], b = (acc2[2 * ks + 1][mt] - mean[mt]) * rstd[mt];
-        const uint4 pk = {pack_h16x2(a[0], a[1]), pack_h16x2(a[2], a[3]), pack_h16x2(b[0], b[1]), pack_h16x2(b[2], b[3])};
-        xf[mt][ks] = __builtin_bit_cast(h16x8_t, pk);
+      for (int q = 0; q < 4; ++q) {
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(xr + 32 * T + 8 * q);
+        if constexpr (OUTPROJ) v += *reinterpret_cast<const f32x4_t*>(p.bo + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc2[T][4 * q + i] = v[i];
       }
+  }
+  h16x8_t wa[3], wb[3];
+  unsigned cur = transition(TB{});  // chunk 0
+  if constexpr (OUTPROJ) {
+    // ---- attention output projection: chunk c = k-steps 2c, 2c+1 x 12 output tiles (fragment 12 ksl + T); the B fragment of a k-step
+    //      is this lane's 16 contiguous bytes of its attention-output row ----
+    const h16_t* orow = p.attn_o + row * PC + 8 * h;
+    h16x8_t of0 = *reinterpret_cast<const h16x8_t*>(orow), of1 = *reinterpret_cast<const h16x8_t*>(orow + 16);
+    lds_read3<0, (ABL & 32) != 0>(cur, wa);
+    for (int c = 0; c < OUT_CHUNKS; ++c) {
+      const int cn = min(c + 1, OUT_CHUNKS - 1);
+      const h16x8_t nf0 = *reinterpret_cast<const h16x8_t*>(orow + 32 * cn), nf1 = *reinterpret_cast<const h16x8_t*>(orow + 32 * cn + 16);
+      sfor<8>([&](auto B_) {
+        constexpr int B = decltype(B_)::value;  // batch: fragments 3B .. 3B+2
+        h16x8_t(&wc)[3] = (B & 1) ? wb : wa;
+        h16x8_t(&wn)[3] = (B & 1) ? wa : wb;
+        if constexpr (B < 7) {
+          lds_read3<(3 * B + 3) * FRAG, (ABL & 32) != 0>(cur, wn);
+          CS_LGKM(3);
+        } else {
+          cur = transition(TB{});
+          lds_read3<0, (ABL & 32) != 0>(cur, wn);
+          CS_SB();
+        }
+        sfor<3>([&](auto I_) {
+          constexpr int F = 3 * B + decltype(I_)::value, T = F % 12;
+          if constexpr (ABL & 8) keep_alive(wc[decltype(I_)::value]);
+          else acc2[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[decltype(I_)::value], F < 12 ? of0 : of1, acc2[T], 0, 0, 0);
+        });
+        CS_SB();
+      });
+      of0 = nf0; of1 = nf1;
+    }
+    CS_LGKM(0);  // (the last transition's reads took the A half of chunk NOUT: unused)
+  }
+
+  // ---- LayerNorm statistics of the rows held in acc2 (two-pass, fp32, in registers; a row lives in lanes j and j + 32) ----
+  auto row_stats = [&](float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) s += (acc2[T][r] + acc2[T][r + 1]) + (acc2[T][r + 2] + acc2[T][r + 3]);
+    s += __shfl_xor(s, 32, 64);
+    mean = s * (1.0f / PC);
+    float q = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = acc2[T][r] - mean;
+        q = fmaf(d, d, q);
+      }
+    q += __shfl_xor(q, 32, 64);
+    rstd = 1.0f / sqrtf(q * (1.0f / PC) + p.eps);
+  };
+  {
+    // norm2 -> the partner's fc1 B fragments: k-step 2T + s is registers 8s .. 8s+7 of tile T (kappa order, see the header)
+    float mean, rstd;
+    row_stats(mean, rstd);
+    const float nb = -mean * rstd;
+    const unsigned r_addr = lds0 + LDS_R + pair * 12 * FRAG + lane16;
+    auto put = [&](auto T_, auto S_) {
+      constexpr int T = decltype(T_)::value, S = decltype(S_)::value;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(acc2[T][8 * S + e], rstd, nb);  // (not (x - mean) * rstd: the 192 differences of the variance pass would be kept alive)
+      lds_write16<((2 * T + S) % 12) * FRAG>(r_addr, pack8(v));
+    };
+    sfor<6>([&](auto T_) { put(T_, IC<0>{}); put(T_, IC<1>{}); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // H1
+    __builtin_amdgcn_s_barrier();  // H2
+    sfor<6>([&](auto T_) { put(IC<6 + decltype(T_)::value>{}, IC<0>{}); put(IC<6 + decltype(T_)::value>{}, IC<1>{}); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // H3
   }
   // the fc2 accumulators start at residual + bias: the residual add and the bias add are free
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.b2 + 16 * nt + 4 * g);
+  for (int T = 0; T < NT; ++T)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] += b4;
-  }
-
-  // ---- MLP: hidden slice i = 32 hidden units.  fc1 (one unit: 32 hidden x 384) -> acc1; GELU + bf16 pack -> hb; fc2 (one unit:
-  //      384 out x 32 hidden) accumulates into acc2.  Software pipeline inside the wave: fc1(i) | GELU(i-1) | fc2(i-2) are
-  //      independent, so the GELU arithmetic of slice i-1 (16 values per lane) is cut into 8 pieces of 2 values, one per step of
-  //      the two units of an iteration, and fills VALU issue slots between the MFMAs of the other two. ----
-  f32x4_t ac0[2][2], ac1[2][2], bb0[2], bb1[2];
-  h16x8_t hb0[2], hb1[2];
-  float gt[8];  // GELU results of the row tile in progress
-  using Q0 = std::integral_constant<int, 0>;
-  using Q1 = std::integral_constant<int, 1>;
-  using Q2 = std::integral_constant<int, 2>;
-  using Q3 = std::integral_constant<int, 3>;
-  using QN = std::integral_constant<int, -1>;  // no GELU piece in this unit
-  using QA = std::integral_constant<int, 10>;
-  using QB = std::integral_constant<int, 11>;
-  using QC = std::integral_constant<int, 12>;
-  using QD = std::integral_constant<int, 13>;
-  // piece Q (0..3) of row tile MT: values (jt = Q/2, r = 2(Q%2), +1) of ac[.][MT]; the last piece packs the B fragment
-  auto gelu_piece = [&](auto Q_, auto MT_, const f32x4_t (&ac)[2][2], h16x8_t (&hb)[2]) {
-    constexpr int Q = decltype(Q_)::value, MT = decltype(MT_)::value;
-    if constexpr (Q >= 10) {  // a whole slice inside one unit (first and last slice): pieces 2(Q-10), 2(Q-10)+1 over both row tiles
-      constexpr int H = Q - 10;
-      auto two = [&](auto P0_, auto P1_, auto M_) {
-        constexpr int P0 = decltype(P0_)::value, P1 = decltype(P1_)::value, MM = decltype(M_)::value;
-        gt[2 * P0] = gelu_erf1(ac[P0 / 2][MM][2 * (P0 % 2)]);
-        gt[2 * P0 + 1] = gelu_erf1(ac[P0 / 2][MM][2 * (P0 % 2) + 1]);
-        gt[2 * P1] = gelu_erf1(ac[P1 / 2][MM][2 * (P1 % 2)]);
-        gt[2 * P1 + 1] = gelu_erf1(ac[P1 / 2][MM][2 * (P1 % 2) + 1]);
-        if constexpr (P1 == 3) {
-          const uint4 pk = {pack_h16x2(gt[0], gt[1]), pack_h16x2(gt[2], gt[3]), pack_h16x2(gt[4], gt[5]), pack_h16x2(gt[6], gt[7])};
-          hb[MM] = __builtin_bit_cast(h16x8_t, pk);
-        }
-      };
-      if constexpr (H == 0) two(Q0{}, Q1{}, Q0{});
-      if constexpr (H == 1) two(Q2{}, Q3{}, Q0{});
-      if constexpr (H == 2) two(Q0{}, Q1{}, Q1{});
-      if constexpr (H == 3) two(Q2{}, Q3{}, Q1{});
-    } else if constexpr (Q >= 0) {
-      gt[2 * Q] = gelu_erf1(ac[Q / 2][MT][2 * (Q % 2)]);
-      gt[2 * Q + 1] = gelu_erf1(ac[Q / 2][MT][2 * (Q % 2) + 1]);
-      if constexpr (Q == 3) {
-        const uint4 pk = {pack_h16x2(gt[0], gt[1]), pack_h16x2(gt[2], gt[3]), pack_h16x2(gt[4], gt[5]), pack_h16x2(gt[6], gt[7])};
-        hb[MT] = __builtin_bit_cast(h16x8_t, pk);
-      }
+    for (int q = 0; q < 4; ++q) {
+      const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.b2 + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc2[T][4 * q + i] += b4[i];
     }
+
+  // ---- fc2, LAG half ticks behind fc1.  Half tick g >= LAG: fragments 12..23 of its chunk = (tile 6p + f/2, k-step f % 2), p = g & 1,
+  //      of hidden slice (g - LAG) / 2, whose activations are in hb slot ((g - LAG) / 2) & 1 ----
+  for (int g = 0; g < LAG; ++g) cur = transition(TB{});  // chunks NOUT+1 .. NOUT+LAG become current; `cur` = chunk NOUT + LAG
+  const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
+  h16x8_t hb[2];
+  auto fc2_half = [&](auto P_, bool more) {
+    constexpr int P = decltype(P_)::value;
+    if constexpr (P == 0) {  // a new slice: its activations (written by the partner before the barrier that made this chunk current)
+      const unsigned a = hb_addr + (((c_next - 1 - NOUT - LAG) >> 1) & 1) * (4 * 2 * FRAG);
+      lds_read1<0>(a, hb[0]);
+      lds_read1<FRAG>(a, hb[1]);
+    }
+    sfor<4>([&](auto B_) {
+      constexpr int B = decltype(B_)::value;  // batch: fragments 12 + 3B .. +2
+      h16x8_t(&wc)[3] = (B & 1) ? wb : wa;
+      h16x8_t(&wn)[3] = (B & 1) ? wa : wb;
+      if constexpr (B < 3) {
+        lds_read3<(12 + 3 * B + 3) * FRAG, (ABL & 32) != 0>(cur, wn);
+        CS_LGKM(3);
+      } else if (more) {
+        cur = transition(TB{});
+        lds_read3<12 * FRAG, (ABL & 32) != 0>(cur, wn);
+        CS_SB();
+      } else {
+        CS_LGKM(0);
+      }
+      sfor<3>([&](auto I_) {
+        constexpr int F = 3 * B + decltype(I_)::value, T = 6 * P + F / 2, S = F % 2;
+        if constexpr (ABL & 8) keep_alive(wc[decltype(I_)::value]);
+        else acc2[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[decltype(I_)::value], hb[S], acc2[T], 0, 0, 0);
+      });
+      CS_SB();
+    });
   };
-  // One unit = 4 steps; NEXT = the first reads of the following unit (issued right after the transition), NCNT = how many;
-  // (GQ.., GMT, GAC, GHB) = the GELU pieces that ride in this unit.
-#define CS_FC1_UNIT(AC, BB, NEXT, NCNT, G0, G1, G2, G3, GMT, GAC, GHB)                                            \
-  read6(sl, B1{}, wb); CS_LGKM(6); gelu_piece(G0{}, GMT{}, GAC, GHB); mm_fc1(B0{}, Last{}, wa, AC[0], AC[1], BB); \
-  read6(sl, B2{}, wa); CS_LGKM(6); gelu_piece(G1{}, GMT{}, GAC, GHB); mm_fc1(B1{}, Last{}, wb, AC[0], AC[1], BB); \
-  read6(sl, B3{}, wb); CS_LGKM(6); gelu_piece(G2{}, GMT{}, GAC, GHB); mm_fc1(B2{}, Last{}, wa, AC[0], AC[1], BB); \
-  sl = transition(NotLast{}); NEXT; CS_LGKM(NCNT); gelu_piece(G3{}, GMT{}, GAC, GHB); mm_fc1(B3{}, Last{}, wb, AC[0], AC[1], BB);
-#define CS_FC2_UNIT(HB, TRANS, NEXT, NCNT, G0, G1, G2, G3, GMT, GAC, GHB)                                        \
-  read6(sl, B1{}, wb); CS_LGKM(6); gelu_piece(G0{}, GMT{}, GAC, GHB); mm_fc2(B0{}, wa, HB);                      \
-  read6(sl, B2{}, wa); CS_LGKM(6); gelu_piece(G1{}, GMT{}, GAC, GHB); mm_fc2(B1{}, wb, HB);                      \
-  read6(sl, B3{}, wb); CS_LGKM(6); gelu_piece(G2{}, GMT{}, GAC, GHB); mm_fc2(B2{}, wa, HB);                      \
-  TRANS; NEXT; CS_LGKM(NCNT); gelu_piece(G3{}, GMT{}, GAC, GHB); mm_fc2(B3{}, wb, HB);
-  // unit order of the packed stream: W1[0] W1[1] | W1[2] W2[0] | W1[3] W2[1] | ... | W1[47] W2[45] | W2[46] W2[47]
-  read6(sl, B0{}, wa);
-  read_bias(0, bb0);
-  CS_FC1_UNIT(ac0, bb0, read6(sl, B0{}, wa); read_bias(1, bb1), 8, QN, QN, QN, QN, Q0, ac0, hb0)   // W1[0] -> ac0
-  CS_FC1_UNIT(ac1, bb1, read6(sl, B0{}, wa); read_bias(2, bb0), 8, QA, QB, QC, QD, Q0, ac0, hb0)   // W1[1] -> ac1, GELU(slice 0) -> hb0
-  for (int i = 2; i < NSL; i += 2) {
-    CS_FC1_UNIT(ac0, bb0, read6(sl, B0{}, wa), 6, Q0, Q1, Q2, Q3, Q0, ac1, hb1)                                              // W1[i]   -> ac0
-    CS_FC2_UNIT(hb0, sl = transition(NotLast{}), read6(sl, B0{}, wa); read_bias(i + 1, bb1), 8, Q0, Q1, Q2, Q3, Q1, ac1, hb1)  // W2[i-2] <- hb0
-    CS_FC1_UNIT(ac1, bb1, read6(sl, B0{}, wa), 6, Q0, Q1, Q2, Q3, Q0, ac0, hb0)                                              // W1[i+1] -> ac1
-    CS_FC2_UNIT(hb1, sl = transition(NotLast{}), read6(sl, B0{}, wa); read_bias(min(i + 2, NSL - 1), bb0), 8, Q0, Q1, Q2, Q3, Q1, ac0, hb0)  // W2[i-1] <- hb1
+  lds_read3<12 * FRAG, (ABL & 32) != 0>(cur, wa);
+  for (int t = 0; t < NSL - 1; ++t) {
+    fc2_half(IC<0>{}, true);
+    fc2_half(IC<1>{}, true);
   }
-  CS_FC2_UNIT(hb0, sl = transition(NotLast{}), read6(sl, B0{}, wa), 6, QA, QB, QC, QD, Q0, ac1, hb1)   // W2[46], GELU(slice 47) -> hb1
-  CS_FC2_UNIT(hb1, (void)0, (void)0, 0, QN, QN, QN, QN, Q0, ac1, hb1)                                  // W2[47]
-  CS_VMCNT(0);  // the padding units' LDS-DMA has landed before the workgroup can end
-#undef CS_FC1_UNIT
-#undef CS_FC2_UNIT
+  fc2_half(IC<0>{}, true);
+  fc2_half(IC<1>{}, false);
+  CS_VMCNT(0);  // the padding chunks' LDS-DMA has landed before the workgroup can end
 
   // ---- epilogue: new residual rows, and the next layer's normalised rows ----
+  if (row_ok) {
+    float* xr = p.x + row * PC + 4 * h;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int row = row0 + 16 * mt + m;
-    if (row < p.M) {
+    for (int T = 0; T < NT; ++T)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4_t*>(p.x + (size_t)row * PC + 16 * nt + 4 * g) = acc2[nt][mt];
-    }
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4_t*>(xr + 32 * T + 8 * q) = f32x4_t{acc2[T][4 * q], acc2[T][4 * q + 1], acc2[T][4 * q + 2], acc2[T][4 * q + 3]};
   }
   if (p.u_out) {
-    float mean[2], rstd[2];
+    float mean, rstd;
     row_stats(mean, rstd);
+    const float nb = -mean * rstd;
+    if (row_ok) {
+      h16_t* ur = p.u_out + row * PC + 4 * h;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int row = row0 + 16 * mt + m;
-      if (row < p.M) {
+      for (int T = 0; T < NT; ++T)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const f32x4_t a = (acc2[nt][mt] - mean[mt]) * rstd[mt];
-          *reinterpret_cast<uint2*>(p.u_out + (size_t)row * PC + 16 * nt + 4 * g) = make_uint2(pack_h16x2(a[0], a[1]), pack_h16x2(a[2], a[3]));
+        for (int q = 0; q < 4; ++q) {
+          const float a0 = fmaf(acc2[T][4 * q], rstd, nb), a1 = fmaf(acc2[T][4 * q + 1], rstd, nb);
+          const float a2 = fmaf(acc2[T][4 * q + 2], rstd, nb), a3 = fmaf(acc2[T][4 * q + 3], rstd, nb);
+          *reinterpret_cast<uint2*>(ur + 32 * T + 8 * q) = make_uint2(pack_h16x2(a0, a1), pack_h16x2(a2, a3));
         }
-      }
     }
   }
 }
 
-// ---- weight image.  One thread per 16-byte chunk (8 bf16).  Unit-local layout: piece p (1 KiB) = 16 rows x 64 B; physical
-//      chunk c of row r holds logical k-chunk gl = c ^ 2*((r>>2)&1) (the XOR makes the 16-lane groups of ds_read_b128 hit 16
-//      distinct 16-byte slots).  Element e of logical chunk gl is contraction index
-//         natural : 8 gl + e                         (out-projection: its B fragments are loaded from memory in natural order)
-//         permuted: 4 gl + e  (e < 4),  16 + 4 gl + e - 4  (e >= 4)     (fc1 / fc2: their B fragments are accumulator tiles)
-//      inside the 32-wide k-step. ----
+// ---- weight image.  One thread per 16-byte fragment element (8 f16): [chunk][fragment 0..23][lane 0..63].  Lane (i = lane & 31,
+//      h = lane >> 5) of an A-operand fragment holds output feature i of its 32-feature tile and 8 contraction indices of its 16-wide
+//      k-step:  natural   : 8 h + e                                   (out-projection: its B fragments are loaded from memory)
+//               permuted  : kappa(h, e) = (e & 3) + 8 (e >> 2) + 4 h   (fc1 / fc2: their B fragments are accumulator tiles)
+//      Chunks: [12 out-projection chunks c: fragment 12 ksl + T = (k-step 2c + ksl, tile T)]
+//              [100 MLP half ticks g: fragments 0..11  = fc1 slice g/2, k-step 12 (g&1) + f                         (g < 96)
+//                                     fragments 12..23 = fc2 slice (g-4)/2, tile 6 (g&1) + f'/2, k-step f' % 2       (g >= 4)]
+//              [2 padding chunks] ----
 __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restrict__ wo, const float* __restrict__ ls1,
                                                             const float* __restrict__ w1, const float* __restrict__ g2,
                                                             const float* __restrict__ w2, const float* __restrict__ ls2,
                                                             h16_t* __restrict__ img) {
-  const int nu = (wo ? OUT_UNITS : 0) + MLP_UNITS;
+  const int nout = wo ? OUT_CHUNKS : 0;
+  const int nch = nout + MLP_CHUNKS;
   const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gi >= (nu + AHEAD) * (UNIT / 16)) return;
-  if (gi >= nu * (UNIT / 16)) {  // padding units: fetched by the last transitions, never read
-    reinterpret_cast<uint4*>(img)[gi] = make_uint4(0, 0, 0, 0);
-    return;
-  }
-  int U = gi / (UNIT / 16);
-  const int within = gi - U * (UNIT / 16);
-  const int pc = within >> 6, r = (within >> 2) & 15, c = within & 3;
-  const int gl = c ^ (((r >> 2) & 1) << 1);
-  float v[8];
-  if (wo && U < OUT_UNITS) {
-    const int row = 32 * U + 16 * (pc / KS) + r, ks = pc % KS;
+  if (gi >= (nch + PAD_CHUNKS) * (CHUNK / 16)) return;
+  const int c = gi / (CHUNK / 16);
+  const int within = gi - c * (CHUNK / 16);
+  const int f = within >> 6, lane = within & 63;
+  const int i = lane & 31, h = lane >> 5;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < nout) {
+    const int ks = 2 * c + f / 12, T = f % 12;
+    const int rowi = 32 * T + i;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = wo[(size_t)row * PC + 32 * ks + 8 * gl + e] * (ls1 ? ls1[row] : 1.f);
-  } else {
-    const int k = U - (wo ? OUT_UNITS : 0);
-    // stream order: W1[0] W1[1] | W1[2] W2[0] | W1[3] W2[1] | ... | W1[47] W2[45] | W2[46] W2[47]
-    bool is_fc1;
-    int s;
-    if (k < 2) { is_fc1 = true; s = k; }
-    else if (k >= MLP_UNITS - 2) { is_fc1 = false; s = NSL - (MLP_UNITS - k); }
-    else { const int j = k - 2; is_fc1 = (j & 1) == 0; s = is_fc1 ? 2 + j / 2 : (j - 1) / 2; }
-    if (is_fc1) {
-      const int row = 32 * s + 16 * (pc / KS) + r, ks = pc % KS;
+    for (int e = 0; e < 8; ++e) v[e] = wo[(size_t)rowi * PC + 16 * ks + 8 * h + e] * (ls1 ? ls1[rowi] : 1.f);
+  } else if (c < nch) {
+    const int g = c - nout;
+    if (f < 12) {
+      if (g < 2 * NSL) {
+        const int t = g >> 1, ks = 12 * (g & 1) + f;
+        const int rowi = 32 * t + i;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int col = 32 * ks + (e < 4 ? 4 * gl + e : 16 + 4 * gl + e - 4);
-        v[e] = w1[(size_t)row * PC + col] * (g2 ? g2[col] : 1.f);
+        for (int e = 0; e < 8; ++e) {
+          const int col = 16 * ks + (e & 3) + 8 * (e >> 2) + 4 * h;
+          v[e] = w1[(size_t)rowi * PC + col] * (g2 ? g2[col] : 1.f);
+        }
       }
-    } else {
-      const int row = 16 * pc + r;
+    } else if (g >= LAG) {
+      const int tt = (g - LAG) >> 1, fp = f - 12;
+      const int T = 6 * (g & 1) + fp / 2, s = fp % 2;
+      const int rowi = 32 * T + i;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int col = 32 * s + (e < 4 ? 4 * gl + e : 16 + 4 * gl + e - 4);
-        v[e] = w2[(size_t)row * PF + col] * (ls2 ? ls2[row] : 1.f);
+        const int col = 32 * tt + 16 * s + (e & 3) + 8 * (e >> 2) + 4 * h;
+        v[e] = w2[(size_t)rowi * PF + col] * (ls2 ? ls2[rowi] : 1.f);
       }
     }
   }
@@ -403,11 +515,11 @@ __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restr
 extern "C" {
 
 int cs_panel_supported(int C, int mlp_ratio) { return C == PC && mlp_ratio * C == PF; }
-size_t cs_panel_image_bytes(int with_outproj) { return (size_t)((with_outproj ? OUT_UNITS : 0) + MLP_UNITS + AHEAD) * UNIT; }
+size_t cs_panel_image_bytes(int with_outproj) { return (size_t)((with_outproj ? OUT_CHUNKS : 0) + MLP_CHUNKS + PAD_CHUNKS) * CHUNK; }
 
 hipError_t cs_panel_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
                                 h16_t* img, hipStream_t st) {
-  const int total = ((wo ? OUT_UNITS : 0) + MLP_UNITS + AHEAD) * (UNIT / 16);
+  const int total = ((wo ? OUT_CHUNKS : 0) + MLP_CHUNKS + PAD_CHUNKS) * (CHUNK / 16);
   hipLaunchKernelGGL(cs_panel_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, wo, ls1, w1, g2, w2, ls2, img);
   return hipGetLastError();
 }
@@ -434,8 +546,18 @@ hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st) {
     attr_done[dev][v] = true;
   }
   const int grid = (p->M + PANEL_ROWS - 1) / PANEL_ROWS;
-  if (v) hipLaunchKernelGGL(cs_panel_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, *p);
-  else hipLaunchKernelGGL(cs_panel_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, *p);
+#ifdef CS_PANEL_ABLATE
+  if (const char* e = getenv("CS_PANEL_ABL")) {
+    const int abl = atoi(e);
+#define CS_ABL_CASE(N) if (abl == N) { \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cs_panel_kernel<true, N>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+      hipLaunchKernelGGL((cs_panel_kernel<true, N>), dim3(grid), dim3(512), LDS_BYTES, st, *p); return hipGetLastError(); }
+    CS_ABL_CASE(1) CS_ABL_CASE(2) CS_ABL_CASE(4) CS_ABL_CASE(8) CS_ABL_CASE(16) CS_ABL_CASE(32) CS_ABL_CASE(12) CS_ABL_CASE(3) CS_ABL_CASE(47) CS_ABL_CASE(5)
+#undef CS_ABL_CASE
+  }
+#endif
+  if (v) hipLaunchKernelGGL(cs_panel_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, st, *p);
+  else hipLaunchKernelGGL(cs_panel_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, st, *p);
   return hipGetLastError();
 }
 
