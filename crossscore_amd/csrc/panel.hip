@@ -42,16 +42,19 @@ constexpr int FRAG = 1024;            // bytes of one MFMA operand fragment (64 
 constexpr int CHUNK = 24 * FRAG;      // ring chunk
 constexpr int NSLOT = 3;
 constexpr int OUT_CHUNKS = KS / 2;    // out-projection: 12 chunks of two k-steps x 12 tiles
-constexpr int LAG = 4;                // half ticks the fc2 side runs behind the fc1 side
-constexpr int MLP_CHUNKS = 2 * NSL + LAG;  // 100 half ticks
+constexpr int LAG = 5;                // half ticks the fc2 side runs behind the fc1 side
+constexpr int MLP_CHUNKS = 2 * NSL + LAG;  // 101 half ticks
 constexpr int PAD_CHUNKS = 2;         // fetched by the last transitions, never read
 constexpr int PANEL_ROWS = 128;
 // LDS map
 constexpr int LDS_RING = 0;
-constexpr int LDS_R = NSLOT * CHUNK;                 // 48 KiB: norm2(x) hand-off, 12 fragments per pair at a time
-constexpr int LDS_HB = LDS_R + 4 * 12 * FRAG;        // 2 slots x 4 pairs x 2 fragments
-constexpr int LDS_B1 = LDS_HB + 2 * 4 * 2 * FRAG;    // fc1 bias, fp32
-constexpr int LDS_BYTES = LDS_B1 + PF * 4;           // 142 KiB
+constexpr int LDS_R = NSLOT * CHUNK;                 // 48 KiB: 3 slots x 4 pairs x 4 KiB residual-row tiles (out-projection phase), then the
+                                                     //         norm2(x) hand-off, 12 fragments per pair at a time
+constexpr int LDS_HB = LDS_R + 4 * 12 * FRAG;        // 24 KiB: 3 slots x 4 pairs x 2 attention-output fragments (out-projection phase), then
+                                                     //         2 slots x 4 pairs x 2 activation fragments (MLP phase)
+constexpr int LDS_B1 = LDS_HB + 3 * 4 * 2 * FRAG;    // fc1 bias, fp32
+constexpr int LDS_BV = LDS_B1 + PF * 4;              // bo | b2, fp32
+constexpr int LDS_BYTES = LDS_BV + 2 * PC * 4;       // 153 KiB
 
 #define CS_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define CS_SB() __builtin_amdgcn_sched_barrier(0) /* nothing crosses (any other mask let hipcc move MFMAs over the asm waits) */
@@ -87,13 +90,6 @@ __device__ __forceinline__ u32x4_t pack8(const float (&v)[8]) {
 
 // ---- inline-asm LDS access of the regions the LDS-DMA also writes or that cross waves (hipcc would order every compiler-visible LDS
 //      access against the DMA with vmcnt(0)); results are retired by the counted CS_LGKM waits of the callers ----
-__device__ __forceinline__ void keep_alive(const h16x8_t& w) { asm volatile("" ::"v"(w)); }  // (ablation builds: rule 17)
-template <int OFF, bool SKIP = false>
-__device__ __forceinline__ void lds_read3(unsigned addr, h16x8_t (&w)[3]) {
-  if constexpr (SKIP) { asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : "v"(addr)); return; }
-  asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6"
-               : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]) : "v"(addr), "n"(OFF), "n"(OFF + FRAG), "n"(OFF + 2 * FRAG) : "memory");
-}
 template <int OFF>
 __device__ __forceinline__ void lds_read1(unsigned addr, h16x8_t& w) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w) : "v"(addr), "n"(OFF) : "memory");
@@ -107,16 +103,26 @@ __device__ __forceinline__ void lds_write16(unsigned addr, u32x4_t v) {
   asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 
-// One LDS-DMA piece = one fragment: 64 lanes x 16 B from `src + OFF` (this lane's address) to the wave-uniform LDS address `dst + OFF`
+// One LDS-DMA piece: 64 lanes x 16 B from `src + OFF` (this lane's address) to the wave-uniform LDS address `dst + OFF`
 // (the instruction's immediate offset applies to both addresses)
 template <int OFF>
 __device__ __forceinline__ void dma_piece(const char* src, unsigned dst) {
   __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(src), (__attribute__((address_space(3))) void*)(size_t)dst, 16, OFF, 0);
 }
 
+#ifdef CS_PANEL_ABLATE
+// diagnostic builds only: per (block < 64, wave) six s_memtime stamps + s_memrealtime at both ends (tools/panel_ablate.py)
+__device__ unsigned long long g_panel_dbg[64 * 8 * 10];
+#define CS_STAMP(k) do { if (blockIdx.x < 64 && lane == 0) { \
+    __builtin_amdgcn_sched_barrier(0); g_panel_dbg[(blockIdx.x * 8 + wv) * 10 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define CS_STAMP_RT(k) do { if (blockIdx.x < 64 && lane == 0) g_panel_dbg[(blockIdx.x * 8 + wv) * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CS_STAMP(k) do { } while (0)
+#define CS_STAMP_RT(k) do { } while (0)
+#endif
+
 // ABL: timing-only ablations (tools/panel_ablate.py builds them with -DCS_PANEL_ABLATE; results are wrong by design):
-//   1 no GELU arithmetic, 2 no LDS-DMA after the prologue, 4 A waves skip their MFMAs, 8 B waves skip theirs, 16 no s_barrier per chunk,
-//   32 no weight-fragment LDS reads
+//   1 no GELU arithmetic, 2 no weight LDS-DMA after the prologue, 16 no s_barrier per chunk
 template <bool OUTPROJ, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,73 +133,116 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   const int pair = wv & 3;
   const int j = lane & 31, h = lane >> 5;
   const int row0 = blockIdx.x * PANEL_ROWS + pair * 32;
+  const size_t row = (size_t)min(row0 + j, p.M - 1);
   constexpr int NOUT = OUTPROJ ? OUT_CHUNKS : 0;
-  // Chunks below SOLO are copied by the A waves alone (6 pieces each): during the out-projection the B waves have ordinary global
-  // loads in flight, which share the vmcnt queue with LDS-DMA.  From SOLO on: A waves 2 pieces, B waves 4.
+  // Chunks below SOLO are copied by the A waves alone (6 weight pieces each; during the out-projection also the pair's residual-row tile,
+  // 4 pieces, and its two attention-output fragments): the B waves then issue no vector-memory instruction before the MLP phase.
+  // From SOLO on: A waves 2 weight pieces, B waves 4.
   constexpr int SOLO = NOUT + 3;
   const unsigned lds0 = (unsigned)(size_t)CS_LDS_PTR(smem);
   const unsigned lane16 = lane * 16;
-  const char* img = reinterpret_cast<const char*>(p.img) + lane16;
+  // per-lane 32-bit byte offsets (the 64-bit addresses are formed where they are used, from the kernel arguments: no address pair stays live)
+  const unsigned xoff = (unsigned)row * (PC * 4) + 64 * h;  // this lane's 16 floats of tile 0 of its residual row (M * 1536 < 2^32: cs_panel_check)
+  const unsigned ooff = (unsigned)row * (PC * 2) + 16 * h;  // this lane's 8 halves of k-step 0 of its attention-output row
 
   int c_next = 0;    // next chunk to make current
   int slot_cur = 0;  // ring slot of chunk c_next
   auto ring_issue = [&](auto ISA_, int c, int slot) {
     constexpr bool ISA = decltype(ISA_)::value;
     const unsigned dst = lds0 + LDS_RING + slot * CHUNK;
-    const char* s = img + (size_t)c * CHUNK;
+    const char* s = reinterpret_cast<const char*>(p.img) + (size_t)c * CHUNK + lane16;
     if (c < SOLO) {
       if constexpr (ISA) {
-        const char* s6 = s + pair * 6 * FRAG;
-        const unsigned d6 = dst + pair * 6 * FRAG;
-        dma_piece<0>(s6, d6); dma_piece<FRAG>(s6, d6); dma_piece<2 * FRAG>(s6, d6); dma_piece<3 * FRAG>(s6, d6);
-        dma_piece<0>(s6 + 4 * FRAG, d6 + 4 * FRAG); dma_piece<FRAG>(s6 + 4 * FRAG, d6 + 4 * FRAG);
+        if constexpr (!(ABL & 2)) {
+          const char* s6 = s + pair * 6 * FRAG;
+          const unsigned d6 = dst + pair * 6 * FRAG;
+          dma_piece<0>(s6, d6); dma_piece<FRAG>(s6, d6); dma_piece<2 * FRAG>(s6, d6); dma_piece<3 * FRAG>(s6, d6);
+          dma_piece<0>(s6 + 4 * FRAG, d6 + 4 * FRAG); dma_piece<FRAG>(s6 + 4 * FRAG, d6 + 4 * FRAG);
+        }
+        if (OUTPROJ && c < NOUT) {
+          // residual-row tile c in the accumulator layout (piece q = registers 4q .. 4q+3 of every lane) and the B fragments of k-steps 2c, 2c+1
+          const unsigned dx = lds0 + LDS_R + (slot * 4 + pair) * 4 * FRAG;
+          const char* sx = reinterpret_cast<const char*>(p.x) + (size_t)(xoff + c * 128);
+          const char* osrc = reinterpret_cast<const char*>(p.attn_o) + (size_t)ooff;
+          dma_piece<0>(sx, dx);
+          // (the immediate offset applies to both sides: source quarter q is 16 q bytes on, its LDS piece 1024 q)
+          dma_piece<0>(sx + 16, dx + FRAG); dma_piece<0>(sx + 32, dx + 2 * FRAG); dma_piece<0>(sx + 48, dx + 3 * FRAG);
+          const unsigned dof = lds0 + LDS_HB + (slot * 4 + pair) * 2 * FRAG;
+          dma_piece<0>(osrc + c * 64, dof);
+          dma_piece<0>(osrc + c * 64 + 32, dof + FRAG);
+        }
       }
-    } else if constexpr (ISA) {
-      dma_piece<0>(s + pair * 2 * FRAG, dst + pair * 2 * FRAG);
-      dma_piece<FRAG>(s + pair * 2 * FRAG, dst + pair * 2 * FRAG);
-    } else {
-      const char* s4 = s + (8 + pair * 4) * FRAG;
-      const unsigned d4 = dst + (8 + pair * 4) * FRAG;
-      dma_piece<0>(s4, d4); dma_piece<FRAG>(s4, d4); dma_piece<2 * FRAG>(s4, d4); dma_piece<3 * FRAG>(s4, d4);
+    } else if constexpr (!(ABL & 2)) {
+      if constexpr (ISA) {
+        dma_piece<0>(s + pair * 2 * FRAG, dst + pair * 2 * FRAG);
+        dma_piece<FRAG>(s + pair * 2 * FRAG, dst + pair * 2 * FRAG);
+      } else {
+        const char* s4 = s + (8 + pair * 4) * FRAG;
+        const unsigned d4 = dst + (8 + pair * 4) * FRAG;
+        dma_piece<0>(s4, d4); dma_piece<FRAG>(s4, d4); dma_piece<2 * FRAG>(s4, d4); dma_piece<3 * FRAG>(s4, d4);
+      }
     }
   };
-  // transition into chunk c_next: this wave's LDS reads of the previous chunk are complete (its slot is about to be refilled) and its
-  // own LDS-DMA pieces of chunk c_next have landed; barrier (the same holds for every wave); then the chunk two ahead goes into the slot
-  // of the previous chunk.  Returns this lane's LDS address of fragment 0 of the now-current chunk.
-  auto transition = [&](auto ISA_) -> unsigned {
+  // transition into chunk c_next: this wave's LDS reads of the current chunk are complete (its slot is refilled right after the barrier) and
+  // its own LDS-DMA pieces of chunk c_next have landed; barrier (the same holds for every wave); then the chunk two ahead of c_next goes into
+  // the slot of the chunk before c_next.  Returns this lane's LDS address of fragment 0 of chunk c_next.
+  int pend_c = 0, pend_slot = 0;  // chunk / slot whose weight pieces a deferred transition left to issue_piece()
+  // piece K of this wave's share of chunk pend_c (MLP phase only: A waves 2 pieces, B waves 4), issued between MFMAs instead of in a
+  // burst behind the barrier: an LDS-DMA costs its wave 60+ cycles of issue, during which the partner keeps the matrix pipe busy
+  auto issue_piece = [&](auto ISA_, auto K_) {
+    constexpr bool ISA = decltype(ISA_)::value;
+    constexpr int K = decltype(K_)::value;
+    if constexpr (ABL & 2) return;
+    const unsigned dst = lds0 + LDS_RING + pend_slot * CHUNK + (ISA ? pair * 2 : 8 + pair * 4) * FRAG;
+    const char* s = reinterpret_cast<const char*>(p.img) + ((size_t)pend_c * CHUNK + (ISA ? pair * 2 : 8 + pair * 4) * FRAG) + lane16;
+    dma_piece<K * FRAG>(s, dst);
+  };
+  auto transition = [&](auto ISA_, bool defer = false) -> unsigned {
     constexpr bool ISA = decltype(ISA_)::value;
     CS_SB();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (ISA) {
-      if (c_next <= SOLO - 2) CS_VMCNT(6); else CS_VMCNT(2);
+      // pieces of chunk c_next + 1 that may still be in flight
+      if (c_next + 1 < NOUT) CS_VMCNT(12);
+      else if (c_next + 1 < SOLO) CS_VMCNT(6);
+      else CS_VMCNT(2);
     } else {
       CS_VMCNT(4);
     }
     if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int s2 = slot_cur + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2;
-    if constexpr (!(ABL & 2)) ring_issue(ISA_, c_next + 2, s2);  // the image ends with PAD_CHUNKS, so the stream needs no tail case
+    if (defer) { pend_c = c_next + 2; pend_slot = s2; }   // (only from SOLO on: the caller issues the pieces one by one)
+    else ring_issue(ISA_, c_next + 2, s2);  // the image ends with PAD_CHUNKS, so the stream needs no tail case
     const unsigned base = lds0 + LDS_RING + slot_cur * CHUNK + lane16;
     ++c_next;
     slot_cur = slot_cur + 1 >= NSLOT ? 0 : slot_cur + 1;
-    CS_SB();  // (rule: register-only MFMAs must not be scheduled above the waits of this statement)
+    CS_SB();  // (register-only MFMAs must not be scheduled above the waits of this statement)
     return base;
   };
   using TA = std::true_type;
   using TB = std::false_type;
+  h16x8_t w[6];  // rolling pool of weight fragments: fragment k of a chunk lives in w[k % 6], five reads ahead of its MFMA
 
   if (is_a) {
     // =====================================================================================================================
-    // A wave: LDS-DMA for the out-projection phase, then fc1 + GELU
+    // A wave: loader of the out-projection phase, then fc1 + GELU
     // =====================================================================================================================
-    // fc1 bias (LN2 beta folded in) -> LDS once per workgroup (the A waves are idle here)
+    CS_STAMP_RT(8); CS_STAMP(0);
+    // bias vectors -> LDS once per workgroup: fc1 (LN2 beta folded in), out-projection and fc2 (LayerScale folded in)
     for (int i = tid; i < PF / 4; i += 256)
       reinterpret_cast<f32x4_t*>(smem + LDS_B1)[i] = reinterpret_cast<const f32x4_t*>(p.b1)[i];
+    if (tid < PC / 4) {
+      reinterpret_cast<f32x4_t*>(smem + LDS_BV)[tid] = OUTPROJ ? reinterpret_cast<const f32x4_t*>(p.bo)[tid] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f32x4_t*>(smem + LDS_BV + PC * 4)[tid] = reinterpret_cast<const f32x4_t*>(p.b2)[tid];
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     ring_issue(TA{}, 0, 0);
     ring_issue(TA{}, 1, 1);
     unsigned cur = transition(TA{});                       // chunk 0
+    CS_STAMP(1);
     for (int c = 0; c < NOUT; ++c) cur = transition(TA{});  // the B waves multiply chunks 0 .. NOUT-1; `cur` ends at chunk NOUT
+    CS_STAMP(2);
     // ---- norm2(x) from the partner: two halves of 12 fragments through the R region ----
     h16x8_t xf[KS];
     const unsigned r_addr = lds0 + LDS_R + pair * 12 * FRAG + lane16;
@@ -204,137 +253,158 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     __builtin_amdgcn_s_barrier();  // H3: second half written
     sfor<12>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(r_addr, xf[12 + decltype(F_)::value]); });
     CS_LGKM(0);
+    CS_STAMP(3);
 
-    // ---- fc1 ticks.  Tick t: acc(t & 1) = b1 + W1[slice t] . xf (two half ticks = two chunks of 12 fragments); GELU of slice t-1
-    //      (the other accumulator) rides between the MFMAs and leaves as two B fragments in hb slot (t-1) & 1 ----
+    // ---- fc1 ticks.  Tick t: acc(t & 1) = b1 + W1[slice t] . xf (two half ticks = two chunks of 12 fragments); the GELU of slice t-1 (the
+    //      other accumulator) rides in the gaps between the MFMAs, one value per gap in 8 of the 12 gaps of a half tick, and leaves as two B
+    //      fragments in hb slot (t-1) & 1 (the partner reads them LAG half ticks after the slice's first half tick) ----
     f32x16_t acE, acO;  // even / odd slices
-    const unsigned bias_addr = lds0 + LDS_B1 + 16 * h;
+    const unsigned bias_addr = lds0 + LDS_B1 + 64 * h;
     const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
     float gv[8];
-    h16x8_t wa[3], wb[3];
-    auto gelu2 = [&](auto V0_, const f32x16_t& src) {  // values V0, V0+1 of the slice being activated
-      constexpr int V0 = decltype(V0_)::value;
-      gv[V0 & 7] = (ABL & 1) ? src[V0] : gelu_erf1(src[V0]);
-      gv[(V0 + 1) & 7] = (ABL & 1) ? src[V0 + 1] : gelu_erf1(src[V0 + 1]);
+    f32x4_t bb[4];
+    auto read_bias = [&](int t) {  // this lane's 16 hidden units of slice t: 32 t + 16 h + r
+      const unsigned a = bias_addr + t * 128;
+      lds_read_f4<0>(a, bb[0]); lds_read_f4<16>(a, bb[1]); lds_read_f4<32>(a, bb[2]); lds_read_f4<48>(a, bb[3]);
     };
-    auto hb_store = [&](int slot, auto S_) { lds_write16<decltype(S_)::value * FRAG>(hb_addr + slot * (4 * 2 * FRAG), pack8(gv)); };
-    auto mm3 = [&](auto K0_, const h16x8_t (&w)[3], f32x16_t& acc) {
-      constexpr int K0 = decltype(K0_)::value;
-      if constexpr (ABL & 4) { keep_alive(w[0]); keep_alive(w[1]); keep_alive(w[2]); return; }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i], xf[K0 + i], acc, 0, 0, 0);
-    };
-    // One half tick: 12 fragments in 4 batches of 3; the reads of batch k+1 are in flight under the MFMAs of batch k, the transition to
-    // the next chunk (and the first reads of it) happens before the last batch.  P = 0: k-steps 0..11, GELU values 0..7 (-> hb fragment
-    // 0); P = 1: k-steps 12..23, values 8..15 in the first two batches, hb fragment 1 before the transition (the partner reads it after).
-    auto half_tick = [&](auto P_, auto FC1_, f32x16_t& acc, const f32x16_t& act, int hb_slot) {
+    // One half tick: per fragment m [counted wait for it; MFMA; read of fragment m + 6 (of the next chunk from m = 6 on); a GELU value];
+    // the transition to the next chunk sits before fragment 6, when all 12 fragments of this chunk are in registers or behind it in the
+    // LDS queue.  P = 0: k-steps 0..11, GELU values 0..7 -> hb fragment 0; P = 1: k-steps 12..23, values 8..15 -> hb fragment 1, and the
+    // next slice's bias.
+    auto half_tick = [&](auto P_, auto FC1_, f32x16_t& acc, const f32x16_t& act, int hb_slot, int t_next) {
       constexpr int P = decltype(P_)::value;
       constexpr bool FC1 = decltype(FC1_)::value;
-      if constexpr (FC1) { lds_read3<3 * FRAG, (ABL & 32) != 0>(cur, wb); CS_LGKM(3); }
-      if constexpr (P == 0) { gelu2(IC<0>{}, act); gelu2(IC<2>{}, act); }
-      else { gelu2(IC<8>{}, act); gelu2(IC<10>{}, act); gelu2(IC<12>{}, act); }
-      if constexpr (FC1) mm3(IC<12 * P + 0>{}, wa, acc);
-      CS_SB();
-      if constexpr (FC1) { lds_read3<6 * FRAG, (ABL & 32) != 0>(cur, wa); CS_LGKM(3); }
-      if constexpr (P == 0) { gelu2(IC<4>{}, act); }
-      else { gelu2(IC<14>{}, act); }
-      if constexpr (FC1) mm3(IC<12 * P + 3>{}, wb, acc);
-      CS_SB();
-      if constexpr (FC1) { lds_read3<9 * FRAG, (ABL & 32) != 0>(cur, wb); CS_LGKM(3); }
-      if constexpr (P == 0) { gelu2(IC<6>{}, act); hb_store(hb_slot, IC<0>{}); }
-      else { hb_store(hb_slot, IC<1>{}); }
-      if constexpr (FC1) mm3(IC<12 * P + 6>{}, wa, acc);
-      CS_SB();
-      cur = transition(TA{});  // waits for every LDS operation of this wave first (batch 3's fragments, the hb store)
-      if constexpr (FC1) {
-        lds_read3<0, (ABL & 32) != 0>(cur, wa);
-        mm3(IC<12 * P + 9>{}, wb, acc);
+      sfor<12>([&](auto M_) {
+        constexpr int M = decltype(M_)::value;
+        if constexpr (M == 6) {
+          cur = transition(TA{}, true);
+          if constexpr (P == 1 && FC1) read_bias(t_next);  // (never leave an inline-asm read without a consumer: hipcc would reuse its
+                                                           //  destination registers at once, and the LDS data would land on top of the new owner)
+        }
+        if constexpr (M == 8) issue_piece(TA{}, IC<0>{});
+        if constexpr (M == 10) issue_piece(TA{}, IC<1>{});
+        if constexpr (FC1) {
+          CS_LGKM(5);
+          if constexpr (P == 0 && M == 0) {
+            f32x16_t b16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) b16[4 * q + i] = bb[q][i];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], xf[0], b16, 0, 0, 0);
+          } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], xf[12 * P + M], acc, 0, 0, 0);
+          }
+          if constexpr (M < 6) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
+          else lds_read1<(M - 6) * FRAG>(cur, w[M % 6]);
+        }
+        constexpr int G = (M % 3 == 2) ? -1 : (M / 3) * 2 + (M % 3);  // gaps 0,1,3,4,6,7,9,10 carry GELU values 0..7 of this half
+        if constexpr (G >= 0) gv[G] = (ABL & 1) ? act[8 * P + G] : gelu_erf1(act[8 * P + G]);
+        if constexpr (M == 11) lds_write16<P * FRAG>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv));
         CS_SB();
-      }
+      });
     };
-    auto bias_init = [&](f32x16_t& acc, int t) {
-      f32x4_t b4[4];
-      const unsigned a = bias_addr + t * 128;
-      lds_read_f4<0>(a, b4[0]); lds_read_f4<32>(a, b4[1]); lds_read_f4<64>(a, b4[2]); lds_read_f4<96>(a, b4[3]);
-      CS_LGKM(0);  // (also retires the first fragments of the chunk: they are older)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * q + i] = b4[q][i];
-    };
-    lds_read3<0, (ABL & 32) != 0>(cur, wa);
+    read_bias(0);  // (before the fragments: the counted waits retire LDS reads in order)
+    sfor<6>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(cur, w[decltype(F_)::value]); });
 #pragma unroll
     for (int i = 0; i < 16; ++i) acO[i] = 0.f;  // tick 0 "activates" this (slice -1: never read by the partner)
     for (int t = 0; t < NSL; t += 2) {
-      bias_init(acE, t);
-      half_tick(IC<0>{}, std::true_type{}, acE, acO, 1);
-      half_tick(IC<1>{}, std::true_type{}, acE, acO, 1);
-      bias_init(acO, t + 1);
-      half_tick(IC<0>{}, std::true_type{}, acO, acE, 0);
-      half_tick(IC<1>{}, std::true_type{}, acO, acE, 0);
+      half_tick(IC<0>{}, std::true_type{}, acE, acO, 1, 0);
+      half_tick(IC<1>{}, std::true_type{}, acE, acO, 1, t + 1);
+      half_tick(IC<0>{}, std::true_type{}, acO, acE, 0, 0);
+      half_tick(IC<1>{}, std::true_type{}, acO, acE, 0, min(t + 2, NSL - 1));
     }
+    CS_STAMP(4);
     // tick NSL: only the GELU of the last slice (odd)
     CS_LGKM(0);
-    half_tick(IC<0>{}, std::false_type{}, acE, acO, 1);
-    half_tick(IC<1>{}, std::false_type{}, acE, acO, 1);
-    // the B waves' last tick
-    cur = transition(TA{});
+    half_tick(IC<0>{}, std::false_type{}, acE, acO, 1, 0);
+    half_tick(IC<1>{}, std::false_type{}, acE, acO, 1, NSL - 1);
+    // the B waves' last LAG - 2 half ticks
+    for (int g = 0; g < LAG - 3; ++g) cur = transition(TA{});
     CS_VMCNT(0);  // the padding chunks' LDS-DMA has landed before the workgroup can end
+    CS_STAMP(5); CS_STAMP_RT(9);
     return;
   }
 
   // =======================================================================================================================
-  // B wave: residual rows; out-projection, LayerNorm hand-off, fc2, epilogue
+  // B wave: residual rows; out-projection, LayerNorm hand-off, fc2, epilogue.  acc2[T][r] = x[row j][32 T + 16 h + r]
   // =======================================================================================================================
+  CS_STAMP_RT(8); CS_STAMP(0);
   f32x16_t acc2[NT];
-  const size_t row = (size_t)min(row0 + j, p.M - 1);
   const bool row_ok = row0 + j < p.M;
-  {
-    const float* xr = p.x + row * PC + 4 * h;
+  const unsigned bv_addr = lds0 + LDS_BV + 64 * h;
+  unsigned cur = transition(TB{});  // chunk 0 (and: the bias vectors are in LDS)
+  CS_STAMP(1);
+  auto add_bias = [&](auto T_, auto INIT_, int which) {  // acc2[T] (+)= bias[32 T + 16 h + r]
+    constexpr int T = decltype(T_)::value;
+    f32x4_t b4[4];
+    const unsigned a = bv_addr + which * (PC * 4);
+    lds_read_f4<T * 128>(a, b4[0]); lds_read_f4<T * 128 + 16>(a, b4[1]); lds_read_f4<T * 128 + 32>(a, b4[2]); lds_read_f4<T * 128 + 48>(a, b4[3]);
+    CS_LGKM(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc2[T][4 * q + i] = (decltype(INIT_)::value ? 0.f : acc2[T][4 * q + i]) + b4[q][i];
+  };
+  if constexpr (OUTPROJ) {
+    // ---- attention output projection.  Chunk c = k-steps 2c, 2c+1 x 12 output tiles (fragment 12 ksl + T).  Its B fragments (this lane's
+    //      16 B of its attention-output row per k-step) and residual-row tile c arrive in LDS with the chunk (copied by the partner). ----
+    sfor<NT>([&](auto T_) { add_bias(T_, std::true_type{}, 0); });
+    const unsigned xs_addr = lds0 + LDS_R + pair * 4 * FRAG + lane16;
+    const unsigned of_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
+    h16x8_t of[2];
+    lds_read1<0>(of_addr, of[0]);
+    lds_read1<FRAG>(of_addr, of[1]);
+    sfor<6>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(cur, w[decltype(F_)::value]); });
+    int slot_x = 0;  // ring slot of the current chunk (its residual tile / attention-output fragments share the index)
+    sfor<OUT_CHUNKS>([&](auto C_) {
+      constexpr int C = decltype(C_)::value;
+      f32x4_t xs[2];
+      auto add_x = [&](auto Q0_) {  // registers 4 Q0 .. 4 Q0 + 7 of tile C
+        constexpr int Q0 = decltype(Q0_)::value;
+        CS_LGKM(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc2[C][4 * (Q0 + q) + i] += xs[q][i];
+        CS_SB();
+      };
+      sfor<24>([&](auto M_) {
+        constexpr int M = decltype(M_)::value;
+        // the chunk's residual-row tile C, two quarters at a time (its LDS slot is refilled after the transition below)
+        if constexpr (M == 12) { const unsigned a = xs_addr + slot_x * (4 * 4 * FRAG); lds_read_f4<0>(a, xs[0]); lds_read_f4<FRAG>(a, xs[1]); }
+        if constexpr (M == 14) add_x(IC<0>{});
+        if constexpr (M == 15) { const unsigned a = xs_addr + slot_x * (4 * 4 * FRAG); lds_read_f4<2 * FRAG>(a, xs[0]); lds_read_f4<3 * FRAG>(a, xs[1]); }
+        if constexpr (M == 17) add_x(IC<2>{});
+        if constexpr (M == 18) {
+          cur = transition(TB{});
+          slot_x = slot_x + 1 >= NSLOT ? 0 : slot_x + 1;
+          if constexpr (C + 1 < OUT_CHUNKS) lds_read1<0>(of_addr + slot_x * (4 * 2 * FRAG), of[0]);  // k-step 0's fragment is free from M = 12 on
+        }
+        if constexpr (M == 0 && C > 0) lds_read1<FRAG>(of_addr + slot_x * (4 * 2 * FRAG), of[1]);  // (needed from M = 12 on)
+        CS_LGKM(5);
+        constexpr int T = M % 12;
+        acc2[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], of[M / 12], acc2[T], 0, 0, 0);
+        if constexpr (M < 18) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
+        else lds_read1<(M - 18) * FRAG>(cur, w[M % 6]);  // (after the last chunk: the A half of chunk NOUT, unused)
+        CS_SB();
+      });
+    });
+    CS_LGKM(0);
+  } else {
+    // no out-projection (tests): x straight from memory
+    const float* xr = p.x + row * PC + 16 * h;
 #pragma unroll
     for (int T = 0; T < NT; ++T)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f32x4_t v = *reinterpret_cast<const f32x4_t*>(xr + 32 * T + 8 * q);
-        if constexpr (OUTPROJ) v += *reinterpret_cast<const f32x4_t*>(p.bo + 32 * T + 8 * q + 4 * h);
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(xr + 32 * T + 4 * q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc2[T][4 * q + i] = v[i];
       }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  h16x8_t wa[3], wb[3];
-  unsigned cur = transition(TB{});  // chunk 0
-  if constexpr (OUTPROJ) {
-    // ---- attention output projection: chunk c = k-steps 2c, 2c+1 x 12 output tiles (fragment 12 ksl + T); the B fragment of a k-step
-    //      is this lane's 16 contiguous bytes of its attention-output row ----
-    const h16_t* orow = p.attn_o + row * PC + 8 * h;
-    h16x8_t of0 = *reinterpret_cast<const h16x8_t*>(orow), of1 = *reinterpret_cast<const h16x8_t*>(orow + 16);
-    lds_read3<0, (ABL & 32) != 0>(cur, wa);
-    for (int c = 0; c < OUT_CHUNKS; ++c) {
-      const int cn = min(c + 1, OUT_CHUNKS - 1);
-      const h16x8_t nf0 = *reinterpret_cast<const h16x8_t*>(orow + 32 * cn), nf1 = *reinterpret_cast<const h16x8_t*>(orow + 32 * cn + 16);
-      sfor<8>([&](auto B_) {
-        constexpr int B = decltype(B_)::value;  // batch: fragments 3B .. 3B+2
-        h16x8_t(&wc)[3] = (B & 1) ? wb : wa;
-        h16x8_t(&wn)[3] = (B & 1) ? wa : wb;
-        if constexpr (B < 7) {
-          lds_read3<(3 * B + 3) * FRAG, (ABL & 32) != 0>(cur, wn);
-          CS_LGKM(3);
-        } else {
-          cur = transition(TB{});
-          lds_read3<0, (ABL & 32) != 0>(cur, wn);
-          CS_SB();
-        }
-        sfor<3>([&](auto I_) {
-          constexpr int F = 3 * B + decltype(I_)::value, T = F % 12;
-          if constexpr (ABL & 8) keep_alive(wc[decltype(I_)::value]);
-          else acc2[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[decltype(I_)::value], F < 12 ? of0 : of1, acc2[T], 0, 0, 0);
-        });
-        CS_SB();
-      });
-      of0 = nf0; of1 = nf1;
-    }
-    CS_LGKM(0);  // (the last transition's reads took the A half of chunk NOUT: unused)
-  }
+  CS_STAMP(2);
 
   // ---- LayerNorm statistics of the rows held in acc2 (two-pass, fp32, in registers; a row lives in lanes j and j + 32) ----
   auto row_stats = [&](float& mean, float& rstd) {
@@ -357,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     rstd = 1.0f / sqrtf(q * (1.0f / PC) + p.eps);
   };
   {
-    // norm2 -> the partner's fc1 B fragments: k-step 2T + s is registers 8s .. 8s+7 of tile T (kappa order, see the header)
+    // norm2 -> the partner's fc1 B fragments: k-step 2T + s is registers 8s .. 8s+7 of tile T
     float mean, rstd;
     row_stats(mean, rstd);
     const float nb = -mean * rstd;
@@ -378,93 +448,94 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     __builtin_amdgcn_s_barrier();  // H3
   }
   // the fc2 accumulators start at residual + bias: the residual add and the bias add are free
-#pragma unroll
-  for (int T = 0; T < NT; ++T)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.b2 + 32 * T + 8 * q + 4 * h);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc2[T][4 * q + i] += b4[i];
-    }
+  sfor<NT>([&](auto T_) { add_bias(T_, std::false_type{}, 1); });
+  CS_STAMP(3);
 
-  // ---- fc2, LAG half ticks behind fc1.  Half tick g >= LAG: fragments 12..23 of its chunk = (tile 6p + f/2, k-step f % 2), p = g & 1,
-  //      of hidden slice (g - LAG) / 2, whose activations are in hb slot ((g - LAG) / 2) & 1 ----
-  for (int g = 0; g < LAG; ++g) cur = transition(TB{});  // chunks NOUT+1 .. NOUT+LAG become current; `cur` = chunk NOUT + LAG
+  // ---- fc2, LAG half ticks behind fc1.  Half tick g >= LAG: fragments 12..23 of its chunk = tile f of k-step p = (g - LAG) & 1 of hidden
+  //      slice (g - LAG) / 2, whose activations are in hb slot ((g - LAG) / 2) & 1 ----
+  for (int g = 0; g < LAG - 1; ++g) cur = transition(TB{});  // chunks NOUT+1 .. NOUT+LAG-1 become current
   const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
   h16x8_t hb[2];
+  // Half p of a slice multiplies k-step p (activation fragment hb[p]) into all 12 tiles, so the other fragment register is free to be
+  // refilled meanwhile: after the transition inside half 1 comes fragment 0 of the NEXT slice (the partner wrote it before that barrier),
+  // after the one inside half 0 fragment 1 of the current slice.
+  auto hb_slot_addr = [&](int g_half) { return hb_addr + (((g_half - LAG) >> 1) & 1) * (4 * 2 * FRAG); };
   auto fc2_half = [&](auto P_, bool more) {
     constexpr int P = decltype(P_)::value;
-    if constexpr (P == 0) {  // a new slice: its activations (written by the partner before the barrier that made this chunk current)
-      const unsigned a = hb_addr + (((c_next - 1 - NOUT - LAG) >> 1) & 1) * (4 * 2 * FRAG);
-      lds_read1<0>(a, hb[0]);
-      lds_read1<FRAG>(a, hb[1]);
-    }
-    sfor<4>([&](auto B_) {
-      constexpr int B = decltype(B_)::value;  // batch: fragments 12 + 3B .. +2
-      h16x8_t(&wc)[3] = (B & 1) ? wb : wa;
-      h16x8_t(&wn)[3] = (B & 1) ? wa : wb;
-      if constexpr (B < 3) {
-        lds_read3<(12 + 3 * B + 3) * FRAG, (ABL & 32) != 0>(cur, wn);
-        CS_LGKM(3);
-      } else if (more) {
-        cur = transition(TB{});
-        lds_read3<12 * FRAG, (ABL & 32) != 0>(cur, wn);
-        CS_SB();
-      } else {
-        CS_LGKM(0);
+    sfor<12>([&](auto M_) {
+      constexpr int M = decltype(M_)::value;
+      if constexpr (M == 6) {
+        if (more) {
+          cur = transition(TB{}, true);
+          const int g_new = c_next - 1 - NOUT;  // the half tick that just became current
+          if constexpr (P == 1) lds_read1<0>(hb_slot_addr(g_new), hb[0]);
+          else lds_read1<FRAG>(hb_slot_addr(g_new), hb[1]);
+        }
       }
-      sfor<3>([&](auto I_) {
-        constexpr int F = 3 * B + decltype(I_)::value, T = 6 * P + F / 2, S = F % 2;
-        if constexpr (ABL & 8) keep_alive(wc[decltype(I_)::value]);
-        else acc2[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[decltype(I_)::value], hb[S], acc2[T], 0, 0, 0);
-      });
+      if constexpr (M >= 7 && M <= 10) {
+        if (more) issue_piece(TB{}, IC<M - 7>{});
+      }
+      CS_LGKM(5);
+      acc2[M] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], hb[P], acc2[M], 0, 0, 0);
+      if constexpr (M < 6) lds_read1<(12 + M + 6) * FRAG>(cur, w[M % 6]);
+      else lds_read1<(12 + M - 6) * FRAG>(cur, w[M % 6]);  // (after the last half tick: padding)
       CS_SB();
     });
   };
-  lds_read3<12 * FRAG, (ABL & 32) != 0>(cur, wa);
+  cur = transition(TB{});  // chunk NOUT + LAG: slice 0, half 0
+  lds_read1<0>(hb_addr, hb[0]);
+  sfor<6>([&](auto F_) { lds_read1<(12 + decltype(F_)::value) * FRAG>(cur, w[decltype(F_)::value]); });
   for (int t = 0; t < NSL - 1; ++t) {
     fc2_half(IC<0>{}, true);
     fc2_half(IC<1>{}, true);
   }
   fc2_half(IC<0>{}, true);
   fc2_half(IC<1>{}, false);
+  CS_LGKM(0);
   CS_VMCNT(0);  // the padding chunks' LDS-DMA has landed before the workgroup can end
+  CS_STAMP(4);
 
-  // ---- epilogue: new residual rows, and the next layer's normalised rows ----
+  // ---- epilogue: new residual rows, and the next layer's normalised rows (64 / 32 contiguous bytes per lane and tile) ----
   if (row_ok) {
-    float* xr = p.x + row * PC + 4 * h;
+    float* xr = p.x + row * PC + 16 * h;
 #pragma unroll
     for (int T = 0; T < NT; ++T)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<f32x4_t*>(xr + 32 * T + 8 * q) = f32x4_t{acc2[T][4 * q], acc2[T][4 * q + 1], acc2[T][4 * q + 2], acc2[T][4 * q + 3]};
+        *reinterpret_cast<f32x4_t*>(xr + 32 * T + 4 * q) = f32x4_t{acc2[T][4 * q], acc2[T][4 * q + 1], acc2[T][4 * q + 2], acc2[T][4 * q + 3]};
   }
   if (p.u_out) {
     float mean, rstd;
     row_stats(mean, rstd);
     const float nb = -mean * rstd;
     if (row_ok) {
-      h16_t* ur = p.u_out + row * PC + 4 * h;
+      h16_t* ur = p.u_out + row * PC + 16 * h;
 #pragma unroll
       for (int T = 0; T < NT; ++T)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float a0 = fmaf(acc2[T][4 * q], rstd, nb), a1 = fmaf(acc2[T][4 * q + 1], rstd, nb);
-          const float a2 = fmaf(acc2[T][4 * q + 2], rstd, nb), a3 = fmaf(acc2[T][4 * q + 3], rstd, nb);
-          *reinterpret_cast<uint2*>(ur + 32 * T + 8 * q) = make_uint2(pack_h16x2(a0, a1), pack_h16x2(a2, a3));
+        for (int q = 0; q < 2; ++q) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(acc2[T][8 * q + e], rstd, nb);
+          *reinterpret_cast<u32x4_t*>(ur + 32 * T + 8 * q) = pack8(v);
         }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CS_STAMP(5); CS_STAMP_RT(9);
 }
 
 // ---- weight image.  One thread per 16-byte fragment element (8 f16): [chunk][fragment 0..23][lane 0..63].  Lane (i = lane & 31,
-//      h = lane >> 5) of an A-operand fragment holds output feature i of its 32-feature tile and 8 contraction indices of its 16-wide
-//      k-step:  natural   : 8 h + e                                   (out-projection: its B fragments are loaded from memory)
-//               permuted  : kappa(h, e) = (e & 3) + 8 (e >> 2) + 4 h   (fc1 / fc2: their B fragments are accumulator tiles)
+//      h = lane >> 5) of an A-operand fragment holds MFMA row i of its 32-feature tile and 8 contraction indices of its 16-wide k-step.
+//      MFMA row i of a D tile is register r = (i & 3) + 4 (i >> 3) of lane half (i >> 2) & 1, and the kernel keeps feature
+//      32 T + 16 h + r there, so row i carries output feature  perm(i) = 16 ((i >> 2) & 1) + (i & 3) + 4 (i >> 3)  of its tile.
+//      Contraction index of element e:  natural  16 ks + 8 h + e                 (out-projection: B fragments come from memory)
+//                                       tiled    32 (ks >> 1) + 16 h + 8 (ks & 1) + e   (fc1 / fc2: B fragments are accumulator tiles)
 //      Chunks: [12 out-projection chunks c: fragment 12 ksl + T = (k-step 2c + ksl, tile T)]
-//              [100 MLP half ticks g: fragments 0..11  = fc1 slice g/2, k-step 12 (g&1) + f                         (g < 96)
-//                                     fragments 12..23 = fc2 slice (g-4)/2, tile 6 (g&1) + f'/2, k-step f' % 2       (g >= 4)]
+//              [101 MLP half ticks g: fragments 0..11  = fc1 slice g/2, k-step 12 (g&1) + f                                  (g < 96)
+//                                     fragments 12..23 = fc2 slice (g-5)/2, tile f', k-step (g-5) & 1                         (g >= 5)]
 //              [2 padding chunks] ----
+__device__ __forceinline__ int panel_perm(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restrict__ wo, const float* __restrict__ ls1,
                                                             const float* __restrict__ w1, const float* __restrict__ g2,
                                                             const float* __restrict__ w2, const float* __restrict__ ls2,
@@ -480,7 +551,7 @@ __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restr
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < nout) {
     const int ks = 2 * c + f / 12, T = f % 12;
-    const int rowi = 32 * T + i;
+    const int rowi = 32 * T + panel_perm(i);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = wo[(size_t)rowi * PC + 16 * ks + 8 * h + e] * (ls1 ? ls1[rowi] : 1.f);
   } else if (c < nch) {
@@ -488,20 +559,20 @@ __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restr
     if (f < 12) {
       if (g < 2 * NSL) {
         const int t = g >> 1, ks = 12 * (g & 1) + f;
-        const int rowi = 32 * t + i;
+        const int rowi = 32 * t + panel_perm(i);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int col = 16 * ks + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int col = 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + e;
           v[e] = w1[(size_t)rowi * PC + col] * (g2 ? g2[col] : 1.f);
         }
       }
     } else if (g >= LAG) {
       const int tt = (g - LAG) >> 1, fp = f - 12;
-      const int T = 6 * (g & 1) + fp / 2, s = fp % 2;
-      const int rowi = 32 * T + i;
+      const int T = fp, s = (g - LAG) & 1;
+      const int rowi = 32 * T + panel_perm(i);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int col = 32 * tt + 16 * s + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int col = 32 * tt + 16 * h + 8 * s + e;
         v[e] = w2[(size_t)rowi * PF + col] * (ls2 ? ls2[rowi] : 1.f);
       }
     }
@@ -513,6 +584,10 @@ __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restr
 }  // namespace
 
 extern "C" {
+
+#ifdef CS_PANEL_ABLATE
+int cs_panel_debug_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_panel_dbg), sizeof(g_panel_dbg)); }
+#endif
 
 int cs_panel_supported(int C, int mlp_ratio) { return C == PC && mlp_ratio * C == PF; }
 size_t cs_panel_image_bytes(int with_outproj) { return (size_t)((with_outproj ? OUT_CHUNKS : 0) + MLP_CHUNKS + PAD_CHUNKS) * CHUNK; }
@@ -528,7 +603,7 @@ const char* cs_panel_check(const CsPanelParams* p) {
   if (!p->x || !p->img || !p->b1 || !p->b2) return "panel: null operand";
   if (p->attn_o && !p->bo) return "panel: the out-projection needs its bias";
   if (p->M <= 0) return "panel: empty shape";
-  if ((long long)p->M * PC >= (1ll << 31)) return "panel: too many rows for 32-bit offsets";
+  if ((long long)p->M * PC * 4 >= (1ll << 32)) return "panel: too many rows for 32-bit byte offsets";
   if (((uintptr_t)p->x | (uintptr_t)p->img | (uintptr_t)p->b1 | (uintptr_t)p->b2 | (uintptr_t)p->attn_o | (uintptr_t)p->u_out | (uintptr_t)p->bo) & 15)
     return "panel: operands must be 16-byte aligned";
   return nullptr;
@@ -552,7 +627,7 @@ hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st) {
 #define CS_ABL_CASE(N) if (abl == N) { \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cs_panel_kernel<true, N>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
       hipLaunchKernelGGL((cs_panel_kernel<true, N>), dim3(grid), dim3(512), LDS_BYTES, st, *p); return hipGetLastError(); }
-    CS_ABL_CASE(1) CS_ABL_CASE(2) CS_ABL_CASE(4) CS_ABL_CASE(8) CS_ABL_CASE(16) CS_ABL_CASE(32) CS_ABL_CASE(12) CS_ABL_CASE(3) CS_ABL_CASE(47) CS_ABL_CASE(5)
+    CS_ABL_CASE(1) CS_ABL_CASE(2) CS_ABL_CASE(3) CS_ABL_CASE(16) CS_ABL_CASE(18)
 #undef CS_ABL_CASE
   }
 #endif

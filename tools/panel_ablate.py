@@ -4,8 +4,8 @@ round of workgroups (256 panels).  bits: 1 no GELU arithmetic, 2 no LDS-DMA afte
 theirs, 16 no per-chunk s_barrier, 32 no weight-fragment LDS reads."""
 import os, subprocess, sys, shutil, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if len(sys.argv) > 1 and sys.argv[1] == "child":
-    sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+if os.environ.get("CS_ABL_PKG"):  # child: crossscore_amd comes from the scratch copy that holds the ablation library
+    sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, os.environ["CS_ABL_PKG"])
     import torch
     import hip_helpers as hh
     from test_hip_panel import _make
@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     img = hh.panel_pack(w["wo"], w["ls1"], w["w1"], w["g2"], w["w2"], w["ls2"])
     res = {}
     for rnd in range(3):
-        for abl in (0, 1, 2, 3, 4, 8, 12, 16, 32, 5, 47):
+        for abl in (0, 1, 2, 3, 16, 18):
             os.environ["CS_PANEL_ABL"] = str(abl)
             for _ in range(2):
                 hh.encoder_panel(x, o, img, w["bo"], w["b1"], w["b2"])
@@ -28,11 +28,31 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             x.zero_().add_(1.0)  # ablated variants may write junk: keep the rows finite
     for abl, v in res.items():
         print(f"ABL={abl:2d}: min {min(v):7.1f} us  median {sorted(v)[len(v)//2]:7.1f} us", flush=True)
+    # phase stamps of the real kernel (ABL = 0): per role, median over blocks < 64 and the four pairs
+    import ctypes, numpy as np
+    from crossscore_amd import _lib
+    os.environ["CS_PANEL_ABL"] = "0"
+    for Mrows in (M, 129 * 128):
+        xs, os_, ws = _make(Mrows, 1, dev)
+        for _ in range(3):
+            hh.encoder_panel(xs, os_, img, w["bo"], w["b1"], w["b2"])
+        torch.cuda.synchronize()
+        buf = np.zeros(64 * 8 * 10, dtype=np.uint64)
+        lib = ctypes.CDLL(os.path.join(os.environ["CS_ABL_PKG"], "crossscore_amd", "libcrossscore_hip.so"))
+        assert lib.cs_panel_debug_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+        d = buf.reshape(64, 8, 10).astype(np.int64)
+        names = ["start->ring/bias|x loaded", "T0", "out-proj phase", "LN hand-off", "MLP", "tail/epilogue"]
+        for role, sl in (("A", slice(0, 4)), ("B", slice(4, 8))):
+            ph = np.diff(d[:, sl, 0:6], axis=2).reshape(-1, 5)
+            clk = (d[:, sl, 5] - d[:, sl, 0]) / np.maximum(d[:, sl, 9] - d[:, sl, 8], 1) * 100.0
+            print(f"M={Mrows} role {role}: phase cycles median", dict(zip(["prologue", "outproj", "handoff", "mlp", "tail"], np.median(ph, axis=0).astype(int).tolist())),
+                  f"total {int(np.median(ph.sum(1)))} cycles; clock ~{np.median(clk):.0f} MHz", flush=True)
     sys.exit(0)
 # parent: build the ablation library next to a copy of the package, then run the child against it
 tmp = tempfile.mkdtemp(prefix="panel_abl_")
 pkg = os.path.join(tmp, "crossscore_amd")
 shutil.copytree(os.path.join(R, "crossscore_amd"), pkg, ignore=shutil.ignore_patterns("*.so", "build", "__pycache__"))
+shutil.copytree(os.path.join(R, "include"), os.path.join(tmp, "include"))
 srcs = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip"]
 objs = []
 procs = []
@@ -45,7 +65,4 @@ for s in srcs:
 for p in procs:
     assert p.wait() == 0
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(pkg, "libcrossscore_hip.so")] + objs)
-env = dict(os.environ, PYTHONPATH=tmp + os.pathsep + os.path.join(R, "tests"))
-# the child imports crossscore_amd from the scratch copy (first on PYTHONPATH), tests/ helpers from the repo
-code = f"import sys; sys.argv=['x','child']; sys.path.insert(0, {tmp!r}); exec(open({os.path.abspath(__file__)!r}).read().replace('sys.path.insert(0, R);', ''))"
-sys.exit(subprocess.call([sys.executable, "-c", code], env=env))
+sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, CS_ABL_PKG=tmp)))
