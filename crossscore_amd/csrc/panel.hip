@@ -55,6 +55,10 @@ constexpr int LDS_HB = LDS_R + 4 * 12 * FRAG;        // 24 KiB: 3 slots x 4 pair
 constexpr int LDS_B1 = LDS_HB + 3 * 4 * 2 * FRAG;    // fc1 bias, fp32
 constexpr int LDS_BV = LDS_B1 + PF * 4;              // bo | b2, fp32
 constexpr int LDS_BYTES = LDS_BV + 2 * PC * 4;       // 153 KiB
+// epilogue staging (over the ring and R, idle by then): per pair 32 rows x 768 B (half a residual row, or a whole normalised f16 row), rows
+// padded to 784 B so that the B waves' 16-byte writes of 16 different rows and the A waves' row-contiguous reads are both conflict-free
+constexpr int ST_ROW = 784;
+constexpr int ST_PAIR = 32 * ST_ROW;
 
 #define CS_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define CS_SB() __builtin_amdgcn_sched_barrier(0) /* nothing crosses (any other mask let hipcc move MFMAs over the asm waits) */
@@ -112,10 +116,10 @@ __device__ __forceinline__ void dma_piece(const char* src, unsigned dst) {
 
 #ifdef CS_PANEL_ABLATE
 // diagnostic builds only: per (block < 64, wave) six s_memtime stamps + s_memrealtime at both ends (tools/panel_ablate.py)
-__device__ unsigned long long g_panel_dbg[64 * 8 * 10];
+__device__ unsigned long long g_panel_dbg[64 * 8 * 16];
 #define CS_STAMP(k) do { if (blockIdx.x < 64 && lane == 0) { \
-    __builtin_amdgcn_sched_barrier(0); g_panel_dbg[(blockIdx.x * 8 + wv) * 10 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define CS_STAMP_RT(k) do { if (blockIdx.x < 64 && lane == 0) g_panel_dbg[(blockIdx.x * 8 + wv) * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    __builtin_amdgcn_sched_barrier(0); g_panel_dbg[(blockIdx.x * 8 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define CS_STAMP_RT(k) do { if (blockIdx.x < 64 && lane == 0) g_panel_dbg[(blockIdx.x * 8 + wv) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CS_STAMP(k) do { } while (0)
 #define CS_STAMP_RT(k) do { } while (0)
@@ -137,7 +141,8 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   constexpr int NOUT = OUTPROJ ? OUT_CHUNKS : 0;
   // Chunks below SOLO are copied by the A waves alone (6 weight pieces each; during the out-projection also the pair's residual-row tile,
   // 4 pieces, and its two attention-output fragments): the B waves then issue no vector-memory instruction before the MLP phase.
-  // From SOLO on: A waves 2 weight pieces, B waves 4.
+  // From SOLO on the B waves copy everything (6 pieces each, one per MFMA gap of the second half of a half tick): the A wave's
+  // instruction stream (MFMA + GELU) is the longer one of a pair.
   constexpr int SOLO = NOUT + 3;
   const unsigned lds0 = (unsigned)(size_t)CS_LDS_PTR(smem);
   const unsigned lane16 = lane * 16;
@@ -172,15 +177,11 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           dma_piece<0>(osrc + c * 64 + 32, dof + FRAG);
         }
       }
-    } else if constexpr (!(ABL & 2)) {
-      if constexpr (ISA) {
-        dma_piece<0>(s + pair * 2 * FRAG, dst + pair * 2 * FRAG);
-        dma_piece<FRAG>(s + pair * 2 * FRAG, dst + pair * 2 * FRAG);
-      } else {
-        const char* s4 = s + (8 + pair * 4) * FRAG;
-        const unsigned d4 = dst + (8 + pair * 4) * FRAG;
-        dma_piece<0>(s4, d4); dma_piece<FRAG>(s4, d4); dma_piece<2 * FRAG>(s4, d4); dma_piece<3 * FRAG>(s4, d4);
-      }
+    } else if constexpr (!(ABL & 2) && !ISA) {
+      const char* s6 = s + pair * 6 * FRAG;
+      const unsigned d6 = dst + pair * 6 * FRAG;
+      dma_piece<0>(s6, d6); dma_piece<FRAG>(s6, d6); dma_piece<2 * FRAG>(s6, d6); dma_piece<3 * FRAG>(s6, d6);
+      dma_piece<0>(s6 + 4 * FRAG, d6 + 4 * FRAG); dma_piece<FRAG>(s6 + 4 * FRAG, d6 + 4 * FRAG);
     }
   };
   // transition into chunk c_next: this wave's LDS reads of the current chunk are complete (its slot is refilled right after the barrier) and
@@ -193,23 +194,33 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     constexpr bool ISA = decltype(ISA_)::value;
     constexpr int K = decltype(K_)::value;
     if constexpr (ABL & 2) return;
-    const unsigned dst = lds0 + LDS_RING + pend_slot * CHUNK + (ISA ? pair * 2 : 8 + pair * 4) * FRAG;
-    const char* s = reinterpret_cast<const char*>(p.img) + ((size_t)pend_c * CHUNK + (ISA ? pair * 2 : 8 + pair * 4) * FRAG) + lane16;
-    dma_piece<K * FRAG>(s, dst);
+    static_assert(!ISA, "from SOLO on only the B waves copy");
+    const unsigned dst = lds0 + LDS_RING + pend_slot * CHUNK + (pair * 6 + (K & 4)) * FRAG;
+    const char* s = reinterpret_cast<const char*>(p.img) + ((size_t)pend_c * CHUNK + (pair * 6 + (K & 4)) * FRAG) + lane16;
+    dma_piece<(K & 3) * FRAG>(s, dst);
   };
+  unsigned long long tw_drain = 0, tw_vm = 0, tw_bar = 0;  // (ABL & 64: where a transition's time goes, summed over the launch)
   auto transition = [&](auto ISA_, bool defer = false) -> unsigned {
     constexpr bool ISA = decltype(ISA_)::value;
     CS_SB();
+    unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
+    if constexpr (ABL & 64) { asm volatile("s_memtime %0" : "=s"(ta)::"memory"); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (ABL & 64) { asm volatile("s_memtime %0" : "=s"(tb)::"memory"); }
     if constexpr (ISA) {
       // pieces of chunk c_next + 1 that may still be in flight
       if (c_next + 1 < NOUT) CS_VMCNT(12);
       else if (c_next + 1 < SOLO) CS_VMCNT(6);
-      else CS_VMCNT(2);
+      else CS_VMCNT(0);
     } else {
-      CS_VMCNT(4);
+      CS_VMCNT(6);
     }
+    if constexpr (ABL & 64) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc)::"memory"); }
     if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+    if constexpr (ABL & 64) {
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td)::"memory");
+      tw_drain += tb - ta; tw_vm += tc - tb; tw_bar += td - tc;
+    }
     asm volatile("" ::: "memory");
     int s2 = slot_cur + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2;
     if (defer) { pend_c = c_next + 2; pend_slot = s2; }   // (only from SOLO on: the caller issues the pieces one by one)
@@ -281,8 +292,6 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           if constexpr (P == 1 && FC1) read_bias(t_next);  // (never leave an inline-asm read without a consumer: hipcc would reuse its
                                                            //  destination registers at once, and the LDS data would land on top of the new owner)
         }
-        if constexpr (M == 8) issue_piece(TA{}, IC<0>{});
-        if constexpr (M == 10) issue_piece(TA{}, IC<1>{});
         if constexpr (FC1) {
           CS_LGKM(5);
           if constexpr (P == 0 && M == 0) {
@@ -322,7 +331,48 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     // the B waves' last LAG - 2 half ticks
     for (int g = 0; g < LAG - 3; ++g) cur = transition(TA{});
     CS_VMCNT(0);  // the padding chunks' LDS-DMA has landed before the workgroup can end
-    CS_STAMP(5); CS_STAMP_RT(9);
+    CS_STAMP(5);
+    // ---- epilogue, A side: the partner stages its rows in LDS (three rounds: residual halves, normalised rows), this wave writes them to
+    //      memory as whole 128-byte lines: a store instruction covers 4 rows x 256 contiguous bytes (16 lanes x 16 B per row) ----
+    {
+      const unsigned st_addr = lds0 + pair * ST_PAIR + (lane >> 4) * ST_ROW + (lane & 15) * 16;
+      const int r_in = lane >> 4;
+      auto drain = [&](char* gbase, size_t row_bytes, int col_bytes) {  // gbase: row0's first byte of this round's 768-byte column range
+        (void)col_bytes;
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+          f32x4_t v[3];
+          lds_read_f4<0>(st_addr + rg * 4 * ST_ROW, v[0]);
+          lds_read_f4<256>(st_addr + rg * 4 * ST_ROW, v[1]);
+          lds_read_f4<512>(st_addr + rg * 4 * ST_ROW, v[2]);
+          CS_LGKM(0);
+          const int r = rg * 4 + r_in;
+          if (row0 + r < p.M) {
+            char* g = gbase + (size_t)r * row_bytes + (lane & 15) * 16;
+            *reinterpret_cast<f32x4_t*>(g) = v[0];
+            *reinterpret_cast<f32x4_t*>(g + 256) = v[1];
+            *reinterpret_cast<f32x4_t*>(g + 512) = v[2];
+          }
+        }
+      };
+      char* xg = reinterpret_cast<char*>(p.x + (size_t)row0 * PC);
+      __builtin_amdgcn_s_barrier();  // E0: every wave's LDS-DMA has landed (the staging area lies over the ring)
+      __builtin_amdgcn_s_barrier();  // E1: residual columns 0..191 staged
+      drain(xg, PC * 4, 768);
+      __builtin_amdgcn_s_barrier();  // E2: read
+      __builtin_amdgcn_s_barrier();  // E3: residual columns 192..383 staged
+      drain(xg + 768, PC * 4, 768);
+      __builtin_amdgcn_s_barrier();  // E4: read
+      if (p.u_out) {
+        __builtin_amdgcn_s_barrier();  // E5: normalised rows staged
+        drain(reinterpret_cast<char*>(p.u_out + (size_t)row0 * PC), PC * 2, 768);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CS_STAMP_RT(9);
+#ifdef CS_PANEL_ABLATE
+    if (blockIdx.x < 64 && lane == 0) { unsigned long long* d = g_panel_dbg + (blockIdx.x * 8 + wv) * 16; d[10] = tw_drain; d[11] = tw_vm; d[12] = tw_bar; }
+#endif
     return;
   }
 
@@ -472,8 +522,8 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           else lds_read1<FRAG>(hb_slot_addr(g_new), hb[1]);
         }
       }
-      if constexpr (M >= 7 && M <= 10) {
-        if (more) issue_piece(TB{}, IC<M - 7>{});
+      if constexpr (M >= 6) {
+        if (more) issue_piece(TB{}, IC<M - 6>{});
       }
       CS_LGKM(5);
       acc2[M] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], hb[P], acc2[M], 0, 0, 0);
@@ -495,34 +545,52 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   CS_VMCNT(0);  // the padding chunks' LDS-DMA has landed before the workgroup can end
   CS_STAMP(4);
 
-  // ---- epilogue: new residual rows, and the next layer's normalised rows (64 / 32 contiguous bytes per lane and tile) ----
-  if (row_ok) {
-    float* xr = p.x + row * PC + 16 * h;
-#pragma unroll
-    for (int T = 0; T < NT; ++T)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<f32x4_t*>(xr + 32 * T + 4 * q) = f32x4_t{acc2[T][4 * q], acc2[T][4 * q + 1], acc2[T][4 * q + 2], acc2[T][4 * q + 3]};
-  }
-  if (p.u_out) {
-    float mean, rstd;
-    row_stats(mean, rstd);
-    const float nb = -mean * rstd;
-    if (row_ok) {
-      h16_t* ur = p.u_out + row * PC + 16 * h;
-#pragma unroll
-      for (int T = 0; T < NT; ++T)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
+  // ---- epilogue, B side: rows go to memory through LDS and the partner (a lane holds 64 B of a row per tile: stored directly, every store
+  //      instruction would touch 32 rows) ----
+  {
+    const unsigned st_addr = lds0 + pair * ST_PAIR + j * ST_ROW + 64 * h;
+    auto stage_x = [&](auto HALF_) {
+      constexpr int HALF = decltype(HALF_)::value;
+      sfor<6>([&](auto T_) {
+        constexpr int T = 6 * HALF + decltype(T_)::value;
+        sfor<4>([&](auto Q_) {
+          constexpr int Q = decltype(Q_)::value;
+          lds_write16<decltype(T_)::value * 128 + 16 * Q>(st_addr, __builtin_bit_cast(u32x4_t, f32x4_t{acc2[T][4 * Q], acc2[T][4 * Q + 1], acc2[T][4 * Q + 2], acc2[T][4 * Q + 3]}));
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    __builtin_amdgcn_s_barrier();  // E0
+    stage_x(IC<0>{});
+    __builtin_amdgcn_s_barrier();  // E1
+    float mean = 0.f, rstd = 0.f;
+    if (p.u_out) row_stats(mean, rstd);  // (under the partner's stores)
+    __builtin_amdgcn_s_barrier();  // E2
+    stage_x(IC<1>{});
+    __builtin_amdgcn_s_barrier();  // E3
+    __builtin_amdgcn_s_barrier();  // E4
+    if (p.u_out) {
+      const float nb = -mean * rstd;
+      const unsigned su = lds0 + pair * ST_PAIR + j * ST_ROW + 32 * h;
+      sfor<NT>([&](auto T_) {
+        constexpr int T = decltype(T_)::value;
+        sfor<2>([&](auto Q_) {
+          constexpr int Q = decltype(Q_)::value;
           float v[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaf(acc2[T][8 * q + e], rstd, nb);
-          *reinterpret_cast<u32x4_t*>(ur + 32 * T + 8 * q) = pack8(v);
-        }
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(acc2[T][8 * Q + e], rstd, nb);
+          lds_write16<T * 64 + 16 * Q>(su, pack8(v));
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // E5
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   CS_STAMP(5); CS_STAMP_RT(9);
+#ifdef CS_PANEL_ABLATE
+  if (blockIdx.x < 64 && lane == 0) { unsigned long long* d = g_panel_dbg + (blockIdx.x * 8 + wv) * 16; d[10] = tw_drain; d[11] = tw_vm; d[12] = tw_bar; }
+#endif
 }
 
 // ---- weight image.  One thread per 16-byte fragment element (8 f16): [chunk][fragment 0..23][lane 0..63].  Lane (i = lane & 31,
@@ -627,7 +695,7 @@ hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st) {
 #define CS_ABL_CASE(N) if (abl == N) { \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cs_panel_kernel<true, N>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
       hipLaunchKernelGGL((cs_panel_kernel<true, N>), dim3(grid), dim3(512), LDS_BYTES, st, *p); return hipGetLastError(); }
-    CS_ABL_CASE(1) CS_ABL_CASE(2) CS_ABL_CASE(3) CS_ABL_CASE(16) CS_ABL_CASE(18)
+    CS_ABL_CASE(1) CS_ABL_CASE(2) CS_ABL_CASE(3) CS_ABL_CASE(16) CS_ABL_CASE(18) CS_ABL_CASE(64)
 #undef CS_ABL_CASE
   }
 #endif

@@ -37,16 +37,27 @@ if os.environ.get("CS_ABL_PKG"):  # child: crossscore_amd comes from the scratch
         for _ in range(3):
             hh.encoder_panel(xs, os_, img, w["bo"], w["b1"], w["b2"])
         torch.cuda.synchronize()
-        buf = np.zeros(64 * 8 * 10, dtype=np.uint64)
+        buf = np.zeros(64 * 8 * 16, dtype=np.uint64)
         lib = ctypes.CDLL(os.path.join(os.environ["CS_ABL_PKG"], "crossscore_amd", "libcrossscore_hip.so"))
         assert lib.cs_panel_debug_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-        d = buf.reshape(64, 8, 10).astype(np.int64)
+        d = buf.reshape(64, 8, 16).astype(np.int64)
         names = ["start->ring/bias|x loaded", "T0", "out-proj phase", "LN hand-off", "MLP", "tail/epilogue"]
         for role, sl in (("A", slice(0, 4)), ("B", slice(4, 8))):
             ph = np.diff(d[:, sl, 0:6], axis=2).reshape(-1, 5)
             clk = (d[:, sl, 5] - d[:, sl, 0]) / np.maximum(d[:, sl, 9] - d[:, sl, 8], 1) * 100.0
             print(f"M={Mrows} role {role}: phase cycles median", dict(zip(["prologue", "outproj", "handoff", "mlp", "tail"], np.median(ph, axis=0).astype(int).tolist())),
                   f"total {int(np.median(ph.sum(1)))} cycles; clock ~{np.median(clk):.0f} MHz", flush=True)
+    # where the transitions' time goes (ABL = 64: s_memtime around the LDS drain, the vmcnt wait and the barrier of every transition)
+    os.environ["CS_PANEL_ABL"] = "64"
+    xs, os_, ws = _make(M, 1, dev)
+    for _ in range(3):
+        hh.encoder_panel(xs, os_, img, w["bo"], w["b1"], w["b2"])
+    torch.cuda.synchronize()
+    assert lib.cs_panel_debug_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    d = buf.reshape(64, 8, 16).astype(np.int64)
+    for role, sl in (("A", slice(0, 4)), ("B", slice(4, 8))):
+        print(f"transitions, role {role}: cycles summed over the launch: LDS drain {int(np.median(d[:, sl, 10]))}, vmcnt {int(np.median(d[:, sl, 11]))}, "
+              f"barrier {int(np.median(d[:, sl, 12]))}; launch {int(np.median(d[:, sl, 5] - d[:, sl, 0]))}", flush=True)
     sys.exit(0)
 # parent: build the ablation library next to a copy of the package, then run the child against it
 tmp = tempfile.mkdtemp(prefix="panel_abl_")
