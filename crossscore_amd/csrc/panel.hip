@@ -46,6 +46,10 @@ constexpr int LAG = 5;                // half ticks the fc2 side runs behind the
 constexpr int MLP_CHUNKS = 2 * NSL + LAG;  // 101 half ticks
 constexpr int PAD_CHUNKS = 2;         // fetched by the last transitions, never read
 constexpr int PANEL_ROWS = 128;
+#ifndef CS_PANEL_NA
+#define CS_PANEL_NA 0
+#endif
+constexpr int NA_PIECES = CS_PANEL_NA;  // of a pair's 6 weight pieces per chunk (MLP phase) the A wave issues this many, the B wave the rest
 // LDS map
 constexpr int LDS_RING = 0;
 constexpr int LDS_R = NSLOT * CHUNK;                 // 48 KiB: 3 slots x 4 pairs x 4 KiB residual-row tiles (out-projection phase), then the
@@ -177,11 +181,14 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           dma_piece<0>(osrc + c * 64 + 32, dof + FRAG);
         }
       }
-    } else if constexpr (!(ABL & 2) && !ISA) {
+    } else if constexpr (!(ABL & 2)) {
+      // (a transition outside the half-tick loops: the wave's whole share at once)
       const char* s6 = s + pair * 6 * FRAG;
       const unsigned d6 = dst + pair * 6 * FRAG;
-      dma_piece<0>(s6, d6); dma_piece<FRAG>(s6, d6); dma_piece<2 * FRAG>(s6, d6); dma_piece<3 * FRAG>(s6, d6);
-      dma_piece<0>(s6 + 4 * FRAG, d6 + 4 * FRAG); dma_piece<FRAG>(s6 + 4 * FRAG, d6 + 4 * FRAG);
+      sfor<6>([&](auto K_) {
+        constexpr int K = decltype(K_)::value;
+        if constexpr (ISA == (K >= 6 - NA_PIECES)) dma_piece<(K & 3) * FRAG>(s6 + (K & 4) * FRAG, d6 + (K & 4) * FRAG);
+      });
     }
   };
   // transition into chunk c_next: this wave's LDS reads of the current chunk are complete (its slot is refilled right after the barrier) and
@@ -194,10 +201,10 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     constexpr bool ISA = decltype(ISA_)::value;
     constexpr int K = decltype(K_)::value;
     if constexpr (ABL & 2) return;
-    static_assert(!ISA, "from SOLO on only the B waves copy");
-    const unsigned dst = lds0 + LDS_RING + pend_slot * CHUNK + (pair * 6 + (K & 4)) * FRAG;
-    const char* s = reinterpret_cast<const char*>(p.img) + ((size_t)pend_c * CHUNK + (pair * 6 + (K & 4)) * FRAG) + lane16;
-    dma_piece<(K & 3) * FRAG>(s, dst);
+    constexpr int PIECE = ISA ? 6 - NA_PIECES + K : K;  // index among the pair's 6 pieces
+    const unsigned dst = lds0 + LDS_RING + pend_slot * CHUNK + (pair * 6 + (PIECE & 4)) * FRAG;
+    const char* s = reinterpret_cast<const char*>(p.img) + ((size_t)pend_c * CHUNK + (pair * 6 + (PIECE & 4)) * FRAG) + lane16;
+    dma_piece<(PIECE & 3) * FRAG>(s, dst);
   };
   unsigned long long tw_drain = 0, tw_vm = 0, tw_bar = 0;  // (ABL & 64: where a transition's time goes, summed over the launch)
   auto transition = [&](auto ISA_, bool defer = false) -> unsigned {
@@ -211,9 +218,9 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       // pieces of chunk c_next + 1 that may still be in flight
       if (c_next + 1 < NOUT) CS_VMCNT(12);
       else if (c_next + 1 < SOLO) CS_VMCNT(6);
-      else CS_VMCNT(0);
+      else CS_VMCNT(NA_PIECES);
     } else {
-      CS_VMCNT(6);
+      CS_VMCNT(6 - NA_PIECES);
     }
     if constexpr (ABL & 64) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc)::"memory"); }
     if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           if constexpr (P == 1 && FC1) read_bias(t_next);  // (never leave an inline-asm read without a consumer: hipcc would reuse its
                                                            //  destination registers at once, and the LDS data would land on top of the new owner)
         }
+        if constexpr (M >= 12 - NA_PIECES) issue_piece(TA{}, IC<M - (12 - NA_PIECES)>{});
         if constexpr (FC1) {
           CS_LGKM(5);
           if constexpr (P == 0 && M == 0) {
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           else lds_read1<FRAG>(hb_slot_addr(g_new), hb[1]);
         }
       }
-      if constexpr (M >= 6) {
+      if constexpr (M >= 6 && M < 12 - NA_PIECES) {
         if (more) issue_piece(TB{}, IC<M - 6>{});
       }
       CS_LGKM(5);

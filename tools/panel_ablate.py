@@ -15,7 +15,7 @@ if os.environ.get("CS_ABL_PKG"):  # child: crossscore_amd comes from the scratch
     img = hh.panel_pack(w["wo"], w["ls1"], w["w1"], w["g2"], w["w2"], w["ls2"])
     res = {}
     for rnd in range(3):
-        for abl in (0, 1, 2, 3, 16, 18):
+        for abl in [int(v) for v in os.environ.get('CS_PANEL_ABLS', '0,1,2,3,16,18').split(',')]:
             os.environ["CS_PANEL_ABL"] = str(abl)
             for _ in range(2):
                 hh.encoder_panel(x, o, img, w["bo"], w["b1"], w["b2"])
@@ -71,7 +71,7 @@ for s in srcs:
     o = os.path.join(tmp, s + ".o"); objs.append(o)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
     if s == "panel.hip":
-        cmd += ["-fno-slp-vectorize", "-DCS_PANEL_ABLATE"]
+        cmd += ["-fno-slp-vectorize", "-DCS_PANEL_ABLATE"] + os.environ.get("CS_PANEL_EXTRA", "").split()
     procs.append(subprocess.Popen(cmd + ["-c", os.path.join(pkg, "csrc", s), "-o", o]))
 for p in procs:
     assert p.wait() == 0
