@@ -20,7 +20,7 @@ class CsConfig(C.Structure):
         ("hidden", C.c_int), ("enc_layers", C.c_int), ("enc_heads", C.c_int), ("mlp_ratio", C.c_int),
         ("patch", C.c_int), ("pos_grid", C.c_int), ("pe_h", C.c_int), ("pe_w", C.c_int),
         ("dec_layers", C.c_int), ("dec_heads", C.c_int), ("do_self_attn", C.c_int), ("do_short_cut", C.c_int),
-        ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int), ("ln_fold", C.c_int), ("lanes", C.c_int), ("enc_fused", C.c_int),
+        ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int), ("ln_fold", C.c_int), ("lanes", C.c_int), ("pos_interp_legacy", C.c_int), ("enc_fused", C.c_int),
     ]
 
 
@@ -47,6 +47,7 @@ SYMBOLS = {
     "cs_op_attention_weights": (_i, [_vp, _vp, _i, _i, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "cs_op_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "cs_op_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cs_op_patch_embed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pos_bicubic": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pe_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_score_to_gray16": (_i, [_vp, C.c_longlong, _i, _vp, _vp]),

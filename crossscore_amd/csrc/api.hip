@@ -32,7 +32,7 @@ hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, c
 hipError_t cs_ln_fold_consts_launch(const h16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
                                     float* s_out, float* c_out, hipStream_t st);
 int cs_gemm_column_tiles(int N);
-hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float* out, hipStream_t st);
+hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float grow, float* out, hipStream_t st);
 hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st);
 hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
                                hipStream_t st);
@@ -316,7 +316,7 @@ int ensure_tables(cs_model* m, int gh, int gw, bool square, hipStream_t st) {
   } else {
     HIPCHK(hipMalloc(&t.pos_tab, (size_t)(1 + Np) * C * sizeof(float)));
     t.pos_owned = true;
-    HIPCHK(cs_pos_bicubic_launch(m->pos, c.pos_grid, C, gh, gw, t.pos_tab, st));
+    HIPCHK(cs_pos_bicubic_launch(m->pos, c.pos_grid, C, gh, gw, c.pos_interp_legacy ? 0.1f : 0.0f, t.pos_tab, st));
   }
   if (gh == c.pe_h && gw == c.pe_w) {  // positional_encoding.py:51-56
     t.pe_tab = m->pe;
@@ -964,6 +964,37 @@ int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int 
   return 0;
 }
 
+// Patch embedding as the forward runs it (im2col -> MFMA GEMM with the PATCH epilogue), for op-level tests of the mean-centred form:
+// centred != 0: every patch's per-channel mean is removed before the fp16 rounding (im2col_rows_kernel) and added back in fp32 as
+// mean_ch * sum_taps W[n][ch] by the epilogue (patch_wsum_kernel).  x (I,3,H,W), w (C,3,P,P), bias (C), pos ((1 + Np), C) -> out (I * (1 + Np), C)
+// fp32 with the patch rows written (CLS rows untouched).  Allocates its temporaries: a test entry point, not a hot path.
+int cs_op_patch_embed(const float* x, const float* w, const float* bias, const float* pos, int I, int H, int W, int P, int C, int centred,
+                      float* out, cs_stream stream) {
+  if (!x || !w || !bias || !pos || !out || I <= 0 || P != 14 || H < P || W < P || C <= 0 || C % 64) return fail(CS_ERR_BAD_ARG, "patch_embed: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int gh = H / P, gw = W / P, Np = gh * gw, Kp = ((3 * P * P + 63) / 64) * 64;
+  h16_t *A = nullptr, *Wp = nullptr; float *pmean = nullptr, *wsum = nullptr;
+  HIPCHK(hipMalloc(&A, (size_t)I * Np * Kp * sizeof(h16_t)));
+  HIPCHK(hipMalloc(&Wp, (size_t)C * Kp * sizeof(h16_t)));
+  HIPCHK(hipMalloc(&pmean, (size_t)I * Np * 4 * sizeof(float)));
+  HIPCHK(hipMalloc(&wsum, (size_t)3 * C * sizeof(float)));
+  int rc = 0;
+  auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = fail(CS_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
+  chk(cs_pack_f16_launch(w, C, 3 * P * P, Wp, Kp, nullptr, nullptr, st), "pack");
+  chk(cs_patch_wsum_launch(w, C, P, wsum, st), "wsum");
+  chk(cs_im2col_launch(x, nullptr, 0, 0, A, I, H, W, P, Kp, centred ? pmean : nullptr, st), "im2col");
+  if (!rc) {
+    CsGemmParams g = gp(A, Kp, Wp, Kp, I * Np, C, Kp, bias, out, C);
+    g.pos = pos; g.Np = Np;
+    if (centred) { g.pmean = pmean; g.wsum = wsum; }
+    if (const char* e = cs_gemm_check(&g, CS_EPI_PATCH_F32)) rc = fail(CS_ERR_BAD_ARG, "%s", e);
+    else chk(cs_gemm_launch(&g, CS_EPI_PATCH_F32, st), "gemm");
+  }
+  chk(hipStreamSynchronize(st), "sync");
+  hipFree(A); hipFree(Wp); hipFree(pmean); hipFree(wsum);
+  return rc;
+}
+
 int cs_op_preprocess_u8(const uint8_t* img, int in_h, int in_w, int in_row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int out_h,
                         int out_w, const float* mean3, const float* std3, float* out, float* scratch, cs_stream stream) {
   if (!img || !out || !mean3 || !std3 || in_h <= 0 || in_w <= 0 || in_row_bytes < 3 * in_w || rs_h <= 0 || rs_w <= 0 || out_h <= 0 ||
@@ -991,7 +1022,7 @@ int cs_op_score_to_rgb(const float* score, long long n, float vmin, float vmax, 
 
 int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream) {
   if (!pos || !out || G <= 0 || C <= 0 || gh <= 0 || gw <= 0) return fail(CS_ERR_BAD_ARG, "pos_bicubic: bad arguments");
-  HIPCHK(cs_pos_bicubic_launch(pos, G, C, gh, gw, out, (hipStream_t)stream));
+  HIPCHK(cs_pos_bicubic_launch(pos, G, C, gh, gw, 0.0f, out, (hipStream_t)stream));
   return 0;
 }
 

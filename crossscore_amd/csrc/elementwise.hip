@@ -268,7 +268,10 @@ __global__ __launch_bounds__(64) void cls_rows_kernel(float* x, int I, int T, in
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
 
-__global__ void pos_bicubic_kernel(const float* __restrict__ pos, int G, int C, int gh, int gw, float* __restrict__ out) {
+// `grow` = 0: source coordinate (dst + 0.5) * G / gh - 0.5, what F.interpolate(size=(h, w)) of transformers >= 4.4x computes;
+// `grow` = 0.1: (dst + 0.5) * G / (gh + 0.1) - 0.5, what interpolate_pos_encoding of the reference's pinned transformers 4.33.3 /
+// torch 2.1.2 computes (scale_factor = ((h + 0.1) / G, (w + 0.1) / G), environment.yaml:293,340).
+__global__ void pos_bicubic_kernel(const float* __restrict__ pos, int G, int C, int gh, int gw, float grow, float* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)(1 + gh * gw) * C;
   if (i >= total) return;
@@ -277,8 +280,8 @@ __global__ void pos_bicubic_kernel(const float* __restrict__ pos, int G, int C, 
   if (t == 0) { out[i] = pos[c]; return; }
   const int oy = (t - 1) / gw, ox = (t - 1) - oy * gw;
   const float A = -0.75f;
-  const float sy = (oy + 0.5f) * ((float)G / (float)gh) - 0.5f;
-  const float sx = (ox + 0.5f) * ((float)G / (float)gw) - 0.5f;
+  const float sy = (oy + 0.5f) * ((float)G / ((float)gh + grow)) - 0.5f;
+  const float sx = (ox + 0.5f) * ((float)G / ((float)gw + grow)) - 0.5f;
   const float fy = floorf(sy), fx = floorf(sx);
   const float ty = sy - fy, tx = sx - fx;
   const int iy = (int)fy, ix = (int)fx;
@@ -469,9 +472,9 @@ hipError_t cs_ln_fold_consts_launch(const h16_t* wp, int ldp, const float* w, co
   return hipGetLastError();
 }
 
-hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float* out, hipStream_t st) {
+hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float grow, float* out, hipStream_t st) {
   const long long total = (long long)(1 + gh * gw) * C;
-  hipLaunchKernelGGL(pos_bicubic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pos, G, C, gh, gw, out);
+  hipLaunchKernelGGL(pos_bicubic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pos, G, C, gh, gw, grow, out);
   return hipGetLastError();
 }
 

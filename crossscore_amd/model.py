@@ -100,6 +100,9 @@ class CrossScoreNet(torch.nn.Module):
         self._dirty = True
         self.enc_chunk_images = 0  # 0 = library default
         self.lanes = 0             # 0 = library default (2 concurrent lanes); 1 = serial
+        # encoder position-embedding resize: "size" (installed transformers, the goldens) or "scale_factor" (the reference's pinned 4.33.3);
+        # an optional key of THIS build under model.backbone (the reference has no such key): pos_embed_interpolation
+        self._pos_legacy = str(cfg.model.backbone.get("pos_embed_interpolation", "size")) == "scale_factor"
         self.enc_fused = 0         # 0 = token-panel kernel per encoder layer where supported (hidden 384), 1 = unfused kernels
         self.ln_fold = 0           # 1 = fold the encoder LayerNorms into the QKV / fc1 GEMM epilogues (opt-in; slower so far)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
@@ -133,7 +136,7 @@ class CrossScoreNet(torch.nn.Module):
                            pos_grid=a.pos_grid, pe_h=a.pe_h, pe_w=a.pe_w, dec_layers=a.dec_layers, dec_heads=a.dec_heads,
                            do_self_attn=int(bool(m.decoder_do_self_attn)), do_short_cut=int(bool(m.decoder_do_short_cut)),
                            act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold),
-                           lanes=int(self.lanes), enc_fused=int(self.enc_fused))
+                           lanes=int(self.lanes), pos_interp_legacy=int(self._pos_legacy), enc_fused=int(self.enc_fused))
         with torch.cuda.device(device):
             h = lib.cs_create(C.byref(cc))
             if not h:

@@ -60,6 +60,9 @@ typedef struct cs_config {
   int ln_fold;       /* 1: encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass; opt-in, measured
                       * slower on MI355X); 0: separate LayerNorm kernels (default) */
   int lanes;         /* internal streams that run independent image chunks / batch groups concurrently: 0 = default (2), 1 = serial, up to 4 */
+  int pos_interp_legacy; /* encoder position-embedding resize (grids other than 37 x 37, or H != W): 0 = F.interpolate(size=(h, w)), the installed
+                       * transformers (>= 4.4x; what the goldens were generated with); 1 = scale_factor ((h + 0.1) / 37, (w + 0.1) / 37) as
+                       * in the reference's pinned transformers 4.33.3 (environment.yaml:340): source coordinates shrink by h / (h + 0.1) */
   int enc_fused;      /* encoder layer structure: 0 = default: with hidden == 384 (ViT-S) each layer is QKV GEMM + attention + ONE
                        * token-panel kernel (out-projection, residual, norm2, fc1, GELU, fc2, residual and the next layer's norm1; the 4C
                        * hidden activations stay in registers), else the unfused kernels; 1 = always the unfused kernels */
@@ -125,6 +128,11 @@ int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int l
 int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
                     uint16_t* out_bf16, cs_stream stream);
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream);
+/* The patch embedding exactly as the forward runs it (HF modeling_dinov2.py:141-149: conv patchify = im2col + GEMM, + position rows), with
+ * (centred != 0) or without the mean-centred operand form: x (I,3,H,W), w (C,3,P,P), bias (C), pos (1 + Np, C) -> out (I * (1 + Np), C) fp32,
+ * patch rows only.  Test entry point (allocates and synchronises). */
+int cs_op_patch_embed(const float* x, const float* w, const float* bias, const float* pos, int I, int H, int W, int P, int C, int centred,
+                      float* out, cs_stream stream);
 /* Input stage: device uint8 HWC image (3 channels, rows in_row_bytes apart) -> fp32 CHW [3][out_h][out_w], the
  * tensor cs_forward consumes.  Same operations, in the same order, as the reference's CPU transforms: x/255 (utils/io/images.py:14-29),
  * antialiased bilinear resize to (rs_h, rs_w) (T.Resize, task/predict.py:87-93; skipped when equal to the input size), crop window

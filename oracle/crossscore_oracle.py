@@ -83,14 +83,14 @@ def _cubic_coeffs(t: Tensor, A: float = -0.75):
     return c2(t + 1.0), c1(t), c1(1.0 - t), c2(2.0 - t)
 
 
-def bicubic_resize_grid(grid: Tensor, oh: int, ow: int) -> Tensor:
+def bicubic_resize_grid(grid: Tensor, oh: int, ow: int, grow: float = 0.0) -> Tensor:
     """F.interpolate(size=(oh,ow), mode='bicubic', align_corners=False) of a (gh,gw,C) grid, as used by
     Dinov2Embeddings.interpolate_pos_encoding (HF:57-95).  src = (dst+0.5)*in/out-0.5 (not clamped for
     cubic), 4 taps with border-clamped indices, separable."""
     gh, gw, C = grid.shape
 
     def axis(n_in: int, n_out: int):
-        scale = n_in / n_out
+        scale = n_in / (n_out + grow)  # grow = 0.1: the scale_factor form of transformers 4.33.3 (see encoder_pos_embed)
         dst = torch.arange(n_out, dtype=torch.float32)
         src = (dst + 0.5) * scale - 0.5
         i0 = torch.floor(src)
@@ -150,19 +150,22 @@ def patch_embed(imgs: Tensor, Wt: Dict[str, Tensor], P: int, rnd) -> Tensor:
     return linear(x, wmat, Wt["backbone.embeddings.patch_embeddings.projection.bias"], rnd)
 
 
-def encoder_pos_embed(Wt: Dict[str, Tensor], h: int, w: int, H: int, W: int) -> Tensor:
-    """(1+h*w, C) position table: parameter as is when grid matches and H==W, else bicubic (HF:57-95)."""
+def encoder_pos_embed(Wt: Dict[str, Tensor], h: int, w: int, H: int, W: int, legacy: bool = False) -> Tensor:
+    """(1+h*w, C) position table: parameter as is when grid matches and H==W, else bicubic (HF:57-95).
+    legacy=True: the interpolation call of the reference's PINNED transformers 4.33.3 (environment.yaml:340), which passed
+    scale_factor=((h + 0.1) / G, (w + 0.1) / G) -- torch then maps dst -> (dst + 0.5) * G / (h + 0.1) - 0.5 -- instead of size=(h, w).
+    That release is not installable offline, so this branch is a restatement of its published source, not pinned by a golden."""
     pos = Wt["backbone.embeddings.position_embeddings"][0]  # (1+G*G, C)
     G2 = pos.shape[0] - 1
     if h * w == G2 and H == W:
         return pos
     G = int(round(math.sqrt(G2)))
     grid = pos[1:].reshape(G, G, -1)
-    res = bicubic_resize_grid(grid, h, w).reshape(h * w, -1)
+    res = bicubic_resize_grid(grid, h, w, 0.1 if legacy else 0.0).reshape(h * w, -1)
     return torch.cat([pos[:1], res], dim=0)
 
 
-def dinov2_encoder(imgs: Tensor, Wt: Dict[str, Tensor], enc_heads: int, P: int, rnd, taps=None) -> Tensor:
+def dinov2_encoder(imgs: Tensor, Wt: Dict[str, Tensor], enc_heads: int, P: int, rnd, taps=None, pos_legacy: bool = False) -> Tensor:
     """Dinov2Model.forward -> last_hidden_state (I,1+h*w,C).  HF:97-116 embeddings, HF:361-380 layers
     (pre-LN, LayerScale, exact GELU), HF:465-470 final LayerNorm."""
     I, _, H, W = imgs.shape
@@ -171,7 +174,7 @@ def dinov2_encoder(imgs: Tensor, Wt: Dict[str, Tensor], enc_heads: int, P: int, 
     if taps is not None:
         taps["patch_embed"] = x.clone()
     cls = Wt["backbone.embeddings.cls_token"].expand(I, -1, -1)
-    x = torch.cat([cls, x], dim=1) + encoder_pos_embed(Wt, h, w, H, W)[None]
+    x = torch.cat([cls, x], dim=1) + encoder_pos_embed(Wt, h, w, H, W, pos_legacy)[None]
     if taps is not None:
         taps["embeddings"] = x.clone()
     l = 0
@@ -310,7 +313,7 @@ def forward(Wt: Dict[str, Tensor], cfg: dict, query_img: Tensor, ref_cross_imgs:
     h, w = H // P, W // P
     # get_featmaps: core.py:119-161
     all_imgs = torch.cat([query_img.view(B, 1, 3, H, W), ref_cross_imgs], dim=1).view(B * (1 + N), 3, H, W)
-    hs = dinov2_encoder(all_imgs, Wt, c["enc_heads"], P, rnd, taps)
+    hs = dinov2_encoder(all_imgs, Wt, c["enc_heads"], P, rnd, taps, bool(c.get("pos_interp_legacy", False)))
     if taps is not None:
         taps["last_hidden_state"] = hs.clone()
     fm = hs[:, 1:].reshape(B, 1 + N, h * w, -1)

@@ -128,3 +128,14 @@ def encoder_panel(x, attn_o, img, bo, b1, b2, want_u=True, eps=1e-6):
     u = torch.zeros((M, x.shape[1]), dtype=torch.float16, device=x.device) if want_u else None
     _lib.check(lib.cs_op_encoder_panel(_p(x), _p(attn_o), _p(img), _p(bo), _p(b1), _p(b2), _p(u), M, eps, _stream()))
     return u
+
+
+def patch_embed(x, w, bias, pos, P, centred):
+    """(I,3,H,W) images -> (I * (1 + Np), C) fp32 token rows (patch rows written, CLS rows left at 7.0)."""
+    lib = _lib.load()
+    I, _, H, W = x.shape
+    C_ = w.shape[0]
+    Np = (H // P) * (W // P)
+    out = torch.full((I * (1 + Np), C_), 7.0, dtype=torch.float32, device=x.device)
+    _lib.check(lib.cs_op_patch_embed(_p(x), _p(w), _p(bias), _p(pos), I, H, W, P, C_, int(centred), _p(out), _stream()))
+    return out

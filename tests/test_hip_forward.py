@@ -236,6 +236,21 @@ def test_fp16_operand_range_on_scaled_up_weights():
     assert mae < MAE_TOL, (mae, mx)
 
 
+def test_pos_embed_scale_factor_interpolation_option():
+    """model.backbone.pos_embed_interpolation=scale_factor: the encoder position-embedding resize of the reference's pinned
+    transformers 4.33.3 (scale_factor=((h+0.1)/G, (w+0.1)/G)) instead of the installed size=(h, w).  The HIP table follows the oracle's
+    restatement of it, and the two conventions really differ on a resized grid (so the switch is live)."""
+    net, arch, sd = _net(TINY, 31, **{"backbone.pos_embed_interpolation": "scale_factor"})
+    q, r = synth.make_inputs(1, 2, 75, 90, 6)
+    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    ref_legacy = _oracle(arch, sd, q, r, pos_interp_legacy=True)["score_map_ref_cross"]
+    ref_size = _oracle(arch, sd, q, r)["score_map_ref_cross"]
+    mae, mx = _compare(out, ref_legacy)
+    assert mae < MAE_TOL and mx < 2 * MAX_TOL, (mae, mx)
+    assert float((ref_legacy - ref_size).abs().mean()) > 3 * mae
+
+
 def test_batch8_vits_matches_oracle_per_item_and_is_batch_invariant():
     """cfg-2 (ViT-S, 518^2, N=5, B=8): item 3 of the batch against the oracle; every item must equal the same item run
     alone (batch shard equivalence: shards are independent, so results are bitwise identical)."""

@@ -193,6 +193,51 @@ def test_gemm_patch_epilogue_and_im2col():
     assert (o3[:, 0] == 7.0).all()  # CLS rows untouched by the GEMM
 
 
+def test_patch_embed_mean_centred_vs_fp32_conv():
+    """Mean-centred patch embedding (im2col_rows_kernel's per-patch channel means + the PATCH epilogue's mean * sum(W) term) against
+    an fp32 convolution (HF modeling_dinov2.py:141-149) on smooth, natural-image-like input, where a patch is mostly its mean: the
+    centred form must beat the plain one clearly, and noise input (patch means ~ 0) must be unaffected."""
+    I, H, W, P, Cc = 2, 98, 112, 14, 128
+    gh, gw = H // P, W // P
+    Np = gh * gw
+    g = _rng(17)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    smooth = np.stack([[1.8 * np.sin(xx / (19.0 + 3 * c) + i) + 1.2 * np.cos(yy / (23.0 + c)) + 0.7 * (c - 1) for c in range(3)] for i in range(I)]).astype(np.float32)
+    smooth += 0.05 * g.standard_normal(smooth.shape, dtype=np.float32)
+    noise = g.standard_normal((I, 3, H, W), dtype=np.float32)
+    wconv = _t(g.standard_normal((Cc, 3, P, P), dtype=np.float32) / math.sqrt(588))
+    b = _t(g.standard_normal((Cc,), dtype=np.float32))
+    pos = _t(g.standard_normal((1 + Np, Cc), dtype=np.float32))
+    errs = {}
+    for name, img in (("smooth", smooth), ("noise", noise)):
+        x = _t(img)
+        ref = torch.nn.functional.conv2d(x.double(), wconv.double(), b.double(), stride=P).flatten(2).transpose(1, 2) + pos[None, 1:].double()
+        for centred in (0, 1):
+            out = hh.patch_embed(x, wconv, b, pos, P, centred).reshape(I, 1 + Np, Cc)
+            torch.cuda.synchronize()
+            assert (out[:, 0] == 7.0).all()
+            errs[(name, centred)] = float((out[:, 1:].double() - ref).abs().mean())
+    print("patch embedding mean abs error vs fp64 conv:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs[("smooth", 1)] < 0.5 * errs[("smooth", 0)]           # the coherent weight-rounding term is gone
+    assert errs[("smooth", 1)] < 1.5 * errs[("noise", 1)] + 1e-4      # and what is left is ordinary operand rounding
+    assert abs(errs[("noise", 1)] - errs[("noise", 0)]) < 0.2 * errs[("noise", 0)] + 1e-5
+
+
+def test_attention_dh96_long_keys():
+    """Decoder cross-attention at ViT-B size: dh = 96, Lk = 13 690 (cfg-3: 10 references of 1369 patches), ragged in both directions."""
+    dh, heads, Lq, Lk = 96, 8, 300, 13690
+    g = _rng(96)
+    Q = _bf(_t(1.5 * g.standard_normal((1, Lq, heads * dh), dtype=np.float32)))
+    K = _bf(_t(1.5 * g.standard_normal((1, Lk, heads * dh), dtype=np.float32)))
+    V = _bf(_t(g.standard_normal((1, Lk, heads * dh), dtype=np.float32)))
+    O, lse = hh.attention(Q, K, V, heads, dh, lse=True)
+    ref, _, lse_ref = _attn_ref(Q, K, V, heads, dh)
+    torch.cuda.synchronize()
+    err = (O.float() - ref).abs()
+    assert err.max() < 2e-2 and err.mean() < 2e-3, (float(err.max()), float(err.mean()))
+    assert (lse * math.log(2.0) - lse_ref).abs().max() < 2e-3
+
+
 @pytest.mark.parametrize("act,powp", [(0, 1.0), (0, 2.0), (0, 0.5), (1, 1.0)])
 def test_gemm_head_score_jigsaw(act, powp):
     """sigmoid/tanh (+pow) + jigsaw store (regression_layer.py:26-62, utils/misc/image.py:8-21)."""
