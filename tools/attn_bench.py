@@ -1,6 +1,7 @@
 """Times the attention kernel alone at the three sites of cfg-2 (HIP events): encoder self-attention (48 images x 6 heads, 1370 tokens,
 dh 64), decoder self-attention (8 x 8 heads, 1369, dh 48), cross-attention (8 x 8 heads, 1369 x 6845, dh 48).
-CS_ATTN_VARIANTS="QT=1,QT=2": also builds the library with -DCS_ATTN_<..> per variant into scratch directories and times each."""
+CS_ATTN_VARIANTS="A=1,B=2+C=3": also builds the library with -DCS_ATTN_<..> per variant (experiment macros a kernel under study may
+read) into scratch directories and times each in turn."""
 import os, subprocess, sys, shutil, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if os.environ.get("CS_ATTN_CHILD"):
@@ -36,14 +37,12 @@ for var in [None] + variants:
         pkg = os.path.join(tmp, "crossscore_amd")
         shutil.copytree(os.path.join(R, "crossscore_amd"), pkg, ignore=shutil.ignore_patterns("*.so", "build", "__pycache__"))
         shutil.copytree(os.path.join(R, "include"), os.path.join(tmp, "include"))
-        if var == "OLD":  # the committed kernel (git HEAD), for same-box comparisons
-            shutil.copy(os.path.join(R, "tools", "attn_old.hip.txt"), os.path.join(pkg, "csrc", "attention.hip"))
         objs, procs = [], []
         for s in srcs:
             o = os.path.join(tmp, s + ".o"); objs.append(o)
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
             if s in ("panel.hip", "attention.hip"): cmd += ["-fno-slp-vectorize"]
-            if s == "attention.hip" and var != "OLD": cmd += ["-DCS_ATTN_" + d for d in var.split("+")]
+            if s == "attention.hip": cmd += ["-DCS_ATTN_" + d for d in var.split("+")]
             procs.append(subprocess.Popen(cmd + ["-c", os.path.join(pkg, "csrc", s), "-o", o]))
         for pr in procs: assert pr.wait() == 0
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(pkg, "libcrossscore_hip.so")] + objs)
