@@ -39,27 +39,24 @@ constexpr int NT = PC / 32;           // 12 output tiles of 32 features
 constexpr int KS = PC / 16;           // 24 k-steps over C
 constexpr int NSL = PF / 32;          // 48 hidden slices of 32
 constexpr int FRAG = 1024;            // bytes of one MFMA operand fragment (64 lanes x 16 B)
-constexpr int CHUNK = 24 * FRAG;      // ring chunk
-constexpr int NSLOT = 3;
-constexpr int OUT_CHUNKS = KS / 2;    // out-projection: 12 chunks of two k-steps x 12 tiles
-constexpr int LAG = 5;                // half ticks the fc2 side runs behind the fc1 side
-constexpr int MLP_CHUNKS = 2 * NSL + LAG;  // 101 half ticks
-constexpr int PAD_CHUNKS = 2;         // fetched by the last transitions, never read
+constexpr int CHUNK = 24 * FRAG;      // out-projection unit: two k-steps x 12 tiles
+constexpr int TICK = 48 * FRAG;       // MLP unit: one tick = [24 fragments of an fc1 slice (A waves) | 24 of an fc2 slice (B waves)]
+constexpr int OUT_CHUNKS = KS / 2;    // 12 out-projection units
+constexpr int LAGT = 2;               // ticks the fc2 side runs behind the fc1 side
+constexpr int NTICK = NSL + LAGT;     // 50 MLP units
+constexpr int PAD_TICKS = 1;          // fetched by the last transition, never read
 constexpr int PANEL_ROWS = 128;
-#ifndef CS_PANEL_NA
-#define CS_PANEL_NA 0
-#endif
-constexpr int NA_PIECES = CS_PANEL_NA;  // of a pair's 6 weight pieces per chunk (MLP phase) the A wave issues this many, the B wave the rest
-// LDS map
+// LDS map.  Out-projection phase: 3 ring slots of 24 KiB, the residual-row tiles and attention-output fragments that travel with them.
+// MLP phase: 2 ring slots of 48 KiB (one barrier per tick) over the ring and the start of the then-idle tile region, activation slots.
 constexpr int LDS_RING = 0;
-constexpr int LDS_R = NSLOT * CHUNK;                 // 48 KiB: 3 slots x 4 pairs x 4 KiB residual-row tiles (out-projection phase), then the
-                                                     //         norm2(x) hand-off, 12 fragments per pair at a time
-constexpr int LDS_HB = LDS_R + 4 * 12 * FRAG;        // 24 KiB: 3 slots x 4 pairs x 2 attention-output fragments (out-projection phase), then
-                                                     //         2 slots x 4 pairs x 2 activation fragments (MLP phase)
-constexpr int LDS_B1 = LDS_HB + 3 * 4 * 2 * FRAG;    // fc1 bias, fp32
+constexpr int LDS_X = 3 * CHUNK;                     // 72 K: 3 slots x 4 pairs x 4 KiB residual-row tiles
+constexpr int LDS_OF = LDS_X + 3 * 4 * 4 * FRAG;     // 120 K: 3 slots x 4 pairs x 2 attention-output fragments
+constexpr int LDS_XF = 2 * TICK;                     // 96 K: norm2(x) hand-off, 4 pairs x 12 fragments at a time (48 KiB; ends at 144 K)
+constexpr int LDS_HB = LDS_OF;                       // 120 K: 2 slots x 4 pairs x 2 activation fragments (MLP phase)
+constexpr int LDS_B1 = LDS_OF + 3 * 4 * 2 * FRAG;    // 144 K: fc1 bias, fp32
 constexpr int LDS_BV = LDS_B1 + PF * 4;              // bo | b2, fp32
 constexpr int LDS_BYTES = LDS_BV + 2 * PC * 4;       // 153 KiB
-// epilogue staging (over the ring and R, idle by then): per pair 32 rows x 768 B (half a residual row, or a whole normalised f16 row), rows
+// epilogue staging (over the ring, idle by then): per pair 32 rows x 768 B (half a residual row, or a whole normalised f16 row), rows
 // padded to 784 B so that the B waves' 16-byte writes of 16 different rows and the A waves' row-contiguous reads are both conflict-free
 constexpr int ST_ROW = 784;
 constexpr int ST_PAIR = 32 * ST_ROW;
@@ -130,7 +127,7 @@ __device__ unsigned long long g_panel_dbg[64 * 8 * 16];
 #endif
 
 // ABL: timing-only ablations (tools/panel_ablate.py builds them with -DCS_PANEL_ABLATE; results are wrong by design):
-//   1 no GELU arithmetic, 2 no weight LDS-DMA after the prologue, 16 no s_barrier per chunk
+//   1 no GELU arithmetic, 2 no weight LDS-DMA after the first two MLP units, 16 no s_barrier per unit, 64 transition-time accounting
 template <bool OUTPROJ, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -143,84 +140,66 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   const int row0 = blockIdx.x * PANEL_ROWS + pair * 32;
   const size_t row = (size_t)min(row0 + j, p.M - 1);
   constexpr int NOUT = OUTPROJ ? OUT_CHUNKS : 0;
-  // Chunks below SOLO are copied by the A waves alone (6 weight pieces each; during the out-projection also the pair's residual-row tile,
-  // 4 pieces, and its two attention-output fragments): the B waves then issue no vector-memory instruction before the MLP phase.
-  // From SOLO on the B waves copy everything (6 pieces each, one per MFMA gap of the second half of a half tick): the A wave's
-  // instruction stream (MFMA + GELU) is the longer one of a pair.
-  constexpr int SOLO = NOUT + 3;
+  constexpr size_t IMG_MLP = (size_t)NOUT * CHUNK;  // byte offset of MLP unit 0 in the image
   const unsigned lds0 = (unsigned)(size_t)CS_LDS_PTR(smem);
   const unsigned lane16 = lane * 16;
   // per-lane 32-bit byte offsets (the 64-bit addresses are formed where they are used, from the kernel arguments: no address pair stays live)
   const unsigned xoff = (unsigned)row * (PC * 4) + 64 * h;  // this lane's 16 floats of tile 0 of its residual row (M * 1536 < 2^32: cs_panel_check)
   const unsigned ooff = (unsigned)row * (PC * 2) + 16 * h;  // this lane's 8 halves of k-step 0 of its attention-output row
 
-  int c_next = 0;    // next chunk to make current
-  int slot_cur = 0;  // ring slot of chunk c_next
-  auto ring_issue = [&](auto ISA_, int c, int slot) {
-    constexpr bool ISA = decltype(ISA_)::value;
-    const unsigned dst = lds0 + LDS_RING + slot * CHUNK;
-    const char* s = reinterpret_cast<const char*>(p.img) + (size_t)c * CHUNK + lane16;
-    if (c < SOLO) {
-      if constexpr (ISA) {
-        if constexpr (!(ABL & 2)) {
-          const char* s6 = s + pair * 6 * FRAG;
-          const unsigned d6 = dst + pair * 6 * FRAG;
-          dma_piece<0>(s6, d6); dma_piece<FRAG>(s6, d6); dma_piece<2 * FRAG>(s6, d6); dma_piece<3 * FRAG>(s6, d6);
-          dma_piece<0>(s6 + 4 * FRAG, d6 + 4 * FRAG); dma_piece<FRAG>(s6 + 4 * FRAG, d6 + 4 * FRAG);
-        }
-        if (OUTPROJ && c < NOUT) {
-          // residual-row tile c in the accumulator layout (piece q = registers 4q .. 4q+3 of every lane) and the B fragments of k-steps 2c, 2c+1
-          const unsigned dx = lds0 + LDS_R + (slot * 4 + pair) * 4 * FRAG;
-          const char* sx = reinterpret_cast<const char*>(p.x) + (size_t)(xoff + c * 128);
-          const char* osrc = reinterpret_cast<const char*>(p.attn_o) + (size_t)ooff;
-          dma_piece<0>(sx, dx);
-          // (the immediate offset applies to both sides: source quarter q is 16 q bytes on, its LDS piece 1024 q)
-          dma_piece<0>(sx + 16, dx + FRAG); dma_piece<0>(sx + 32, dx + 2 * FRAG); dma_piece<0>(sx + 48, dx + 3 * FRAG);
-          const unsigned dof = lds0 + LDS_HB + (slot * 4 + pair) * 2 * FRAG;
-          dma_piece<0>(osrc + c * 64, dof);
-          dma_piece<0>(osrc + c * 64 + 32, dof + FRAG);
-        }
-      }
-    } else if constexpr (!(ABL & 2)) {
-      // (a transition outside the half-tick loops: the wave's whole share at once)
-      const char* s6 = s + pair * 6 * FRAG;
-      const unsigned d6 = dst + pair * 6 * FRAG;
-      sfor<6>([&](auto K_) {
-        constexpr int K = decltype(K_)::value;
-        if constexpr (ISA == (K >= 6 - NA_PIECES)) dma_piece<(K & 3) * FRAG>(s6 + (K & 4) * FRAG, d6 + (K & 4) * FRAG);
-      });
-    }
+  // Units: u < NOUT an out-projection chunk (24 KiB, ring slot u % 3, fetched two units ahead); u = NOUT + t MLP tick t (48 KiB, ring slot
+  // t % 2, fetched one unit ahead).  The A waves copy the out-projection units (with their pair's residual-row tile and attention-output
+  // fragments) and MLP ticks 0 and 1 -- the B waves issue no vector-memory instruction before the MLP phase --, the B waves every later
+  // tick, one 1-KiB piece per MFMA gap.
+  int u_next = 0;  // next unit to make current
+  auto out_unit_issue = [&](int c) {  // A waves: out-projection chunk c with its tile and fragments
+    const int slot = c % 3;
+    const unsigned dst = lds0 + LDS_RING + slot * CHUNK + pair * 6 * FRAG;
+    const char* s6 = reinterpret_cast<const char*>(p.img) + (size_t)c * CHUNK + pair * 6 * FRAG + lane16;
+    dma_piece<0>(s6, dst); dma_piece<FRAG>(s6, dst); dma_piece<2 * FRAG>(s6, dst); dma_piece<3 * FRAG>(s6, dst);
+    dma_piece<0>(s6 + 4 * FRAG, dst + 4 * FRAG); dma_piece<FRAG>(s6 + 4 * FRAG, dst + 4 * FRAG);
+    // residual-row tile c in the accumulator layout (piece q = registers 4q .. 4q+3 of every lane) and the B fragments of k-steps 2c, 2c+1
+    const unsigned dx = lds0 + LDS_X + (slot * 4 + pair) * 4 * FRAG;
+    const char* sx = reinterpret_cast<const char*>(p.x) + (size_t)(xoff + c * 128);
+    dma_piece<0>(sx, dx); dma_piece<0>(sx + 16, dx + FRAG); dma_piece<0>(sx + 32, dx + 2 * FRAG); dma_piece<0>(sx + 48, dx + 3 * FRAG);
+    const unsigned dof = lds0 + LDS_OF + (slot * 4 + pair) * 2 * FRAG;
+    const char* so = reinterpret_cast<const char*>(p.attn_o) + (size_t)(ooff + c * 64);
+    dma_piece<0>(so, dof); dma_piece<0>(so + 32, dof + FRAG);
   };
-  // transition into chunk c_next: this wave's LDS reads of the current chunk are complete (its slot is refilled right after the barrier) and
-  // its own LDS-DMA pieces of chunk c_next have landed; barrier (the same holds for every wave); then the chunk two ahead of c_next goes into
-  // the slot of the chunk before c_next.  Returns this lane's LDS address of fragment 0 of chunk c_next.
-  int pend_c = 0, pend_slot = 0;  // chunk / slot whose weight pieces a deferred transition left to issue_piece()
-  // piece K of this wave's share of chunk pend_c (MLP phase only: A waves 2 pieces, B waves 4), issued between MFMAs instead of in a
-  // burst behind the barrier: an LDS-DMA costs its wave 60+ cycles of issue, during which the partner keeps the matrix pipe busy
-  auto issue_piece = [&](auto ISA_, auto K_) {
-    constexpr bool ISA = decltype(ISA_)::value;
+  int pend_t = 0;          // tick whose pieces issue_piece() copies
+  bool pend_late = false;  // pieces 6..11 of it are still to be issued (in the first gaps of the next tick)
+  // piece K (0..11) of this pair's twelve 1-KiB pieces of tick pend_t
+  auto issue_piece = [&](auto K_) {
     constexpr int K = decltype(K_)::value;
-    if constexpr (ABL & 2) return;
-    constexpr int PIECE = ISA ? 6 - NA_PIECES + K : K;  // index among the pair's 6 pieces
-    const unsigned dst = lds0 + LDS_RING + pend_slot * CHUNK + (pair * 6 + (PIECE & 4)) * FRAG;
-    const char* s = reinterpret_cast<const char*>(p.img) + ((size_t)pend_c * CHUNK + (pair * 6 + (PIECE & 4)) * FRAG) + lane16;
-    dma_piece<(PIECE & 3) * FRAG>(s, dst);
+    const unsigned dst = lds0 + LDS_RING + (pend_t & 1) * TICK + (pair * 12 + (K & ~3)) * FRAG;
+    const char* s = reinterpret_cast<const char*>(p.img) + (IMG_MLP + (size_t)pend_t * TICK + (pair * 12 + (K & ~3)) * FRAG) + lane16;
+    dma_piece<(K & 3) * FRAG>(s, dst);
+  };
+  auto tick_issue_all = [&](int t) {  // a wave's whole share of tick t at once (outside the tick loops)
+    pend_t = t;
+    sfor<12>([&](auto K_) {
+      constexpr int K = decltype(K_)::value;
+      const unsigned dst = lds0 + LDS_RING + (t & 1) * TICK + (pair * 12 + (K & ~3)) * FRAG;
+      const char* s = reinterpret_cast<const char*>(p.img) + (IMG_MLP + (size_t)t * TICK + (pair * 12 + (K & ~3)) * FRAG) + lane16;
+      dma_piece<(K & 3) * FRAG>(s, dst);
+    });
   };
   unsigned long long tw_drain = 0, tw_vm = 0, tw_bar = 0;  // (ABL & 64: where a transition's time goes, summed over the launch)
+  // transition into unit u_next: this wave's LDS reads of the current unit are complete (its slot may be refilled right after the barrier)
+  // and its own LDS-DMA pieces of unit u_next have landed; barrier (the same holds for every wave); then the next fetch is started (or, with
+  // `defer`, left to issue_piece() between the caller's MFMAs).  Returns this lane's LDS address of fragment 0 of unit u_next.
   auto transition = [&](auto ISA_, bool defer = false) -> unsigned {
     constexpr bool ISA = decltype(ISA_)::value;
     CS_SB();
     unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
     if constexpr (ABL & 64) { asm volatile("s_memtime %0" : "=s"(ta)::"memory"); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr (ABL & 64) { asm volatile("s_memtime %0" : "=s"(tb)::"memory"); }
+    if constexpr (ABL & 64) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb)::"memory"); }
     if constexpr (ISA) {
-      // pieces of chunk c_next + 1 that may still be in flight
-      if (c_next + 1 < NOUT) CS_VMCNT(12);
-      else if (c_next + 1 < SOLO) CS_VMCNT(6);
-      else CS_VMCNT(NA_PIECES);
+      if (u_next + 1 < NOUT) CS_VMCNT(12);  // the out-projection unit after u_next may still be in flight
+      else CS_VMCNT(0);
     } else {
-      CS_VMCNT(6 - NA_PIECES);
+      CS_VMCNT(0);
     }
     if constexpr (ABL & 64) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc)::"memory"); }
     if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
@@ -229,18 +208,25 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       tw_drain += tb - ta; tw_vm += tc - tb; tw_bar += td - tc;
     }
     asm volatile("" ::: "memory");
-    int s2 = slot_cur + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2;
-    if (defer) { pend_c = c_next + 2; pend_slot = s2; }   // (only from SOLO on: the caller issues the pieces one by one)
-    else ring_issue(ISA_, c_next + 2, s2);  // the image ends with PAD_CHUNKS, so the stream needs no tail case
-    const unsigned base = lds0 + LDS_RING + slot_cur * CHUNK + lane16;
-    ++c_next;
-    slot_cur = slot_cur + 1 >= NSLOT ? 0 : slot_cur + 1;
+    if (u_next + 2 < NOUT) {
+      if constexpr (ISA && OUTPROJ) out_unit_issue(u_next + 2);
+    } else if (u_next + 1 >= NOUT) {
+      const int t = u_next + 1 - NOUT;  // the tick to fetch now (the image ends with PAD_TICKS: no tail case)
+      if (t < 2) {
+        if constexpr (ISA) tick_issue_all(t);
+      } else if constexpr (!ISA && !(ABL & 2)) {
+        if (defer) { pend_t = t; pend_late = true; }
+        else tick_issue_all(t);
+      }
+    }
+    const unsigned base = lds0 + LDS_RING + lane16 + (u_next < NOUT ? (u_next % 3) * CHUNK : ((u_next - NOUT) & 1) * TICK);
+    ++u_next;
     CS_SB();  // (register-only MFMAs must not be scheduled above the waits of this statement)
     return base;
   };
   using TA = std::true_type;
   using TB = std::false_type;
-  h16x8_t w[6];  // rolling pool of weight fragments: fragment k of a chunk lives in w[k % 6], five reads ahead of its MFMA
+  h16x8_t w[6];  // rolling pool of weight fragments: fragment k of a unit lives in w[k % 6], five reads ahead of its MFMA
 
   if (is_a) {
     // =====================================================================================================================
@@ -255,15 +241,15 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       reinterpret_cast<f32x4_t*>(smem + LDS_BV + PC * 4)[tid] = reinterpret_cast<const f32x4_t*>(p.b2)[tid];
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    ring_issue(TA{}, 0, 0);
-    ring_issue(TA{}, 1, 1);
-    unsigned cur = transition(TA{});                       // chunk 0
+    if constexpr (OUTPROJ) { out_unit_issue(0); out_unit_issue(1); }
+    else tick_issue_all(0);
+    unsigned cur = transition(TA{});                       // unit 0
     CS_STAMP(1);
-    for (int c = 0; c < NOUT; ++c) cur = transition(TA{});  // the B waves multiply chunks 0 .. NOUT-1; `cur` ends at chunk NOUT
+    for (int c = 0; c < NOUT; ++c) cur = transition(TA{});  // the B waves multiply units 0 .. NOUT-1; `cur` ends at MLP tick 0
     CS_STAMP(2);
-    // ---- norm2(x) from the partner: two halves of 12 fragments through the R region ----
+    // ---- norm2(x) from the partner: two halves of 12 fragments through the hand-off region ----
     h16x8_t xf[KS];
-    const unsigned r_addr = lds0 + LDS_R + pair * 12 * FRAG + lane16;
+    const unsigned r_addr = lds0 + LDS_XF + pair * 12 * FRAG + lane16;
     __builtin_amdgcn_s_barrier();  // H1: first half written
     sfor<12>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(r_addr, xf[decltype(F_)::value]); });
     CS_LGKM(0);
@@ -273,9 +259,9 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     CS_LGKM(0);
     CS_STAMP(3);
 
-    // ---- fc1 ticks.  Tick t: acc(t & 1) = b1 + W1[slice t] . xf (two half ticks = two chunks of 12 fragments); the GELU of slice t-1 (the
-    //      other accumulator) rides in the gaps between the MFMAs, one value per gap in 8 of the 12 gaps of a half tick, and leaves as two B
-    //      fragments in hb slot (t-1) & 1 (the partner reads them LAG half ticks after the slice's first half tick) ----
+    // ---- fc1 ticks.  Tick t: acc(t & 1) = b1 + W1[slice t] . xf (24 fragments of the tick's unit); the GELU of slice t-1 (the other
+    //      accumulator) rides in the gaps between the MFMAs, one value per gap in the first 16 gaps, and leaves as two B fragments in hb slot
+    //      (t-1) & 1 before the tick's transition (gap 18): the partner multiplies them from tick t+1 on ----
     f32x16_t acE, acO;  // even / odd slices
     const unsigned bias_addr = lds0 + LDS_B1 + 64 * h;
     const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
@@ -285,24 +271,20 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       const unsigned a = bias_addr + t * 128;
       lds_read_f4<0>(a, bb[0]); lds_read_f4<16>(a, bb[1]); lds_read_f4<32>(a, bb[2]); lds_read_f4<48>(a, bb[3]);
     };
-    // One half tick: per fragment m [counted wait for it; MFMA; read of fragment m + 6 (of the next chunk from m = 6 on); a GELU value];
-    // the transition to the next chunk sits before fragment 6, when all 12 fragments of this chunk are in registers or behind it in the
-    // LDS queue.  P = 0: k-steps 0..11, GELU values 0..7 -> hb fragment 0; P = 1: k-steps 12..23, values 8..15 -> hb fragment 1, and the
-    // next slice's bias.
-    auto half_tick = [&](auto P_, auto FC1_, f32x16_t& acc, const f32x16_t& act, int hb_slot, int t_next) {
-      constexpr int P = decltype(P_)::value;
+    // One tick: per fragment m [counted wait for it; MFMA; read of fragment m + 6 (of the next unit from m = 18 on); a GELU value]; the
+    // transition to the next unit sits before fragment 18, when all 24 fragments of this unit are in registers or behind it in the LDS queue.
+    auto tick = [&](auto FC1_, f32x16_t& acc, const f32x16_t& act, int hb_slot, int t_next) {
       constexpr bool FC1 = decltype(FC1_)::value;
-      sfor<12>([&](auto M_) {
+      sfor<24>([&](auto M_) {
         constexpr int M = decltype(M_)::value;
-        if constexpr (M == 6) {
-          cur = transition(TA{}, true);
-          if constexpr (P == 1 && FC1) read_bias(t_next);  // (never leave an inline-asm read without a consumer: hipcc would reuse its
-                                                           //  destination registers at once, and the LDS data would land on top of the new owner)
+        if constexpr (M == 18) {
+          cur = transition(TA{});
+          if constexpr (FC1) read_bias(t_next);  // (never leave an inline-asm read without a consumer: hipcc would reuse its destination
+                                                 //  registers at once, and the LDS data would land on top of the new owner)
         }
-        if constexpr (M >= 12 - NA_PIECES) issue_piece(TA{}, IC<M - (12 - NA_PIECES)>{});
         if constexpr (FC1) {
           CS_LGKM(5);
-          if constexpr (P == 0 && M == 0) {
+          if constexpr (M == 0) {
             f32x16_t b16;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -310,14 +292,14 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
               for (int i = 0; i < 4; ++i) b16[4 * q + i] = bb[q][i];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], xf[0], b16, 0, 0, 0);
           } else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], xf[12 * P + M], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], xf[M], acc, 0, 0, 0);
           }
-          if constexpr (M < 6) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
-          else lds_read1<(M - 6) * FRAG>(cur, w[M % 6]);
+          if constexpr (M < 18) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
+          else lds_read1<(M - 18) * FRAG>(cur, w[M % 6]);
         }
-        constexpr int G = (M % 3 == 2) ? -1 : (M / 3) * 2 + (M % 3);  // gaps 0,1,3,4,6,7,9,10 carry GELU values 0..7 of this half
-        if constexpr (G >= 0) gv[G] = (ABL & 1) ? act[8 * P + G] : gelu_erf1(act[8 * P + G]);
-        if constexpr (M == 11) lds_write16<P * FRAG>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv));
+        if constexpr (M < 16) gv[M & 7] = (ABL & 1) ? act[M] : gelu_erf1(act[M]);
+        if constexpr (M == 7) lds_write16<0>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv));
+        if constexpr (M == 15) lds_write16<FRAG>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv));
         CS_SB();
       });
     };
@@ -326,27 +308,22 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acO[i] = 0.f;  // tick 0 "activates" this (slice -1: never read by the partner)
     for (int t = 0; t < NSL; t += 2) {
-      half_tick(IC<0>{}, std::true_type{}, acE, acO, 1, 0);
-      half_tick(IC<1>{}, std::true_type{}, acE, acO, 1, t + 1);
-      half_tick(IC<0>{}, std::true_type{}, acO, acE, 0, 0);
-      half_tick(IC<1>{}, std::true_type{}, acO, acE, 0, min(t + 2, NSL - 1));
+      tick(std::true_type{}, acE, acO, 1, t + 1);
+      tick(std::true_type{}, acO, acE, 0, min(t + 2, NSL - 1));
     }
     CS_STAMP(4);
     // tick NSL: only the GELU of the last slice (odd)
     CS_LGKM(0);
-    half_tick(IC<0>{}, std::false_type{}, acE, acO, 1, 0);
-    half_tick(IC<1>{}, std::false_type{}, acE, acO, 1, NSL - 1);
-    // the B waves' last LAG - 2 half ticks
-    for (int g = 0; g < LAG - 3; ++g) cur = transition(TA{});
-    CS_VMCNT(0);  // the padding chunks' LDS-DMA has landed before the workgroup can end
+    tick(std::false_type{}, acE, acO, 1, 0);
+    // (this was the transition into the last tick, NTICK - 1: the B waves' last slice)
+    CS_VMCNT(0);  // every LDS-DMA has landed before the workgroup can end
     CS_STAMP(5);
     // ---- epilogue, A side: the partner stages its rows in LDS (three rounds: residual halves, normalised rows), this wave writes them to
     //      memory as whole 128-byte lines: a store instruction covers 4 rows x 256 contiguous bytes (16 lanes x 16 B per row) ----
     {
       const unsigned st_addr = lds0 + pair * ST_PAIR + (lane >> 4) * ST_ROW + (lane & 15) * 16;
       const int r_in = lane >> 4;
-      auto drain = [&](char* gbase, size_t row_bytes, int col_bytes) {  // gbase: row0's first byte of this round's 768-byte column range
-        (void)col_bytes;
+      auto drain = [&](char* gbase, size_t row_bytes) {  // gbase: row0's first byte of this round's 768-byte column range
 #pragma unroll
         for (int rg = 0; rg < 8; ++rg) {
           f32x4_t v[3];
@@ -366,14 +343,14 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       char* xg = reinterpret_cast<char*>(p.x + (size_t)row0 * PC);
       __builtin_amdgcn_s_barrier();  // E0: every wave's LDS-DMA has landed (the staging area lies over the ring)
       __builtin_amdgcn_s_barrier();  // E1: residual columns 0..191 staged
-      drain(xg, PC * 4, 768);
+      drain(xg, PC * 4);
       __builtin_amdgcn_s_barrier();  // E2: read
       __builtin_amdgcn_s_barrier();  // E3: residual columns 192..383 staged
-      drain(xg + 768, PC * 4, 768);
+      drain(xg + 768, PC * 4);
       __builtin_amdgcn_s_barrier();  // E4: read
       if (p.u_out) {
         __builtin_amdgcn_s_barrier();  // E5: normalised rows staged
-        drain(reinterpret_cast<char*>(p.u_out + (size_t)row0 * PC), PC * 2, 768);
+        drain(reinterpret_cast<char*>(p.u_out + (size_t)row0 * PC), PC * 2);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -389,9 +366,8 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   // =======================================================================================================================
   CS_STAMP_RT(8); CS_STAMP(0);
   f32x16_t acc2[NT];
-  const bool row_ok = row0 + j < p.M;
   const unsigned bv_addr = lds0 + LDS_BV + 64 * h;
-  unsigned cur = transition(TB{});  // chunk 0 (and: the bias vectors are in LDS)
+  unsigned cur = transition(TB{});  // unit 0 (and: the bias vectors are in LDS)
   CS_STAMP(1);
   auto add_bias = [&](auto T_, auto INIT_, int which) {  // acc2[T] (+)= bias[32 T + 16 h + r]
     constexpr int T = decltype(T_)::value;
@@ -405,16 +381,16 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       for (int i = 0; i < 4; ++i) acc2[T][4 * q + i] = (decltype(INIT_)::value ? 0.f : acc2[T][4 * q + i]) + b4[q][i];
   };
   if constexpr (OUTPROJ) {
-    // ---- attention output projection.  Chunk c = k-steps 2c, 2c+1 x 12 output tiles (fragment 12 ksl + T).  Its B fragments (this lane's
-    //      16 B of its attention-output row per k-step) and residual-row tile c arrive in LDS with the chunk (copied by the partner). ----
+    // ---- attention output projection.  Unit c = k-steps 2c, 2c+1 x 12 output tiles (fragment 12 ksl + T).  Its B fragments (this lane's
+    //      16 B of its attention-output row per k-step) and residual-row tile c arrive in LDS with the unit (copied by the partner). ----
     sfor<NT>([&](auto T_) { add_bias(T_, std::true_type{}, 0); });
-    const unsigned xs_addr = lds0 + LDS_R + pair * 4 * FRAG + lane16;
-    const unsigned of_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
+    const unsigned xs_addr = lds0 + LDS_X + pair * 4 * FRAG + lane16;
+    const unsigned of_addr = lds0 + LDS_OF + pair * 2 * FRAG + lane16;
     h16x8_t of[2];
     lds_read1<0>(of_addr, of[0]);
     lds_read1<FRAG>(of_addr, of[1]);
     sfor<6>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(cur, w[decltype(F_)::value]); });
-    int slot_x = 0;  // ring slot of the current chunk (its residual tile / attention-output fragments share the index)
+    int slot_x = 0;  // ring slot of the current unit (its residual tile / attention-output fragments share the index)
     sfor<OUT_CHUNKS>([&](auto C_) {
       constexpr int C = decltype(C_)::value;
       f32x4_t xs[2];
@@ -429,14 +405,14 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       };
       sfor<24>([&](auto M_) {
         constexpr int M = decltype(M_)::value;
-        // the chunk's residual-row tile C, two quarters at a time (its LDS slot is refilled after the transition below)
+        // the unit's residual-row tile C, two quarters at a time (its LDS slot is refilled after the transition below)
         if constexpr (M == 12) { const unsigned a = xs_addr + slot_x * (4 * 4 * FRAG); lds_read_f4<0>(a, xs[0]); lds_read_f4<FRAG>(a, xs[1]); }
         if constexpr (M == 14) add_x(IC<0>{});
         if constexpr (M == 15) { const unsigned a = xs_addr + slot_x * (4 * 4 * FRAG); lds_read_f4<2 * FRAG>(a, xs[0]); lds_read_f4<3 * FRAG>(a, xs[1]); }
         if constexpr (M == 17) add_x(IC<2>{});
         if constexpr (M == 18) {
           cur = transition(TB{});
-          slot_x = slot_x + 1 >= NSLOT ? 0 : slot_x + 1;
+          slot_x = slot_x + 1 >= 3 ? 0 : slot_x + 1;
           if constexpr (C + 1 < OUT_CHUNKS) lds_read1<0>(of_addr + slot_x * (4 * 2 * FRAG), of[0]);  // k-step 0's fragment is free from M = 12 on
         }
         if constexpr (M == 0 && C > 0) lds_read1<FRAG>(of_addr + slot_x * (4 * 2 * FRAG), of[1]);  // (needed from M = 12 on)
@@ -444,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
         constexpr int T = M % 12;
         acc2[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], of[M / 12], acc2[T], 0, 0, 0);
         if constexpr (M < 18) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
-        else lds_read1<(M - 18) * FRAG>(cur, w[M % 6]);  // (after the last chunk: the A half of chunk NOUT, unused)
+        else lds_read1<(M - 18) * FRAG>(cur, w[M % 6]);  // (after the last unit: the A half of MLP tick 0, unused)
         CS_SB();
       });
     });
@@ -489,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     float mean, rstd;
     row_stats(mean, rstd);
     const float nb = -mean * rstd;
-    const unsigned r_addr = lds0 + LDS_R + pair * 12 * FRAG + lane16;
+    const unsigned r_addr = lds0 + LDS_XF + pair * 12 * FRAG + lane16;
     auto put = [&](auto T_, auto S_) {
       constexpr int T = decltype(T_)::value, S = decltype(S_)::value;
       float v[8];
@@ -509,48 +485,43 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   sfor<NT>([&](auto T_) { add_bias(T_, std::false_type{}, 1); });
   CS_STAMP(3);
 
-  // ---- fc2, LAG half ticks behind fc1.  Half tick g >= LAG: fragments 12..23 of its chunk = tile f of k-step p = (g - LAG) & 1 of hidden
-  //      slice (g - LAG) / 2, whose activations are in hb slot ((g - LAG) / 2) & 1 ----
-  for (int g = 0; g < LAG - 1; ++g) cur = transition(TB{});  // chunks NOUT+1 .. NOUT+LAG-1 become current
+  // ---- fc2, LAGT ticks behind fc1.  Tick t >= LAGT: fragments 24 .. 47 of its unit = (k-step f / 12, tile f % 12) of hidden slice t - LAGT,
+  //      whose activations are in hb slot (t - LAGT) & 1.  A k-step uses ONE activation fragment for all 12 tiles, so the other fragment
+  //      register is free to be refilled meanwhile: behind the tick's transition (gap 18) comes fragment 0 of the NEXT slice (the partner
+  //      wrote it before that barrier), in gap 0 fragment 1 of the current slice. ----
+  for (int g = 0; g < LAGT - 1; ++g) cur = transition(TB{});
   const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
   h16x8_t hb[2];
-  // Half p of a slice multiplies k-step p (activation fragment hb[p]) into all 12 tiles, so the other fragment register is free to be
-  // refilled meanwhile: after the transition inside half 1 comes fragment 0 of the NEXT slice (the partner wrote it before that barrier),
-  // after the one inside half 0 fragment 1 of the current slice.
-  auto hb_slot_addr = [&](int g_half) { return hb_addr + (((g_half - LAG) >> 1) & 1) * (4 * 2 * FRAG); };
-  auto fc2_half = [&](auto P_, bool more) {
-    constexpr int P = decltype(P_)::value;
-    sfor<12>([&](auto M_) {
+  auto fc2_tick = [&](int slice, bool more) {
+    sfor<24>([&](auto M_) {
       constexpr int M = decltype(M_)::value;
-      if constexpr (M == 6) {
+      if constexpr (M == 0) lds_read1<FRAG>(hb_addr + (slice & 1) * (4 * 2 * FRAG), hb[1]);
+      if constexpr (M == 18) {
         if (more) {
           cur = transition(TB{}, true);
-          const int g_new = c_next - 1 - NOUT;  // the half tick that just became current
-          if constexpr (P == 1) lds_read1<0>(hb_slot_addr(g_new), hb[0]);
-          else lds_read1<FRAG>(hb_slot_addr(g_new), hb[1]);
+          lds_read1<0>(hb_addr + ((slice + 1) & 1) * (4 * 2 * FRAG), hb[0]);
         }
       }
-      if constexpr (M >= 6 && M < 12 - NA_PIECES) {
-        if (more) issue_piece(TB{}, IC<M - 6>{});
+      if constexpr (M >= 18) {
+        if (more && pend_late) issue_piece(IC<M - 18>{});
+      } else if constexpr (M < 6) {
+        if (pend_late) issue_piece(IC<6 + M>{});
       }
+      if constexpr (M == 5) pend_late = false;
       CS_LGKM(5);
-      acc2[M] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], hb[P], acc2[M], 0, 0, 0);
-      if constexpr (M < 6) lds_read1<(12 + M + 6) * FRAG>(cur, w[M % 6]);
-      else lds_read1<(12 + M - 6) * FRAG>(cur, w[M % 6]);  // (after the last half tick: padding)
+      acc2[M % 12] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], hb[M / 12], acc2[M % 12], 0, 0, 0);
+      if constexpr (M < 18) lds_read1<(24 + M + 6) * FRAG>(cur, w[M % 6]);
+      else lds_read1<(24 + M - 18) * FRAG>(cur, w[M % 6]);  // (after the last tick: re-reads of this unit, unused)
       CS_SB();
     });
   };
-  cur = transition(TB{});  // chunk NOUT + LAG: slice 0, half 0
+  cur = transition(TB{});  // MLP tick LAGT: slice 0
   lds_read1<0>(hb_addr, hb[0]);
-  sfor<6>([&](auto F_) { lds_read1<(12 + decltype(F_)::value) * FRAG>(cur, w[decltype(F_)::value]); });
-  for (int t = 0; t < NSL - 1; ++t) {
-    fc2_half(IC<0>{}, true);
-    fc2_half(IC<1>{}, true);
-  }
-  fc2_half(IC<0>{}, true);
-  fc2_half(IC<1>{}, false);
+  sfor<6>([&](auto F_) { lds_read1<(24 + decltype(F_)::value) * FRAG>(cur, w[decltype(F_)::value]); });
+  for (int sl = 0; sl < NSL - 1; ++sl) fc2_tick(sl, true);
+  fc2_tick(NSL - 1, false);
   CS_LGKM(0);
-  CS_VMCNT(0);  // the padding chunks' LDS-DMA has landed before the workgroup can end
+  CS_VMCNT(0);  // every LDS-DMA has landed before the workgroup can end
   CS_STAMP(4);
 
   // ---- epilogue, B side: rows go to memory through LDS and the partner (a lane holds 64 B of a row per tile: stored directly, every store
@@ -601,55 +572,60 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
 #endif
 }
 
-// ---- weight image.  One thread per 16-byte fragment element (8 f16): [chunk][fragment 0..23][lane 0..63].  Lane (i = lane & 31,
-//      h = lane >> 5) of an A-operand fragment holds MFMA row i of its 32-feature tile and 8 contraction indices of its 16-wide k-step.
+// ---- weight image.  One thread per 16-byte fragment element (8 f16): [unit][fragment][lane 0..63].  Lane (i = lane & 31, h = lane >> 5) of
+//      an A-operand fragment holds MFMA row i of its 32-feature tile and 8 contraction indices of its 16-wide k-step.
 //      MFMA row i of a D tile is register r = (i & 3) + 4 (i >> 3) of lane half (i >> 2) & 1, and the kernel keeps feature
 //      32 T + 16 h + r there, so row i carries output feature  perm(i) = 16 ((i >> 2) & 1) + (i & 3) + 4 (i >> 3)  of its tile.
 //      Contraction index of element e:  natural  16 ks + 8 h + e                 (out-projection: B fragments come from memory)
 //                                       tiled    32 (ks >> 1) + 16 h + 8 (ks & 1) + e   (fc1 / fc2: B fragments are accumulator tiles)
-//      Chunks: [12 out-projection chunks c: fragment 12 ksl + T = (k-step 2c + ksl, tile T)]
-//              [101 MLP half ticks g: fragments 0..11  = fc1 slice g/2, k-step 12 (g&1) + f                                  (g < 96)
-//                                     fragments 12..23 = fc2 slice (g-5)/2, tile f', k-step (g-5) & 1                         (g >= 5)]
-//              [2 padding chunks] ----
+//      Units: [12 out-projection chunks c of 24 fragments: fragment 12 ksl + T = (k-step 2c + ksl, tile T)]
+//             [50 MLP ticks t of 48 fragments: fragments 0..23  = fc1 slice t, k-step f                              (t < 48)
+//                                              fragments 24..47 = fc2 slice t - 2, k-step f' / 12, tile f' % 12       (t >= 2)]
+//             [1 padding tick] ----
 __device__ __forceinline__ int panel_perm(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restrict__ wo, const float* __restrict__ ls1,
                                                             const float* __restrict__ w1, const float* __restrict__ g2,
                                                             const float* __restrict__ w2, const float* __restrict__ ls2,
                                                             h16_t* __restrict__ img) {
   const int nout = wo ? OUT_CHUNKS : 0;
-  const int nch = nout + MLP_CHUNKS;
-  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gi >= (nch + PAD_CHUNKS) * (CHUNK / 16)) return;
-  const int c = gi / (CHUNK / 16);
-  const int within = gi - c * (CHUNK / 16);
-  const int f = within >> 6, lane = within & 63;
-  const int i = lane & 31, h = lane >> 5;
+  const long long n_out16 = (long long)nout * (CHUNK / 16);
+  const long long total16 = n_out16 + (long long)(NTICK + PAD_TICKS) * (TICK / 16);
+  const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= total16) return;
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (c < nout) {
+  if (gi < n_out16) {
+    const int c = (int)(gi / (CHUNK / 16));
+    const int within = (int)(gi - (long long)c * (CHUNK / 16));
+    const int f = within >> 6, lane = within & 63, i = lane & 31, h = lane >> 5;
     const int ks = 2 * c + f / 12, T = f % 12;
     const int rowi = 32 * T + panel_perm(i);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = wo[(size_t)rowi * PC + 16 * ks + 8 * h + e] * (ls1 ? ls1[rowi] : 1.f);
-  } else if (c < nch) {
-    const int g = c - nout;
-    if (f < 12) {
-      if (g < 2 * NSL) {
-        const int t = g >> 1, ks = 12 * (g & 1) + f;
-        const int rowi = 32 * t + panel_perm(i);
+  } else {
+    const long long g2i = gi - n_out16;
+    const int t = (int)(g2i / (TICK / 16));
+    const int within = (int)(g2i - (long long)t * (TICK / 16));
+    const int f = within >> 6, lane = within & 63, i = lane & 31, h = lane >> 5;
+    if (t < NTICK) {
+      if (f < 24) {
+        if (t < NSL) {
+          const int ks = f;
+          const int rowi = 32 * t + panel_perm(i);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int col = 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + e;
+            v[e] = w1[(size_t)rowi * PC + col] * (g2 ? g2[col] : 1.f);
+          }
+        }
+      } else if (t >= LAGT) {
+        const int tt = t - LAGT, fp = f - 24;
+        const int s = fp / 12, T = fp % 12;
+        const int rowi = 32 * T + panel_perm(i);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int col = 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + e;
-          v[e] = w1[(size_t)rowi * PC + col] * (g2 ? g2[col] : 1.f);
+          const int col = 32 * tt + 16 * h + 8 * s + e;
+          v[e] = w2[(size_t)rowi * PF + col] * (ls2 ? ls2[rowi] : 1.f);
         }
-      }
-    } else if (g >= LAG) {
-      const int tt = (g - LAG) >> 1, fp = f - 12;
-      const int T = fp, s = (g - LAG) & 1;
-      const int rowi = 32 * T + panel_perm(i);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int col = 32 * tt + 16 * h + 8 * s + e;
-        v[e] = w2[(size_t)rowi * PF + col] * (ls2 ? ls2[rowi] : 1.f);
       }
     }
   }
@@ -666,11 +642,11 @@ int cs_panel_debug_read(unsigned long long* dst) { return (int)hipMemcpyFromSymb
 #endif
 
 int cs_panel_supported(int C, int mlp_ratio) { return C == PC && mlp_ratio * C == PF; }
-size_t cs_panel_image_bytes(int with_outproj) { return (size_t)((with_outproj ? OUT_CHUNKS : 0) + MLP_CHUNKS + PAD_CHUNKS) * CHUNK; }
+size_t cs_panel_image_bytes(int with_outproj) { return (size_t)(with_outproj ? OUT_CHUNKS : 0) * CHUNK + (size_t)(NTICK + PAD_TICKS) * TICK; }
 
 hipError_t cs_panel_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
                                 h16_t* img, hipStream_t st) {
-  const int total = ((wo ? OUT_CHUNKS : 0) + MLP_CHUNKS + PAD_CHUNKS) * (CHUNK / 16);
+  const int total = (int)(cs_panel_image_bytes(wo ? 1 : 0) / 16);
   hipLaunchKernelGGL(cs_panel_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, wo, ls1, w1, g2, w2, ls2, img);
   return hipGetLastError();
 }
