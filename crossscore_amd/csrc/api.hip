@@ -37,6 +37,7 @@ hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh,
 hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
                                hipStream_t st);
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
+constexpr float LOG2E = 1.4426950408889634f;
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
 hipError_t cs_score_gray16_launch(const float* score, size_t n, int signed_range, uint16_t* out, hipStream_t stream);
@@ -248,7 +249,7 @@ struct Launcher {
     if (rc) return false;
     if (const char* e = cs_gemm_check(&g, epi)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
     g.bpc = bpc;
-    // algorithmic HBM bytes of one launch: A and W once (bf16), bias, the output once, the residual / position addend once
+    // algorithmic HBM bytes of one launch: A and W once (fp16), bias, the output once, the residual / position addend once
     const double mn = (double)g.M * g.N;
     const bool f32out = epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32 || epi == CS_EPI_HEAD_SCORE;
     double bytes = 2.0 * g.M * g.K + 2.0 * g.N * g.K + 4.0 * g.N + mn * (f32out ? 4.0 : 2.0);
@@ -274,7 +275,7 @@ struct Launcher {
     if (rc) return false;
     if (const char* e = cs_panel_check(&q)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
     const double M = q.M, C = m->cfg.hidden, F = (double)m->cfg.mlp_ratio * C;
-    // algorithmic bytes: x read + written (fp32), attention output read, u written (bf16), the weight stream once
+    // algorithmic bytes: x read + written (fp32), attention output read, u written (fp16), the weight stream once
     begin(40, 2.0 * M * C * C * (q.attn_o ? 1 : 0) + 4.0 * M * C * F,
           M * C * (8.0 + (q.attn_o ? 2.0 : 0.0) + (q.u_out ? 2.0 : 0.0)) + (double)cs_panel_image_bytes(q.attn_o ? 1 : 0));
     hipError_t e = cs_panel_launch(&q, st);
@@ -446,6 +447,15 @@ int cs_finalize(cs_handle h) {
   h->cls = t_cls->d; h->pos = t_pos->d; h->bpatch = t_pb->d;
   { ALLOC_BF(wp, (size_t)C * h->Kp) if (int r = pack(t_pw->d, (int)C, (int)(3 * P * P), h->Kp, wp)) return r; h->Wpatch = wp; }
   { ALLOC_F(ws, (size_t)3 * C) HIPCHK(cs_patch_wsum_launch(t_pw->d, (int)C, (int)P, ws, st)); h->wsum = ws; }
+  // softmax scale folded into the Q projections: the attention kernel takes Q pre-multiplied by log2(e)/sqrt(dh) (scale_log2e = 1),
+  // so the factor is applied to the fp32 weights and biases before their single fp16 rounding instead of to fp16 Q values
+  ALLOC_F(qs_enc, (size_t)C) ALLOC_F(qs_dec, (size_t)C)
+  {
+    std::vector<float> hv((size_t)C, LOG2E / std::sqrt((float)(C / c.enc_heads)));
+    HIPCHK(hipMemcpy(qs_enc, hv.data(), (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    std::fill(hv.begin(), hv.end(), LOG2E / std::sqrt((float)(C / c.dec_heads)));
+    HIPCHK(hipMemcpy(qs_dec, hv.data(), (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+  }
   h->enc.resize(c.enc_layers);
   for (int l = 0; l < c.enc_layers; ++l) {
     const std::string p = "backbone.encoder.layer." + std::to_string(l) + ".";
@@ -469,10 +479,11 @@ int cs_finalize(cs_handle h) {
     const bool fold = h->lnfold || h->panel;
     const float* g1 = fold ? n1w->d : nullptr;  // LayerNorm gamma folded into the columns of the consuming projection
     const float* g2 = fold ? n2w->d : nullptr;
-    if (int r = pack(qw->d, (int)C, (int)C, (int)C, wqkv, nullptr, g1)) return r;
+    if (int r = pack(qw->d, (int)C, (int)C, (int)C, wqkv, qs_enc, g1)) return r;
     if (int r = pack(kw->d, (int)C, (int)C, (int)C, wqkv + C * C, nullptr, g1)) return r;
     if (int r = pack(vw->d, (int)C, (int)C, (int)C, wqkv + 2 * C * C, nullptr, g1)) return r;
-    D2D(bqkv, qb->d, C); D2D(bqkv + C, kb->d, C); D2D(bqkv + 2 * C, vb->d, C);
+    HIPCHK(cs_vec_mul_launch(qb->d, qs_enc, bqkv, (int)C, st));
+    D2D(bqkv + C, kb->d, C); D2D(bqkv + 2 * C, vb->d, C);
     ALLOC_BF(wo, (size_t)C * C) ALLOC_BF(w1, (size_t)F * C) ALLOC_BF(w2, (size_t)C * F)
     if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo, l1->d)) return r;
     if (int r = pack(f1w->d, (int)F, (int)C, (int)C, w1, nullptr, g2)) return r;
@@ -488,9 +499,11 @@ int cs_finalize(cs_handle h) {
     if (fold) {
       ALLOC_F(sq, (size_t)3 * C) ALLOC_F(cq, (size_t)3 * C) ALLOC_F(s1v, (size_t)F) ALLOC_F(c1v, (size_t)F)
       const float* wsrc[3] = {qw->d, kw->d, vw->d};
+      const float* bsrc[3] = {qb->d, kb->d, vb->d};
       for (int part = 0; part < 3; ++part)
-        HIPCHK(cs_ln_fold_consts_launch(wqkv + (size_t)part * C * C, (int)C, wsrc[part], n1b->d, bqkv + part * C, (int)C, (int)C,
+        HIPCHK(cs_ln_fold_consts_launch(wqkv + (size_t)part * C * C, (int)C, wsrc[part], n1b->d, bsrc[part], (int)C, (int)C,
                                         sq + part * C, cq + part * C, st));
+      HIPCHK(cs_vec_mul_launch(cq, qs_enc, cq, (int)C, st));  // c = b + W beta of the Q rows carries the softmax scale too
       HIPCHK(cs_ln_fold_consts_launch(w1, (int)C, f1w->d, n2b->d, f1b->d, (int)F, (int)C, s1v, c1v, st));
       L.s_qkv = sq; L.c_qkv = cq; L.s_1 = s1v; L.c_1 = c1v;
     }
@@ -513,18 +526,24 @@ int cs_finalize(cs_handle h) {
     if (c.do_self_attn) {
       NEED(iw, p + "self_attn.in_proj_weight", 3 * C, C) NEED(ib, p + "self_attn.in_proj_bias", 3 * C)
       NEED(ow, p + "self_attn.out_proj.weight", C, C) NEED(ob, p + "self_attn.out_proj.bias", C)
-      ALLOC_BF(w, (size_t)3 * C * C) if (int r = pack(iw->d, (int)(3 * C), (int)C, (int)C, w)) return r;
+      ALLOC_BF(w, (size_t)3 * C * C) ALLOC_F(bin, (size_t)3 * C)
+      if (int r = pack(iw->d, (int)C, (int)C, (int)C, w, qs_dec)) return r;
+      if (int r = pack(iw->d + C * C, (int)(2 * C), (int)C, (int)C, w + C * C)) return r;
+      HIPCHK(cs_vec_mul_launch(ib->d, qs_dec, bin, (int)C, st));
+      D2D(bin + C, ib->d + C, 2 * C);
       ALLOC_BF(wo, (size_t)C * C) if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
-      L.sa_Win = w; L.sa_bin = ib->d; L.sa_Wo = wo; L.sa_bo = ob->d;
+      L.sa_Win = w; L.sa_bin = bin; L.sa_Wo = wo; L.sa_bo = ob->d;
     }
     NEED(iw, p + "multihead_attn.in_proj_weight", 3 * C, C) NEED(ib, p + "multihead_attn.in_proj_bias", 3 * C)
     NEED(ow, p + "multihead_attn.out_proj.weight", C, C) NEED(ob, p + "multihead_attn.out_proj.bias", C)
-    ALLOC_BF(wq, (size_t)C * C) if (int r = pack(iw->d, (int)C, (int)C, (int)C, wq)) return r;
+    ALLOC_BF(wq, (size_t)C * C) ALLOC_F(bq, (size_t)C)
+    if (int r = pack(iw->d, (int)C, (int)C, (int)C, wq, qs_dec)) return r;
+    HIPCHK(cs_vec_mul_launch(ib->d, qs_dec, bq, (int)C, st));
     // rows [C:3C) = [Wk;Wv] of this layer -> rows [l*2C, (l+1)*2C) of the fused KV projection (same memory for both layers)
     if (int r = pack(iw->d + C * C, (int)(2 * C), (int)C, (int)C, h->Wkv_all + (size_t)l * 2 * C * C)) return r;
     D2D(h->bkv_all + (size_t)l * 2 * C, ib->d + C, 2 * C);
     ALLOC_BF(wo, (size_t)C * C) if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo)) return r;
-    L.ca_Wq = wq; L.ca_bq = ib->d; L.ca_Wo = wo; L.ca_bo = ob->d;
+    L.ca_Wq = wq; L.ca_bq = bq; L.ca_Wo = wo; L.ca_bo = ob->d;
     NEED(l1w, p + "linear1.weight", C, C) NEED(l1b, p + "linear1.bias", C) NEED(l2w, p + "linear2.weight", C, C) NEED(l2b, p + "linear2.bias", C)
     ALLOC_BF(w1, (size_t)C * C) if (int r = pack(l1w->d, (int)C, (int)C, (int)C, w1)) return r;
     ALLOC_BF(w2, (size_t)C * C) if (int r = pack(l2w->d, (int)C, (int)C, (int)C, w2)) return r;
@@ -557,8 +576,8 @@ size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W) {
   return make_plan(h, B, N, N, H, W, nullptr).total;
 }
 
-// mode 0: full forward (query + reference images); mode 1: query images + cached reference tokens (`ref_tokens`, bf16
-// [B][N][Np][C]); mode 2: encode `B` images as references into `tokens_out` (bf16 [B][Np][C]), no decoder.
+// mode 0: full forward (query + reference images); mode 1: query images + cached reference tokens (`ref_tokens`, fp16
+// [B][N][Np][C]); mode 2: encode `B` images as references into `tokens_out` (fp16 [B][Np][C]), no decoder.
 static int forward_body(cs_handle h, int mode, const float* query, const float* refs, const h16_t* ref_tokens, h16_t* tokens_out,
                         int B, int N, int H, int W, float* score_out, float* attn_out, int head_id, float* mean_out,
                         cs_stream stream) {
@@ -599,7 +618,6 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   if (int r = ensure_tables(h, p.gh, p.gw, H == W, st)) return r;
   const int enc_dh = C / c.enc_heads, dec_dh = C / c.dec_heads;
   const int F = c.mlp_ratio * C;
-  const float LOG2E = 1.4426950408889634f;
   const int KV = 2 * C * c.dec_layers;
 
   // ---- lanes: fork from the caller's stream, join back before returning (everything stays stream-ordered on `st`) ----
@@ -639,7 +657,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     hipStream_t s = L.st;
     float* x = p.x[slot]; h16_t* u = p.u[slot]; h16_t* r1 = p.r1[slot];
     const int Mc = ic * p.T;
-    // patches are mean-centred per channel before the bf16 rounding; the patch GEMM adds mean * sum(W) back in fp32
+    // patches are mean-centred per channel before the fp16 rounding; the patch GEMM adds mean * sum(W) back in fp32
     float* pmean = p.pmean[slot];
     if (stage == -1) {
     L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, pmean, s), "im2col"); L.end();
@@ -651,7 +669,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     {
       CsGemmParams g = gp(r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, x, C);
       g.pos = h->pos_tab; g.Np = p.Np; g.pmean = pmean; g.wsum = h->wsum;
-      if (fold) { g.out_bf16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }  // bf16 rows + LayerNorm partial sums for layer 0
+      if (fold) { g.out_f16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }  // fp16 rows + LayerNorm partial sums for layer 0
       L.gemm(g, CS_EPI_PATCH_F32, 3.0 * P * P);
     }
     }
@@ -665,9 +683,9 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       a.Q = r1; a.K = r1 + C; a.V = r1 + 2 * C;
       a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
       a.q_bs = a.k_bs = a.v_bs = (long long)p.T * 3 * C; a.o_bs = (long long)p.T * C;
-      a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = LOG2E / std::sqrt((float)enc_dh); a.lse = nullptr;
+      a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = 1.0f;  // folded into the Q rows of Wqkv (cs_finalize) a.lse = nullptr;
       if (h->panel) {
-        // u = bf16 normalised rows (norm1 without gamma/beta: folded into Wqkv / c_qkv), written by the previous layer's panel
+        // u = fp16 normalised rows (norm1 without gamma/beta: folded into Wqkv / c_qkv), written by the previous layer's panel
         // kernel; layer 0 gets it from the LayerNorm kernel
         if (l == 0) { L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, h->ones, h->zeros, 1e-6f, nullptr, u, s), "ln1"); L.end(); }
         L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C), CS_EPI_BIAS_F16);
@@ -680,7 +698,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         continue;
       }
       if (fold) {
-        // u holds bf16(x) and `stats` the per-row partial sums, both written by the epilogue that produced x: LayerNorm is
+        // u holds fp16(x) and `stats` the per-row partial sums, both written by the epilogue that produced x: LayerNorm is
         // applied inside the consuming projection's epilogue (CS_EPI_LN_*), there is no separate LN pass over x
         {
           CsGemmParams g = gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C);
@@ -691,7 +709,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.attn(a, enc_dh, ic);
         {
           CsGemmParams g = gp(ob, C, E.Wo, C, Mc, C, C, E.bo, x, C);
-          g.resid = x; g.ldr = C; g.out_bf16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp;
+          g.resid = x; g.ldr = C; g.out_f16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp;
           L.gemm(g, CS_EPI_RESID_F32_LN);
         }
         {
@@ -702,7 +720,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         {
           CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);
           g.resid = x; g.ldr = C;
-          if (!last) { g.out_bf16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }
+          if (!last) { g.out_f16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }
           L.gemm(g, last ? CS_EPI_RESID_F32 : CS_EPI_RESID_F32_LN);  // the final LayerNorm reads the fp32 stream
         }
         continue;
@@ -763,7 +781,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         a.Q = dqkv; a.K = dqkv + C; a.V = dqkv + 2 * C; a.O = dob;
         a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
         a.q_bs = a.k_bs = a.v_bs = (long long)p.Np * 3 * C; a.o_bs = (long long)p.Np * C;
-        a.Lq = a.Lk = p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
+        a.Lq = a.Lk = p.Np; a.heads = c.dec_heads; a.scale_log2e = 1.0f;  // folded into the Q projection (cs_finalize)
         L.attn(a, dec_dh, nb);
         CsGemmParams g = gp(dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, y, C);
         g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
@@ -776,7 +794,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       a.Q = dq; a.K = kv + (size_t)l * 2 * C; a.V = kv + (size_t)l * 2 * C + C; a.O = dob;
       a.ldq = C; a.ldk = a.ldv = KV; a.ldo = C;
       a.q_bs = (long long)p.Np * C; a.k_bs = a.v_bs = (long long)N * p.Np * KV; a.o_bs = (long long)p.Np * C;
-      a.Lq = p.Np; a.Lk = N * p.Np; a.heads = c.dec_heads; a.scale_log2e = LOG2E / std::sqrt((float)dec_dh);
+      a.Lq = p.Np; a.Lk = N * p.Np; a.heads = c.dec_heads; a.scale_log2e = 1.0f;  // folded into the Q projection (cs_finalize)
       const bool want_w = attn_out && l == c.dec_layers - 1;  // only the last layer's weights are returned (transformer.py:266-268)
       a.lse = want_w ? lse : nullptr;
       L.attn(a, dec_dh, nb);
@@ -916,10 +934,10 @@ int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, do
 // ---------------------------------------------------------------------------------------------------------
 int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
                const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np, int gw, int P, int act,
-               float powp, uint16_t* out_bf16, float* stats_out, int stats_sp, const float* ln_part, int ln_sp, const float* col_s,
+               float powp, uint16_t* out_f16, float* stats_out, int stats_sp, const float* ln_part, int ln_sp, const float* col_s,
                float ln_eps, cs_stream stream) {
   CsGemmParams g = gp(A, lda, W, ldw, M, N, K, bias, out, ldc);
-  g.out_bf16 = out_bf16; g.stats_out = stats_out; g.stats_sp = stats_sp; g.ln_part = ln_part; g.ln_sp = ln_sp; g.col_s = col_s;
+  g.out_f16 = out_f16; g.stats_out = stats_out; g.stats_sp = stats_sp; g.ln_part = ln_part; g.ln_sp = ln_sp; g.col_s = col_s;
   g.ln_eps = ln_eps;
   g.resid = resid; g.ldr = ldr; g.pos = pos; g.Np = Np; g.gw = gw; g.P = P; g.act = act; g.powp = powp;
   if (epi < 0 || epi > CS_EPI_RESID_F32_LN) return fail(CS_ERR_BAD_ARG, "gemm: unknown epilogue %d", epi);
@@ -930,31 +948,32 @@ int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, in
 
 int cs_op_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* V, uint16_t* O, int ldq, int ldk, int ldv, int ldo,
                     long long q_bs, long long k_bs, long long v_bs, long long o_bs, int batch, int heads, int Lq, int Lk, int dh,
-                    float* lse, cs_stream stream) {
+                    float q_scale, float* lse, cs_stream stream) {
   CsAttnParams a{};
   a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs; a.Lq = Lq; a.Lk = Lk; a.heads = heads;
-  a.scale_log2e = 1.4426950408889634f / std::sqrt((float)dh); a.lse = lse;
+  if (!(q_scale >= 0.f)) return fail(CS_ERR_BAD_ARG, "attention: q_scale must be >= 0 (0 = log2(e)/sqrt(dh))");
+  a.scale_log2e = q_scale == 0.f ? LOG2E / std::sqrt((float)dh) : q_scale; a.lse = lse;
   if (const char* e = cs_attn_check(&a, dh, batch)) return fail(CS_ERR_BAD_ARG, "%s", e);
   HIPCHK(cs_attn_launch(&a, dh, batch, (hipStream_t)stream));
   return 0;
 }
 
 int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int ldk, long long q_bs, long long k_bs, int batch,
-                            int heads, int Lq, int Lk, int dh, const float* lse, int head, float* out, cs_stream stream) {
-  if (!Q || !K || !lse || !out || !supported_dh(dh) || head < 0 || head >= heads || Lq <= 0 || Lk <= 0 || Lq > 65535 || batch <= 0 || batch > 65535)
+                            int heads, int Lq, int Lk, int dh, float q_scale, const float* lse, int head, float* out, cs_stream stream) {
+  if (!Q || !K || !lse || !out || !supported_dh(dh) || !(q_scale >= 0.f) || head < 0 || head >= heads || Lq <= 0 || Lk <= 0 || Lq > 65535 || batch <= 0 || batch > 65535)
     return fail(CS_ERR_BAD_ARG, "attention_weights: bad arguments");
   CsAttnParams a{};
   a.Q = Q; a.K = K; a.ldq = ldq; a.ldk = ldk; a.q_bs = q_bs; a.k_bs = k_bs; a.Lq = Lq; a.Lk = Lk; a.heads = heads;
-  a.scale_log2e = 1.4426950408889634f / std::sqrt((float)dh); a.lse = const_cast<float*>(lse);
+  a.scale_log2e = q_scale == 0.f ? LOG2E / std::sqrt((float)dh) : q_scale; a.lse = const_cast<float*>(lse);
   HIPCHK(cs_attn_weights_launch(&a, dh, batch, head, out, (hipStream_t)stream));
   return 0;
 }
 
 int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
-                    uint16_t* out_bf16, cs_stream stream) {
+                    uint16_t* out_f16, cs_stream stream) {
   if (!x || !gamma || !beta || M <= 0 || C <= 0 || C % 4 || C > 1024) return fail(CS_ERR_BAD_ARG, "layernorm: C must be a multiple of 4 and <= 1024");
-  HIPCHK(cs_layernorm_launch(x, M, C, gamma, beta, eps, out_f32, out_bf16, (hipStream_t)stream));
+  HIPCHK(cs_layernorm_launch(x, M, C, gamma, beta, eps, out_f32, out_f16, (hipStream_t)stream));
   return 0;
 }
 
@@ -1034,7 +1053,7 @@ int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, fl
 
 int cs_op_pack_f16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
                     cs_stream stream) {
-  if (!w || !out || rows <= 0 || K <= 0 || ldo < K) return fail(CS_ERR_BAD_ARG, "pack_bf16: bad arguments");
+  if (!w || !out || rows <= 0 || K <= 0 || ldo < K) return fail(CS_ERR_BAD_ARG, "pack_f16: bad arguments");
   HIPCHK(cs_pack_f16_launch(w, rows, K, out, ldo, row_scale, col_scale, (hipStream_t)stream));
   return 0;
 }

@@ -1,4 +1,4 @@
-// Flash-style fused attention for gfx950: O = softmax(Q K^T / sqrt(dh)) V, no mask, bf16 in/out, fp32 softmax.
+// Flash-style fused attention for gfx950: O = softmax(Q K^T / sqrt(dh)) V, no mask, fp16 in/out, fp32 softmax.
 //
 // One kernel serves the three attention sites of the CrossScore forward:
 //   * DINOv2 encoder self-attention, dh = 64, per image over T = 1 + h*w tokens   (HF modeling_dinov2.py:153-234)
@@ -7,15 +7,27 @@
 // Q/K/V are addressed through (row stride, batch stride, head*dh column offset) so the packed projections the
 // GEMMs emit ([tokens][3C], [tokens][4C]) are consumed in place -- no head-split copies.
 //
-// Structure (wave64, MFMA 32x32x16 bf16): a workgroup = 4 waves = 128 query rows, each wave 32 rows; keys are
+// Structure (wave64, MFMA 32x32x16 fp16): a workgroup = 4 waves = 128 query rows, each wave 32 rows; keys are
 // streamed in 64-key tiles, K and V staged HBM -> VGPR -> LDS (issue early / write late), double buffered, one
 // barrier per tile.  QK^T is computed "swapped" (S^T = K Q^T) so each lane owns one query column: row max and
 // row sum are lane-local plus one cross-half exchange, and the S^T accumulator IS the B operand of the PV MFMA
-// (O^T = V^T P^T) after an in-register bf16 pack -- P never touches LDS.  V^T fragments come from a row-major V
+// (O^T = V^T P^T) after an in-register fp16 pack -- P never touches LDS.  The softmax reference point moves lazily (see
+// kTau below): on most tiles the per-score VALU work is max, exp2, sum and the fp16 pack only.  V^T fragments come from a row-major V
 // image through ds_read_b64_tr_b16 (hardware transposed read); LDS row strides are chosen bank-conflict free
 // (K: odd number of 16-B slots; V: 192 B so the four rows of a transposed block hit disjoint bank windows).
 #include "cs_common.h"
 #include <math.h>
+
+#ifdef CS_ATTN_STAMP
+// phase clocks of the tile loop (tools/attn_phases.py): per (block < 64, wave) the cycles summed over all tiles of
+// 0: K reads + QK^T + max (S available)  1: exp2 / sums / pack  2: V reads + PV issue  3: tile write (waits for the
+// global loads)  4: barrier;  5: loop start (10-ns ticks), 6: the loop in shader cycles, 7: the loop in 10-ns ticks
+__device__ unsigned long long g_attn_dbg[64 * 4 * 8];
+#define CS_TS(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    ph[k] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CS_TS(k) do { } while (0)
+#endif
 
 namespace {
 
@@ -80,13 +92,32 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
   uint4 kreg[NIT], vreg[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) { kreg[it] = make_uint4(0, 0, 0, 0); vreg[it] = make_uint4(0, 0, 0, 0); }
+  // global byte offsets of this thread's chunks inside a tile (32-bit: cs_attn_check bounds Lk*ld); a tile's base is wave-uniform,
+  // so a full tile costs no address arithmetic per load (SGPR base + VGPR offset); only the ragged last tile clamps its rows
+  unsigned kgo[NIT], vgo[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    kgo[it] = ((unsigned)skey[it] * (unsigned)p.ldk + (unsigned)sch[it] * 8u) * 2u;
+    vgo[it] = ((unsigned)skey[it] * (unsigned)p.ldv + (unsigned)sch[it] * 8u) * 2u;
+  }
 #define CS_ATTN_LOAD_TILE(T)                                                                       \
-  _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                             \
-    if (kFullLast || it + 1 < NIT || tid + it * 256 < 64 * CH) {                                   \
-      int key_ = (T) * 64 + skey[it];                                                              \
-      key_ = key_ < p.Lk ? key_ : p.Lk - 1;                                                        \
-      kreg[it] = *reinterpret_cast<const uint4*>(Kb + (size_t)key_ * p.ldk + sch[it] * 8);         \
-      vreg[it] = *reinterpret_cast<const uint4*>(Vb + (size_t)key_ * p.ldv + sch[it] * 8);         \
+  if ((T) * 64 + 64 <= p.Lk) {                                                                     \
+    const char* kt_ = reinterpret_cast<const char*>(Kb + (size_t)(T) * 64 * p.ldk);                \
+    const char* vt_ = reinterpret_cast<const char*>(Vb + (size_t)(T) * 64 * p.ldv);                \
+    _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
+      if (kFullLast || it + 1 < NIT || tid + it * 256 < 64 * CH) {                                 \
+        kreg[it] = *reinterpret_cast<const uint4*>(kt_ + kgo[it]);                                 \
+        vreg[it] = *reinterpret_cast<const uint4*>(vt_ + vgo[it]);                                 \
+      }                                                                                            \
+    }                                                                                              \
+  } else {                                                                                         \
+    _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
+      if (kFullLast || it + 1 < NIT || tid + it * 256 < 64 * CH) {                                 \
+        int key_ = (T) * 64 + skey[it];                                                            \
+        key_ = key_ < p.Lk ? key_ : p.Lk - 1;                                                      \
+        kreg[it] = *reinterpret_cast<const uint4*>(Kb + (size_t)key_ * p.ldk + sch[it] * 8);       \
+        vreg[it] = *reinterpret_cast<const uint4*>(Vb + (size_t)key_ * p.ldv + sch[it] * 8);       \
+      }                                                                                            \
     }                                                                                              \
   }
 #define CS_ATTN_WRITE_TILE(BUF)                                                                    \
@@ -103,9 +134,26 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
   for (int d = 0; d < DT; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) ot[d][e] = 0.f;
-  float m_run = -INFINITY;  // running max of s*scale*log2e
+  // Online softmax with a lazily moved reference point (base-2 domain): every lane owns one query row; m_run is the row's
+  // reference, p = 2^(s - m_run).  The reference is only moved when some row of the wave exceeds it by more than kTau
+  // (p <= 2^kTau = 256: exact in fp32 sums, in range for the fp16 P operand, same relative precision), so on most tiles
+  // nothing is subtracted and nothing is rescaled: -m_run enters through the C operand of the first QK^T MFMA of the tile
+  // (negm: 16 registers of the lane's -m_run), and the only per-score VALU work left is max, exp2, sum and the fp16 pack.
+  constexpr float kTau = 8.0f;
+  float m_run = 0.f;        // reference point of s*scale*log2e (set from the first tile)
   float l_run = 0.f;        // running sum over this lane's keys (other half lives in lane^32)
-  const float sc = p.scale_log2e;
+  f32x16_t negm;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
+  {  // Q is used pre-multiplied by scale*log2e (scale_log2e == 1: the producer already folded it into the Q projection)
+    const float sc = p.scale_log2e;
+    if (sc != 1.0f) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (_Float16)((float)qf[s][j] * sc);
+    }
+  }
 
   // per-lane LDS byte offsets
   const int koff = r * Cfg::KROW + hh * 16;                                  // + kt2*32*KROW + s*32
@@ -116,21 +164,24 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
   CS_ATTN_LOAD_TILE(0)
   CS_ATTN_WRITE_TILE(0)
   __syncthreads();
+#ifdef CS_ATTN_STAMP
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};
+  const unsigned long long tbegin = __builtin_amdgcn_s_memtime(), rbegin = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tlast = tbegin;
+#endif
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) { CS_ATTN_LOAD_TILE(t + 1) }
     const char* kb = smem + (t & 1) * Cfg::STAGE;
     const char* vb = kb + Cfg::KTILE;
 
-    // ---- S^T = K Q^T : two 32-key sub-tiles ----
+    // ---- S^T - m = K Q^T - m : two 32-key sub-tiles ----
     f32x16_t st[2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) st[k2][e] = 0.f;
-#pragma unroll
       for (int s = 0; s < KS; ++s) {
         h16x8_t kf = *reinterpret_cast<const h16x8_t*>(kb + koff + k2 * 32 * Cfg::KROW + s * 32);
-        st[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[k2], 0, 0, 0);
+        st[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], s == 0 ? negm : st[k2], 0, 0, 0);
       }
     }
     // ---- mask the ragged tail (keys >= Lk) : wave-uniform branch ----
@@ -144,37 +195,49 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
           if (key >= p.Lk) st[k2][e] = -INFINITY;
         }
     }
-    // ---- online softmax (base-2 domain) ----
     float tmax = st[0][0];
 #pragma unroll
     for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
 #pragma unroll
     for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax * sc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));  // the row's maximum of this tile, relative to m_run
+    CS_TS(0);
+    // ---- move the reference (rare after the first tiles): wave-uniform branch ----
+    if (t == 0 || __builtin_amdgcn_ballot_w64(tmax > kTau) != 0) {
+      const float delta = t == 0 ? tmax : fmaxf(tmax, 0.f);  // every tile holds a valid key: finite
+      const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+      m_run += delta;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) negm[e] = -m_run;
+      asm volatile("" : "+v"(negm));  // keep the 16 copies resident instead of re-materialising them per tile
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[k2][e] -= delta;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ot[d][e] *= alpha;
+    }
+    float ps0 = 0.f, ps1 = 0.f;  // two chains of plain v_add_f32 (packed f32 adds cost more issue cycles than they save)
     h16x8_t pf[2][2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pv = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j] * sc - m_new);
-          psum += pv;
-          pf[k2][s2][j] = (_Float16)pv;
+        for (int j = 0; j < 8; j += 2) {
+          const float pa = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j]);
+          const float pb = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j + 1]);
+          ps0 += pa;
+          ps1 += pb;
+          pf[k2][s2][j] = (_Float16)pa;
+          pf[k2][s2][j + 1] = (_Float16)pb;
         }
       }
-    l_run = l_run * alpha + psum;
-    // rescale the running output only when some row's maximum moved (alpha == 1 exactly otherwise): wave-uniform branch
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) ot[d][e] *= alpha;
-    }
+    l_run += ps0 + ps1;
+    CS_TS(1);
 
     // ---- O^T += V^T P^T : V^T fragments via transposed LDS reads ----
 #pragma unroll
@@ -193,9 +256,21 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
         }
       }
 
+    CS_TS(2);
     if (t + 1 < nt) { CS_ATTN_WRITE_TILE((t + 1) & 1) }
+    CS_TS(3);
     __syncthreads();
+    CS_TS(4);
   }
+#ifdef CS_ATTN_STAMP
+  if (blockIdx.x % 50 == 0 && blockIdx.x / 50 < 64 && lane == 0) {  // a sample across the whole grid
+    unsigned long long* d = g_attn_dbg + (blockIdx.x / 50 * 4 + wv) * 8;
+    for (int k = 0; k < 5; ++k) d[k] = ph[k];
+    d[5] = rbegin;
+    d[6] = __builtin_amdgcn_s_memtime() - tbegin;
+    d[7] = __builtin_amdgcn_s_memrealtime() - rbegin;  // 100 MHz
+  }
+#endif
 
   // ---- epilogue: O[q][head*DH + d] = O^T[d][q] / l ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -232,6 +307,10 @@ hipError_t launch(CsAttnParams p, int batch, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef CS_ATTN_STAMP
+extern "C" int cs_attn_debug_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_dbg), sizeof(g_attn_dbg)); }
+#endif
+
 extern "C" const char* cs_attn_check(const CsAttnParams* p, int dh, int batch) {
   if (dh != 16 && dh != 48 && dh != 64 && dh != 96) return "attention: head dim must be 16, 48, 64 or 96";
   if (p->Lq <= 0 || p->Lk <= 0 || p->heads <= 0 || batch <= 0) return "attention: empty shape";
@@ -239,6 +318,7 @@ extern "C" const char* cs_attn_check(const CsAttnParams* p, int dh, int batch) {
   if (p->ldq % 8 || p->ldk % 8 || p->ldv % 8 || p->ldo % 4) return "attention: row strides must keep 16-byte rows";
   if (p->q_bs % 8 || p->k_bs % 8 || p->v_bs % 8 || p->o_bs % 4) return "attention: batch strides must keep 16-byte rows";
   if (!p->Q || !p->K || !p->V || !p->O) return "attention: null operand";
+  if ((long long)p->Lk * p->ldk >= (1ll << 30) || (long long)p->Lk * p->ldv >= (1ll << 30)) return "attention: Lk * row stride must stay below 2^30 elements (32-bit tile offsets)";
   return nullptr;
 }
 

@@ -45,8 +45,8 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // GELU(x) = x * Phi(x) with the exact (erf) Phi of HF ACT2FN["gelu"] (HF modeling_dinov2.py:293-297) approximated by
 // Phi(x) ~ 0.5 + x * P(x^2), x clamped to +-4.2; P is a degree-7 minimax fit of the GELU error:
-// max |GELU_fit - GELU_erf| = 6.7e-5 (2.1e-4 as evaluated in fp32 Horner form, near |x| = 4 where y ~ x; a bf16 half-ulp is
-// 2e-3 at |y| = 1 and 8e-3 at 4).  12 plain VALU ops, no
+// max |GELU_fit - GELU_erf| = 6.7e-5 (2.1e-4 as evaluated in fp32 Horner form, near |x| = 4 where y ~ x; an fp16 half-ulp is
+// 4.9e-4 at |y| = 1 and 2e-3 at 4).  12 plain VALU ops, no
 // transcendentals: the fc1 epilogue was spending more issue slots on erf (v_exp + v_rcp) than its K loop on MFMAs
 // (PMC: SQ_ACTIVE_INST_VALU 51 % vs MFMA pipe busy 26 % with the Abramowitz-Stegun erf).
 // Four values per call as two packed-fp32 Horner chains (v_pk_fma_f32) issued alternately from one asm block: a lone chain pays
@@ -88,7 +88,7 @@ __device__ __forceinline__ void gelu_erf4(float (&v)[4]) {
 
 // ---- kernel parameter blocks (plain structs; launchers live in the matching .hip files) -------------
 enum CsEpilogue {
-  CS_EPI_BIAS_F16 = 0,        // out_bf16[m][n] = acc + bias[n]
+  CS_EPI_BIAS_F16 = 0,        // out_f16[m][n] = acc + bias[n]
   CS_EPI_BIAS_GELU_F16 = 1,   // exact erf GELU
   CS_EPI_BIAS_RELU_F16 = 2,
   CS_EPI_BIAS_LEAKY_F16 = 3,  // slope 0.01
@@ -96,23 +96,23 @@ enum CsEpilogue {
   CS_EPI_PATCH_F32 = 5,        // out_f32[(m + m/Np + 1)][n] = acc + bias[n] + pos[(m%Np+1)][n]
   CS_EPI_HEAD_SCORE = 6,       // score[b][P*i+py][P*j+px] = act(acc + bias[n]), m=b*Np+i*gw+j, n=py*P+px
   // LayerNorm folded into the consuming projection (no separate LN pass over the fp32 residual stream):
-  //   LN(x) W^T + b = rstd[m] * (bf16(x) W'^T - mu[m] * s[n]) + c[n],  W' = W*gamma (per input column), s[n] = sum_k W'[n][k],
+  //   LN(x) W^T + b = rstd[m] * (fp16(x) W'^T - mu[m] * s[n]) + c[n],  W' = W*gamma (per input column), s[n] = sum_k W'[n][k],
   //   c[n] = b[n] + sum_k beta[k] W[n][k];  mu / rstd come from per-row partial sums the PRODUCING epilogue wrote.
-  CS_EPI_LN_F16 = 7,          // out_bf16 = rstd*(acc - mu*s) + c
+  CS_EPI_LN_F16 = 7,          // out_f16 = rstd*(acc - mu*s) + c
   CS_EPI_LN_GELU_F16 = 8,     // ... then GELU
-  CS_EPI_RESID_F32_LN = 9,     // CS_EPI_RESID_F32 + bf16 copy of the new rows + their partial (sum, sum of squares)
+  CS_EPI_RESID_F32_LN = 9,     // CS_EPI_RESID_F32 + fp16 copy of the new rows + their partial (sum, sum of squares)
 };
 
 struct CsGemmParams {
-  const h16_t* A;    // [M][lda] bf16, K contiguous
-  const h16_t* W;    // [N][ldw] bf16, K contiguous (nn.Linear layout)
+  const h16_t* A;    // [M][lda] fp16, K contiguous
+  const h16_t* W;    // [N][ldw] fp16, K contiguous (nn.Linear layout)
   int lda, ldw;
   int M, N, K;        // K % 64 == 0
   const float* bias;  // [N] or null
   const float* scale; // [N] or null
   const float* resid; // [M][ldr] fp32 or null
   int ldr;
-  void* out;          // bf16 or fp32, see epilogue
+  void* out;          // fp16 or fp32, see epilogue
   int ldc;
   // CS_EPI_PATCH_F32 / CS_EPI_HEAD_SCORE extras
   const float* pos;   // [(1+Np)][ldc] position table (patch)
@@ -125,11 +125,11 @@ struct CsGemmParams {
   int act;            // 0 sigmoid, 1 tanh
   float powp;         // 1 -> identity
   // LayerNorm fold (see CS_EPI_LN_*): producer side (RESID_F32_LN, PATCH_F32) ...
-  h16_t* out_bf16;    // [rows][ldc] bf16 copy of the fp32 rows written (the next GEMM's A operand), or null
+  h16_t* out_f16;    // [rows][ldc] fp16 copy of the fp32 rows written (the next GEMM's A operand), or null
   float* stats_out;    // [rows][stats_sp][2] partial (sum, sumsq) per row: slot = column_tile*4 + wave, or null
   int stats_sp;
   // ... consumer side (LN_BF16, LN_GELU_BF16); `bias` carries c[n]
-  const float* ln_part;  // [M][ln_sp][2] partial sums of the A rows (fp32 values before bf16 rounding)
+  const float* ln_part;  // [M][ln_sp][2] partial sums of the A rows (fp32 values before fp16 rounding)
   int ln_sp;             // 4, 8 or 16
   const float* col_s;    // [N] s[n]
   float ln_eps;
@@ -149,11 +149,11 @@ struct CsAttnParams {
 // Encoder "token panel" kernel (panel.hip): one launch per DINOv2 layer does, for 128-row panels of the residual stream,
 //   x += attn_o Wo'^T + bo'                 (attention output projection, LayerScale folded; HF modeling_dinov2.py:249-252,365-370)
 //   x += GELU(LN2(x) W1'^T + b1') W2'^T + b2'   (norm2 + MLP + LayerScale; HF:373-378, 293-297)
-//   u_out = bf16((x - mean) * rstd)         (norm1 of the NEXT layer without gamma/beta: they are folded into its QKV projection)
+//   u_out = fp16((x - mean) * rstd)         (norm1 of the NEXT layer without gamma/beta: they are folded into its QKV projection)
 // The weights arrive as one pre-packed stream of 24-KiB "units" in the exact LDS image / consumption order (cs_panel_pack_*).
 struct CsPanelParams {
   float* x;                // [M][C] fp32 residual stream, updated in place
-  const h16_t* attn_o;    // [M][C] bf16 attention output, or null: no out-projection (x is taken as is)
+  const h16_t* attn_o;    // [M][C] fp16 attention output, or null: no out-projection (x is taken as is)
   const h16_t* img;       // unit stream: [12 Wo units (if attn_o)] [96 MLP units]
   const float* bo;         // [C] out-projection bias (LayerScale folded), used when attn_o
   const float* b1;         // [4C] fc1 bias with LN2 beta folded in

@@ -8,7 +8,7 @@
 namespace {
 
 // -------------------------------------------------------------------------------------------------------
-// im2col: x fp32 (I,3,H,W) -> A bf16 [I*Np][Kp], k = ch*P*P + dy*P + dx (conv weight.reshape(C,588) order,
+// im2col: x fp32 (I,3,H,W) -> A fp16 [I*Np][Kp], k = ch*P*P + dy*P + dx (conv weight.reshape(C,588) order,
 // HF modeling_dinov2.py:139-149); columns 588..Kp-1 are zero so the GEMM K is a multiple of 64.
 // One thread per 8-element output chunk.
 // -------------------------------------------------------------------------------------------------------
@@ -49,9 +49,9 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 }
 
 // Same result, coalesced on both sides: one block per (image, patch row).  The 3*P image rows of the patch row are read with
-// consecutive lanes on consecutive pixels, scattered into an LDS image of the gw output rows ([gw][Kp] bf16, pad columns zero),
+// consecutive lanes on consecutive pixels, scattered into an LDS image of the gw output rows ([gw][Kp] fp16, pad columns zero),
 // which is then streamed out as one contiguous piece.  (The gather kernel above reads 56-byte runs: 2.3 TB/s; this one 4+.)
-// With `pmean`, each patch's per-channel mean (fp32, fixed summation order) is removed before the bf16 rounding and stored as
+// With `pmean`, each patch's per-channel mean (fp32, fixed summation order) is removed before the fp16 rounding and stored as
 // pmean[row][ch]; the patch GEMM adds mean * sum(W) back in fp32 (gemm.hip patch_dc).
 template <int P>
 __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ xq, const float* __restrict__ xr, int N, int img0,
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // -------------------------------------------------------------------------------------------------------
 // Final encoder LayerNorm (HF:465-470) fused with CLS drop + query/ref split (core.py:142-153) + multi-view PE
 // add (positional_encoding.py:42-75).  x: [I*T][C] fp32, image = b*(1+N)+v.  Row (b,v,p):
-//   v == 0 : q_f32[b*Np+p], q_bf16[b*Np+p]      (decoder residual stream + GEMM operand)
-//   v >= 1 : mem_bf16[b*N*Np + (v-1)*Np + p]    (cross-attention memory, GEMM operand only)
+//   v == 0 : q_f32[b*Np+p], q_f16[b*Np+p]      (decoder residual stream + GEMM operand)
+//   v >= 1 : mem_f16[b*N*Np + (v-1)*Np + p]    (cross-attention memory, GEMM operand only)
 // -------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __restrict__ x, int I, int img0, int Np, int C, int N,
                                                               const float* __restrict__ g, const float* __restrict__ b, float eps,
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __rest
 }
 
 // CLS rows of the residual stream: x[img*T][c] = cls[c] + pos[0][c]  (HF:108-112).  One wave per image.  With the LayerNorm
-// fold the row also gets its bf16 copy and its (sum, sumsq) in partial slot 0 (the other slots are zeroed).
+// fold the row also gets its fp16 copy and its (sum, sumsq) in partial slot 0 (the other slots are zeroed).
 __global__ __launch_bounds__(64) void cls_rows_kernel(float* x, int I, int T, int C, const float* cls, const float* pos, h16_t* xb,
                                                       float* stats, int sp) {
   const int img = blockIdx.x, lane = threadIdx.x;
@@ -324,7 +324,7 @@ __global__ void pe_bilinear_kernel(const float* __restrict__ pe, int ph, int pw,
   out[i] = top * (1.f - ly) + bot * ly;
 }
 
-// fp32 -> bf16 weight packing (K-contiguous rows; optional zero padding of K to ldo; optional per-output-row scale:
+// fp32 -> fp16 weight packing (K-contiguous rows; optional zero padding of K to ldo; optional per-output-row scale:
 // LayerScale lambda folded into the projection, HF modeling_dinov2.py:277-278, so the GEMM epilogue has no scale operand)
 __global__ void pack_f16_kernel(const float* __restrict__ w, int rows, int K, h16_t* __restrict__ out, int ldo,
                                  const float* __restrict__ row_scale, const float* __restrict__ col_scale) {
@@ -337,7 +337,7 @@ __global__ void pack_f16_kernel(const float* __restrict__ w, int rows, int K, h1
 }
 
 // LayerNorm fold constants of one projection (see CS_EPI_LN_* in cs_common.h), one wave per output row n:
-//   s[n] = sum_k float(Wp[n][k])            over the PACKED bf16 weights W' = W*gamma (what the MFMA really multiplies)
+//   s[n] = sum_k float(Wp[n][k])            over the PACKED fp16 weights W' = W*gamma (what the MFMA really multiplies)
 //   c[n] = bias[n] + sum_k beta[k] W[n][k]   in fp32 from the original weights
 __global__ __launch_bounds__(256) void ln_fold_consts_kernel(const h16_t* __restrict__ wp, int ldp, const float* __restrict__ w,
                                                              const float* __restrict__ beta, const float* __restrict__ bias, int N,
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void ln_fold_consts_kernel(const h16_t* __rest
   if (lane == 0) { if (s_out) s_out[n] = s; c_out[n] = c + (bias ? bias[n] : 0.f); }
 }
 
-__global__ void vec_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+__global__ void vec_mul_kernel(const float* a, const float* b, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] * b[i];
 }
@@ -364,7 +364,7 @@ __global__ void vec_mul_kernel(const float* __restrict__ a, const float* __restr
 // Optional attention-weight map (cross_reference.py:91-93 / torch functional.py:6576-6612): probabilities of
 // ONE head of the last decoder layer's cross-attention, P[b][q][k] = exp2(s*scale*log2e - lse2[b][head][q]).
 // lse2 comes from the fused attention kernel, so this pass only recomputes q.k for one head (fp32 dot on the
-// bf16 operands the fused kernel used) and streams the fp32 matrix out: HBM-write bound (B*Lq*Lk*4 bytes).
+// fp16 operands the fused kernel used) and streams the fp32 matrix out: HBM-write bound (B*Lq*Lk*4 bytes).
 // One wave per (q, 64 keys): lane = key; q row broadcast from registers.
 // -------------------------------------------------------------------------------------------------------
 template <int DH>
@@ -379,6 +379,9 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(CsAttnParams p, int h
   const float lse = p.lse[((size_t)bat * p.heads + head) * p.Lq + q];
   if (key < p.Lk) {
     const h16_t* kp = p.K + (size_t)bat * p.k_bs + (size_t)key * p.ldk + head * DH;
+    // the same operand values as cs_attn_kernel: Q pre-multiplied by scale_log2e (rounded to fp16 here when the producer did not fold it)
+    const float sc = p.scale_log2e;
+    const bool raw = sc != 1.0f;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < DH / 8; ++c) {
@@ -387,11 +390,13 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(CsAttnParams p, int h
       const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        s += h2f((h16_t)(kw[e] & 0xffffu)) * h2f((h16_t)(qw[e] & 0xffffu));
-        s += h2f((h16_t)(kw[e] >> 16)) * h2f((h16_t)(qw[e] >> 16));
+        float q0 = h2f((h16_t)(qw[e] & 0xffffu)), q1 = h2f((h16_t)(qw[e] >> 16));
+        if (raw) { q0 = h2f(f2h(q0 * sc)); q1 = h2f(f2h(q1 * sc)); }
+        s += h2f((h16_t)(kw[e] & 0xffffu)) * q0;
+        s += h2f((h16_t)(kw[e] >> 16)) * q1;
       }
     }
-    out[((size_t)bat * p.Lq + q) * p.Lk + key] = __builtin_amdgcn_exp2f(s * p.scale_log2e - lse);
+    out[((size_t)bat * p.Lq + q) * p.Lk + key] = __builtin_amdgcn_exp2f(s - lse);
   }
 }
 

@@ -1,11 +1,11 @@
-// bf16 MFMA GEMM with fused epilogues for the CrossScore hot path (gfx950).
+// fp16 MFMA GEMM with fused epilogues for the CrossScore hot path (gfx950).
 //
-//   out[m][n] = epilogue( bias[n] + sum_k A[m][k] * W[n][k] )     A:[M][K] bf16 (activations), W:[N][K] bf16 (nn.Linear layout)
+//   out[m][n] = epilogue( bias[n] + sum_k A[m][k] * W[n][k] )     A:[M][K] fp16 (activations), W:[N][K] fp16 (nn.Linear layout)
 //
 // Replaces the eager nn.Linear / Conv2d-patchify op groups K2,K4,K6,K7,K10,K12,K13,K15-K18 of SURVEY.md 2a
 // (HF modeling_dinov2.py:148,211-213,250,293-297; torch functional.py:5785-5852; cross_reference.py:45-50).
 //
-// Structure: 128 x {192,128} x 32 tiles, 4 waves side by side in N, wave tile 128 x {48,32} of v_mfma_f32_16x16x32_bf16.
+// Structure: 128 x {192,128} x 32 tiles, 4 waves side by side in N, wave tile 128 x {48,32} of v_mfma_f32_16x16x32_f16.
 // * Both operands are K-contiguous, so both fragments are 16-byte rows: staged HBM->LDS by global_load_lds_dwordx4 (no
 //   VGPR round trip) into a lane-linear image whose 16-byte chunks are XOR-swizzled on the SOURCE address and on the
 //   ds_read_b128 address (conflict free), 3-slot ring, counted s_waitcnt vmcnt + raw s_barrier, one barrier per K slice.
@@ -41,7 +41,7 @@ template <int NSUB> struct GemmCfg {
   static constexpr int RING = NS * STAGE_BYTES;
   static constexpr int WN = 16 * NSUB;                    // wave tile columns
   static constexpr int PROW_F = WN * 4 + 16;              // patch row (fp32), padded: conflict-free b128 writes
-  static constexpr int PROW_H = WN * 2 + 16;              // patch row (bf16)
+  static constexpr int PROW_H = WN * 2 + 16;              // patch row (fp16)
   static constexpr int PATCH = 16 * PROW_F + (NSUB == 2 ? 512 : 0);  // one 16-row patch per wave (+ room for the LN stash)
   static constexpr int BIAS_MAX = 1536;                   // the bias vector lives in LDS when N <= BIAS_MAX (every N of the path)
   static constexpr int BIAS_OFF = RING + 4 * PATCH;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void rb_touch(f32x4_t& r) { asm volatile("" : "+v"(r)
 
 // (sum, sum of squares) of one lane's 4 values, reduced over the LPR lanes that hold a row.  One helper with explicit fma order
 // for the full-tile and the ragged path: with -ffp-contract the compiler would otherwise fuse the two copies differently, and
-// a row's LayerNorm statistics (hence every later bf16 rounding) would depend on which tile the row fell into.
+// a row's LayerNorm statistics (hence every later fp16 rounding) would depend on which tile the row fell into.
 // The total lands in the LAST lane of the row (lane % LPR == LPR-1).  LPR == 16 is one DPP row: four v_add with row_shr
 // (no LDS crossbar traffic, which ds_bpermute-based shuffles would put into every epilogue step).
 template <int SHR>
@@ -140,8 +140,8 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F&
   (f(std::integral_constant<int, Js>{}), ...);
 }
 
-// Patch embedding on mean-centred patches: im2col removed each patch's per-channel mean before the bf16 rounding (a smooth image
-// patch is mostly its mean, and a bf16 rounding error of the weights times that mean was the largest single error term of the
+// Patch embedding on mean-centred patches: im2col removed each patch's per-channel mean before the fp16 rounding (a smooth image
+// patch is mostly its mean, and a fp16 rounding error of the weights times that mean was the largest single error term of the
 // encoder on natural images); the exact contribution mean_ch * sum_taps(W[n][ch]) comes back here in fp32.
 __device__ __forceinline__ f32x4_t patch_dc(const CsGemmParams& p, int m, int n) {
   const f32x4_t mu = *reinterpret_cast<const f32x4_t*>(p.pmean + (size_t)m * 4);
@@ -156,7 +156,7 @@ template <int EPI> struct EpiTraits {
   static constexpr bool kHalf = EPI == CS_EPI_BIAS_F16 || EPI == CS_EPI_BIAS_GELU_F16 || EPI == CS_EPI_BIAS_RELU_F16 ||
                                 EPI == CS_EPI_BIAS_LEAKY_F16 || kLN;
   static constexpr bool kResid = EPI == CS_EPI_RESID_F32 || EPI == CS_EPI_RESID_F32_LN;
-  static constexpr bool kLnOut = EPI == CS_EPI_RESID_F32_LN || EPI == CS_EPI_PATCH_F32;      // may emit bf16 copy + row partials
+  static constexpr bool kLnOut = EPI == CS_EPI_RESID_F32_LN || EPI == CS_EPI_PATCH_F32;      // may emit fp16 copy + row partials
 };
 
 // NSUB = 16-column sub-tiles per wave; block tile = 128 x (64*NSUB); 4 waves side by side in N, wave tile 128 x 16*NSUB.
@@ -173,15 +173,15 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   static_assert(D == 2, "the vmcnt bookkeeping below tracks exactly two iterations of epilogue traffic");
   constexpr bool kHalf = EpiTraits<EPI>::kHalf;
   // row-segment geometry of the epilogue steps (16 bytes per lane)
-  constexpr int CPR = kHalf ? Cfg::WN * 2 / 16 : Cfg::WN * 4 / 16;         // 16-byte chunks per patch row: 6/4 (bf16), 12/8 (fp32)
+  constexpr int CPR = kHalf ? Cfg::WN * 2 / 16 : Cfg::WN * 4 / 16;         // 16-byte chunks per patch row: 6/4 (fp16), 12/8 (fp32)
   constexpr int LPR = kHalf ? (NSUB == 2 ? 4 : 8) : (NSUB == 2 ? 8 : 16);  // lanes assigned per row
   constexpr int RPI = 64 / LPR;                                            // rows per ds_read / global access
-  constexpr int NRD = 16 / RPI;                                            // accesses per 16-row step: 2/1 (bf16), 4/2 (fp32)
+  constexpr int NRD = 16 / RPI;                                            // accesses per 16-row step: 2/1 (fp16), 4/2 (fp32)
   constexpr int PROW = kHalf ? Cfg::PROW_H : Cfg::PROW_F;
   // vector-memory instructions one full-tile epilogue step issues: stores (+ the row partials of an LN-folded consumer);
-  // stores + as many addend loads for RESID / PATCH (+ bf16 copy + row partials when those are emitted)
+  // stores + as many addend loads for RESID / PATCH (+ fp16 copy + row partials when those are emitted)
   constexpr int VE = kHalf ? NRD : (kLnOut ? 4 * NRD : (PIPE ? NRD : 2 * NRD));
-  // LN-folded consumer: behind the bf16 patch rows each wave keeps s[n], c[n] of the tile's columns and (mu, rstd) of the
+  // LN-folded consumer: behind the fp16 patch rows each wave keeps s[n], c[n] of the tile's columns and (mu, rstd) of the
   // tile's 128 rows, filled once per tile, so the epilogue steps issue no vector-memory loads (a load consumed inside a
   // step would wait for every older LDS-DMA: the queue retires in order)
   constexpr int STASH = 16 * Cfg::PROW_H;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
       const int mrow0 = pm0 + I * 16 + rrow;
       const int n = ncol0 + rch * (kHalf ? 8 : 4);
       [[maybe_unused]] const int st_slot = (pn0 / BN) * 4 + wn;
-      [[maybe_unused]] const bool ln_out = kLnOut && p.out_bf16 && p.stats_out;
+      [[maybe_unused]] const bool ln_out = kLnOut && p.out_f16 && p.stats_out;
       if (prev_full && (!kResid || p.resid) && (!kLnOut || EPI == CS_EPI_PATCH_F32 || ln_out) &&
           (EPI != CS_EPI_PATCH_F32 || ln_out)) {
         // every row and column of the tile exists: no row tests, a fixed number (VE) of memory instructions
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
               const size_t row = EPI == CS_EPI_PATCH_F32 ? (size_t)(m + m / p.Np + 1) : (size_t)m;
               *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + row * p.ldc + n) = seg[q];
               if constexpr (kLnOut)
-                *reinterpret_cast<u32x2_t*>(p.out_bf16 + row * p.ldc + n) =
+                *reinterpret_cast<u32x2_t*>(p.out_f16 + row * p.ldc + n) =
                     u32x2_t{pack_h16x2(seg[q][0], seg[q][1]), pack_h16x2(seg[q][2], seg[q][3])};
             }
           }
@@ -476,8 +476,8 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
             }
             *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + row * p.ldc + n) = seg[q];
             if constexpr (kLnOut)
-              if (p.out_bf16)
-                *reinterpret_cast<u32x2_t*>(p.out_bf16 + row * p.ldc + n) =
+              if (p.out_f16)
+                *reinterpret_cast<u32x2_t*>(p.out_f16 + row * p.ldc + n) =
                     u32x2_t{pack_h16x2(seg[q][0], seg[q][1]), pack_h16x2(seg[q][2], seg[q][3])};
           }
         }
@@ -754,13 +754,13 @@ extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
   if (p->M <= 0 || p->N <= 0 || p->K <= 0) return "gemm: empty shape";
   if (p->K % 64) return "gemm: K must be a multiple of 64";
   if (p->N % 4 || p->ldc % 4) return "gemm: N and ldc must be multiples of 4";
-  if (epi <= CS_EPI_BIAS_LEAKY_F16 && (p->N % 8 || p->ldc % 8)) return "gemm: bf16 outputs need N and ldc multiples of 8 (16-byte row stores)";
+  if (epi <= CS_EPI_BIAS_LEAKY_F16 && (p->N % 8 || p->ldc % 8)) return "gemm: fp16 outputs need N and ldc multiples of 8 (16-byte row stores)";
   if (p->lda % 8 || p->ldw % 8) return "gemm: lda/ldw must be multiples of 8 (16-byte rows)";
   if (p->lda < p->K || p->ldw < p->K) return "gemm: lda/ldw smaller than K";
   if (!p->A || !p->W || !p->out) return "gemm: null operand";
   if (p->scale) return "gemm: a per-column scale is folded into the packed weights (cs_op_pack_f16 row_scale), it is not an epilogue operand";
   if ((epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN) && p->resid && p->ldr % 4) return "gemm: ldr must be a multiple of 4";
-  if (epi == CS_EPI_RESID_F32_LN && (!p->out_bf16 || !p->stats_out)) return "gemm: RESID_F32_LN needs out_bf16 and stats_out";
+  if (epi == CS_EPI_RESID_F32_LN && (!p->out_f16 || !p->stats_out)) return "gemm: RESID_F32_LN needs out_f16 and stats_out";
   if ((epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32) && p->stats_out && p->stats_sp != 4 * cs_gemm_column_tiles(p->N))
     return "gemm: stats_sp must be 4 x the number of column tiles";
   if ((epi == CS_EPI_LN_F16 || epi == CS_EPI_LN_GELU_F16) &&

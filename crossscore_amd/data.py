@@ -192,7 +192,7 @@ class ReferenceTokenCache:
         return any(k[0] == path for k in self.tokens)
 
     def gather(self, ref_lists: List[List[str]], decoded: Dict[str, np.ndarray], size: Tuple[int, int], zero_reference: bool):
-        """ref_lists: per item the N reference paths -> (tokens (B,N,Np,C) bf16, images (B,N,3,h,w) fp32 or None)."""
+        """ref_lists: per item the N reference paths -> (tokens (B,N,Np,C) fp16, images (B,N,3,h,w) fp32 or None)."""
         oh, ow = size
         keys = [[(EMPTY if (p == EMPTY or zero_reference) else p, oh, ow) for p in refs] for refs in ref_lists]
         missing = list(dict.fromkeys(k for ks in keys for k in ks if k not in self.tokens))

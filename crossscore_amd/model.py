@@ -212,7 +212,7 @@ class CrossScoreNet(torch.nn.Module):
     # -- reference-feature cache: a separate mode, bit-identical results ---------------------------
     @torch.no_grad()
     def encode_references(self, ref_imgs):
-        """(R,3,H,W) normalised reference images -> (R, h*w, C) bf16 decoder-ready tokens (final LN + multi-view PE).
+        """(R,3,H,W) normalised reference images -> (R, h*w, C) fp16 decoder-ready tokens (final LN + multi-view PE).
         A reference's tokens depend neither on the query nor on its view slot, so they can be computed once per image of
         reference_dir and gathered per query."""
         if ref_imgs.dim() != 4 or ref_imgs.shape[1] != 3 or not ref_imgs.is_cuda:
@@ -230,7 +230,7 @@ class CrossScoreNet(torch.nn.Module):
 
     @torch.no_grad()
     def forward_cached(self, query_img, ref_tokens, need_attn_weights=False, need_attn_weights_head_id=0, return_mean=False):
-        """forward() with the reference views given as cached tokens (B, N, h*w, C) bf16 from encode_references."""
+        """forward() with the reference views given as cached tokens (B, N, h*w, C) fp16 from encode_references."""
         if query_img.dim() != 4 or ref_tokens.dim() != 4 or ref_tokens.shape[0] != query_img.shape[0]:
             raise ValueError("expected query_img (B,3,H,W) and ref_tokens (B,N,h*w,C)")
         if not query_img.is_cuda or not ref_tokens.is_cuda or ref_tokens.device != query_img.device:

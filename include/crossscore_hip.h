@@ -8,7 +8,7 @@
  * reference code it replaces.  Plain pointers and sizes only: no torch / Python types cross this line.
  *
  * Ownership: the caller (PyTorch) owns every input / output / weight-source buffer; the library owns only its
- * packed bf16 weights and its workspace.  Threading: a handle is not thread-safe; one handle per process per
+ * packed fp16 weights and its workspace.  Threading: a handle is not thread-safe; one handle per process per
  * GPU (a handle may be re-created on another GPU of the process: launcher state is kept per device).  All work is enqueued on
  * the caller's hipStream_t (a forward that arrives on another stream than the previous one waits for it with an event: the
  * workspace is shared).  No entry point waits for the device or a stream except cs_finalize, cs_profile_* and cs_destroy:
@@ -79,7 +79,7 @@ int cs_set_weight(cs_handle h, const char* name, const float* data, int is_devic
 /* Number of tensors cs_finalize expects and the i-th expected name (for loaders / strict checking). */
 int cs_num_weights(cs_handle h);
 const char* cs_weight_name(cs_handle h, int i);
-/* Packs weights to bf16 / fused layouts (QKV, both decoder layers' KV). Fails if a tensor is missing. */
+/* Packs weights to fp16 / fused layouts (QKV, both decoder layers' KV). Fails if a tensor is missing. */
 int cs_finalize(cs_handle h);
 
 /* Replaces CrossScoreNet.forward (task/core.py:58-117) with norm_img=False.
@@ -93,7 +93,7 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
 /* Reference-feature cache.  In predict the N references of every query are drawn from one finite
  * reference_dir (dataloading/dataset/simple_reference.py:55-58, utils/neighbour/sampler.py:27-34), and a reference's
  * decoder input -- final LayerNorm of its DINOv2 tokens + multi-view PE, task/core.py:141-153,93-98 -- does not depend on the
- * query or on its view slot.  cs_encode_references encodes R images once into bf16 tokens (R, h*w, C); cs_forward_cached
+ * query or on its view slot.  cs_encode_references encodes R images once into fp16 tokens (R, h*w, C); cs_forward_cached
  * scores B queries against gathered tokens (B, N, h*w, C).  Results are bit-identical to cs_forward on the same images; the
  * encoder work per query drops from 1+N images to 1 (a separate mode: it changes the algorithmic FLOPs). */
 int cs_encode_references(cs_handle h, const float* imgs, int R, int H, int W, uint16_t* tokens_out, cs_stream stream);
@@ -111,22 +111,25 @@ int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, do
 int cs_profile_read_bytes(cs_handle h, int family, double* bytes);
 
 /* ---- single-op entry points (used by the parity tests; same kernels the forward launches) ------------- */
-/* out = epilogue(bias + A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. bf16 = raw uint16. */
+/* out = epilogue(bias + A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. fp16 = raw uint16. */
 int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
                const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np,
                int gw, int P, int act, float powp,
                /* LayerNorm fold (CsEpilogue 7-9): producer outputs, then consumer inputs; NULL / 0 when unused */
-               uint16_t* out_bf16, float* stats_out, int stats_sp, const float* ln_part, int ln_sp, const float* col_s,
+               uint16_t* out_f16, float* stats_out, int stats_sp, const float* ln_part, int ln_sp, const float* col_s,
                float ln_eps, cs_stream stream);
 /* softmax(QK^T/sqrt(dh))V for `batch` x `heads`; strides in elements; lse may be NULL. */
+/* O = softmax(Q K^T / sqrt(dh)) V computed in the base-2 domain: p = 2^(q_scale * q.k - m).  The forward folds log2(e)/sqrt(dh) into its
+ * Q projections and passes q_scale = 1 (Q arrives pre-multiplied); q_scale = 0 means log2(e)/sqrt(dh) applied here, to raw Q, at the
+ * price of one more fp16 rounding of Q.  lse (optional, [batch][heads][Lq]) is in base-2 units of the scaled logits. */
 int cs_op_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* V, uint16_t* O, int ldq, int ldk, int ldv,
                     int ldo, long long q_bs, long long k_bs, long long v_bs, long long o_bs, int batch, int heads,
-                    int Lq, int Lk, int dh, float* lse, cs_stream stream);
+                    int Lq, int Lk, int dh, float q_scale, float* lse, cs_stream stream);
 int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int ldk, long long q_bs, long long k_bs,
-                            int batch, int heads, int Lq, int Lk, int dh, const float* lse, int head, float* out,
-                            cs_stream stream);
+                            int batch, int heads, int Lq, int Lk, int dh, float q_scale, const float* lse, int head,
+                            float* out, cs_stream stream);
 int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
-                    uint16_t* out_bf16, cs_stream stream);
+                    uint16_t* out_f16, cs_stream stream);
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream);
 /* The patch embedding exactly as the forward runs it (HF modeling_dinov2.py:141-149: conv patchify = im2col + GEMM, + position rows), with
  * (centred != 0) or without the mean-centred operand form: x (I,3,H,W), w (C,3,P,P), bias (C), pos (1 + Np, C) -> out (I * (1 + Np), C) fp32,
@@ -149,7 +152,7 @@ int cs_op_score_to_gray16(const float* score, long long n, int signed_range, uin
 int cs_op_score_to_rgb(const float* score, long long n, float vmin, float vmax, const uint8_t* lut256x3, uint8_t* out, cs_stream stream);
 int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream);
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
-/* fp32 [rows][K] -> bf16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
+/* fp32 [rows][K] -> fp16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
  * rows of a projection, LayerNorm gamma into its columns */
 int cs_op_pack_f16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
                     cs_stream stream);
@@ -161,7 +164,7 @@ int cs_op_ln_fold_consts(const uint16_t* w_packed, int ldp, const float* w, cons
  * per-column scale g2 (norm2 gamma), w2 (C,4C) with per-row scale ls2 (layer_scale2); scales may be NULL.  img must hold
  * cs_panel_image_bytes(wo != NULL) bytes.  cs_op_encoder_panel then computes, in place on x (M,C) fp32,
  *   x += attn_o Wo'^T + bo   (skipped when attn_o is NULL);   x += GELU(norm(x) W1'^T + b1) W2'^T + b2;
- *   u_out = bf16(norm(x))    (skipped when NULL), norm = LayerNorm without gamma/beta (HF modeling_dinov2.py:361-380). */
+ *   u_out = fp16(norm(x))    (skipped when NULL), norm = LayerNorm without gamma/beta (HF modeling_dinov2.py:361-380). */
 int cs_panel_supported(int hidden, int mlp_ratio);
 size_t cs_panel_image_bytes(int with_outproj);
 int cs_op_panel_pack(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,

@@ -15,8 +15,8 @@ def _stream():
 
 
 def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_F16, resid=None, out=None, pos=None, Np=0, gw=0, P=0, act=0, powp=1.0,
-         K=None, ldc=None, out_bf16=None, stats_out=None, ln_part=None, col_s=None, ln_eps=1e-6):
-    """A:(M,lda) bf16, W:(N,ldw) bf16 -> out (allocated here unless given)."""
+         K=None, ldc=None, out_f16=None, stats_out=None, ln_part=None, col_s=None, ln_eps=1e-6):
+    """A:(M,lda) fp16, W:(N,ldw) fp16 -> out (allocated here unless given)."""
     lib = _lib.load()
     M, lda = A.shape
     N, ldw = W.shape
@@ -26,42 +26,48 @@ def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_F16, resid=None, out=None, pos=None,
         out = torch.zeros((M, N), dtype=dt, device=A.device)
     ldc = ldc or out.shape[-1]
     rc = lib.cs_op_gemm(_p(A), lda, _p(W), ldw, M, N, K, _p(bias), _p(resid), resid.shape[-1] if resid is not None else 0,
-                        _p(out), ldc, epi, _p(pos), Np, gw, P, act, powp, _p(out_bf16), _p(stats_out),
+                        _p(out), ldc, epi, _p(pos), Np, gw, P, act, powp, _p(out_f16), _p(stats_out),
                         stats_out.shape[1] if stats_out is not None else 0, _p(ln_part), ln_part.shape[1] if ln_part is not None else 0,
                         _p(col_s), ln_eps, _stream())
     _lib.check(rc)
     return out
 
 
-def attention(Q, K, V, heads, dh, lse=False):
-    """Q:(B,Lq,heads*dh) K,V:(B,Lk,heads*dh) bf16 contiguous -> O (B,Lq,heads*dh) bf16 [, lse (B,heads,Lq)]."""
+def prescale_q(Q, dh):
+    """Q * log2(e)/sqrt(dh) in fp32, rounded to fp16 once: what the forward's Q projections emit (the factor is folded into their weights)."""
+    return (Q.float() * (1.4426950408889634 / dh ** 0.5)).to(torch.float16)
+
+
+def attention(Q, K, V, heads, dh, lse=False, q_scale=0.0):
+    """Q:(B,Lq,heads*dh) K,V:(B,Lk,heads*dh) fp16 contiguous -> O (B,Lq,heads*dh) fp16 [, lse (B,heads,Lq), base 2].
+    q_scale=1: Q is prescale_q(..) already; 0: raw Q, scaled (and re-rounded) inside the kernel."""
     lib = _lib.load()
     B, Lq, Cq = Q.shape
     Lk = K.shape[1]
     O = torch.zeros((B, Lq, heads * dh), dtype=torch.float16, device=Q.device)
     L = torch.zeros((B, heads, Lq), dtype=torch.float32, device=Q.device) if lse else None
     rc = lib.cs_op_attention(_p(Q), _p(K), _p(V), _p(O), Q.stride(1), K.stride(1), V.stride(1), O.stride(1), Q.stride(0), K.stride(0),
-                             V.stride(0), O.stride(0), B, heads, Lq, Lk, dh, _p(L), _stream())
+                             V.stride(0), O.stride(0), B, heads, Lq, Lk, dh, q_scale, _p(L), _stream())
     _lib.check(rc)
     return (O, L) if lse else O
 
 
-def attention_weights(Q, K, heads, dh, lse, head):
+def attention_weights(Q, K, heads, dh, lse, head, q_scale=0.0):
     lib = _lib.load()
     B, Lq, _ = Q.shape
     Lk = K.shape[1]
     out = torch.zeros((B, Lq, Lk), dtype=torch.float32, device=Q.device)
-    rc = lib.cs_op_attention_weights(_p(Q), _p(K), Q.stride(1), K.stride(1), Q.stride(0), K.stride(0), B, heads, Lq, Lk, dh, _p(lse),
-                                     head, _p(out), _stream())
+    rc = lib.cs_op_attention_weights(_p(Q), _p(K), Q.stride(1), K.stride(1), Q.stride(0), K.stride(0), B, heads, Lq, Lk, dh, q_scale,
+                                     _p(lse), head, _p(out), _stream())
     _lib.check(rc)
     return out
 
 
-def layernorm(x, g, b, eps, want_f32=True, want_bf16=True):
+def layernorm(x, g, b, eps, want_f32=True, want_f16=True):
     lib = _lib.load()
     M, Cc = x.shape
     of = torch.zeros_like(x) if want_f32 else None
-    ob = torch.zeros((M, Cc), dtype=torch.float16, device=x.device) if want_bf16 else None
+    ob = torch.zeros((M, Cc), dtype=torch.float16, device=x.device) if want_f16 else None
     _lib.check(lib.cs_op_layernorm(_p(x), M, Cc, _p(g), _p(b), eps, _p(of), _p(ob), _stream()))
     return of, ob
 
@@ -122,7 +128,7 @@ def panel_pack(wo, ls1, w1, g2, w2, ls2):
 
 
 def encoder_panel(x, attn_o, img, bo, b1, b2, want_u=True, eps=1e-6):
-    """In place on x (M,384) fp32; returns u (M,384) bf16 or None."""
+    """In place on x (M,384) fp32; returns u (M,384) fp16 or None."""
     lib = _lib.load()
     M = x.shape[0]
     u = torch.zeros((M, x.shape[1]), dtype=torch.float16, device=x.device) if want_u else None

@@ -129,9 +129,9 @@ def test_tiny_shape_sweep_vs_oracle(B, N, H, W):
 
 
 def test_structured_images_vs_oracle():
-    """Natural-image-like inputs (smooth patterns + mild noise, ImageNet-normalised uint8 pixels) are the hard case for bf16
+    """Natural-image-like inputs (smooth patterns + mild noise, ImageNet-normalised uint8 pixels) are the hard case for 16-bit
     operands: a patch is mostly its mean, so the rounding error of the patch-embedding weights adds up coherently.  The
-    mean-centred patch embedding + split-bf16 tail keep the score-map MAE well inside the bound (plain bf16: 1.0e-3)."""
+    mean-centred patch embedding + fp16 operands keep the score-map MAE well inside the bound (plain bf16 operands: 1.0e-3)."""
     from oracle import preprocess_oracle as po
 
     net, arch, sd = _net("facebook/dinov2-small", 1)
@@ -168,7 +168,7 @@ def test_attention_weights_full_size_vs_oracle():
     assert (rows.sum(-1) - 1).abs().max() < 1e-4 and rows.min() >= 0
     ref = _oracle(arch, sd, q, r, need_w=True, head=5)["attn_weights_map_ref_cross"].reshape(1369, -1)
     d = (rows.cpu() - ref).abs()
-    assert float(d.sum(-1).max()) < 0.05, float(d.sum(-1).max())   # total-variation-like distance per row (bf16 logits)
+    assert float(d.sum(-1).max()) < 0.05, float(d.sum(-1).max())   # total-variation-like distance per row (fp16 logits)
     assert float(d.max()) < 2e-2
 
 

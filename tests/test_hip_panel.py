@@ -53,15 +53,18 @@ def test_panel_vs_torch(M, outproj):
     u = hh.encoder_panel(xk, o if outproj else None, img, w["bo"] if outproj else None, w["b1"], w["b2"])
     torch.cuda.synchronize()
     ref_x, ref_u = _reference(x, o, w, outproj, emulate=True)
-    # same bf16 operand roundings as the kernel: what is left is fp32 summation order and the GELU fit (<= 2.1e-4)
+    # same fp16 operand roundings as the kernel: what is left is fp32 summation order and the GELU fit (<= 2.1e-4)
     assert torch.isfinite(xk).all()
     err = (xk - ref_x).abs().max().item()
-    assert err < 2e-2, err
-    assert (xk - ref_x).abs().mean().item() < 1.5e-3
-    assert (u.float() - ref_u).abs().max().item() < 4e-2  # bf16 output of O(1..4) values: half an ulp is up to 1.6e-2
-    # against exact fp32 arithmetic the bf16 operand rounding dominates
+    assert err < 4e-3, err
+    mean_err = (xk - ref_x).abs().mean().item()
+    assert mean_err < 3e-4, mean_err
+    u_err = (u.float() - ref_u).abs().max().item()
+    assert u_err < 6e-3, u_err  # fp16 output of O(1..4) values: half an ulp is up to 2e-3
+    # against exact fp32 arithmetic the fp16 operand rounding dominates
     ex_x, _ = _reference(x, o, w, outproj, emulate=False)
-    assert (xk - ex_x).abs().mean().item() < 8e-3
+    ex_err = (xk - ex_x).abs().mean().item()
+    assert ex_err < 1.2e-3, ex_err
 
 
 def test_panel_rows_are_independent():

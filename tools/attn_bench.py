@@ -27,6 +27,8 @@ if os.environ.get("CS_ATTN_CHILD"):
         err = (O[0, :, :dh].float() - ref).abs().max().item()
         print(f"  {name}: {us:7.1f} us  {fl / us / 1e6:6.0f} TFLOP/s  max err {err:.1e}", flush=True)
     sys.exit(0)
+sys.path.insert(0, R)
+from crossscore_amd import build
 variants = [v for v in os.environ.get("CS_ATTN_VARIANTS", "").split(",") if v]
 srcs = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip"]
 for var in [None] + variants:
@@ -41,8 +43,8 @@ for var in [None] + variants:
         for s in srcs:
             o = os.path.join(tmp, s + ".o"); objs.append(o)
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-            if s in ("panel.hip", "attention.hip"): cmd += ["-fno-slp-vectorize"]
-            if s == "attention.hip": cmd += ["-DCS_ATTN_" + d for d in var.split("+")]
+            cmd += build.EXTRA_FLAGS.get(s, [])
+            if s == "attention.hip": cmd += ["-fno-slp-vectorize" if d == "NOSLP" else "-DCS_ATTN_" + d for d in var.split("+")]
             procs.append(subprocess.Popen(cmd + ["-c", os.path.join(pkg, "csrc", s), "-o", o]))
         for pr in procs: assert pr.wait() == 0
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(pkg, "libcrossscore_hip.so")] + objs)

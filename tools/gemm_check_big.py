@@ -1,4 +1,4 @@
-"""Correctness of the residual GEMM at full encoder sizes against torch (fp32 accumulate of the same bf16 operands)."""
+"""Correctness of the residual GEMM at full encoder sizes against torch (fp32 accumulate of the same fp16 operands)."""
 import os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))

@@ -1,4 +1,4 @@
-"""Per-shape timing of the encoder GEMMs: this library's kernel (with its fused epilogue) vs torch.matmul (hipBLASLt, bf16
+"""Per-shape timing of the encoder GEMMs: this library's kernel (with its fused epilogue) vs torch.matmul (hipBLASLt, fp16
 out, no epilogue) on the same operands. Calibrates how far the fused kernels are from a tuned library GEMM."""
 import os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""Where does the panel kernel differ from the bf16-emulating torch restatement?  (debug aid)"""
+"""Where does the panel kernel differ from the fp16-emulating torch restatement?  (debug aid)"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
