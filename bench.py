@@ -28,6 +28,7 @@ import torch  # noqa: E402
 from crossscore_amd import synth  # noqa: E402
 from crossscore_amd.config import model_config  # noqa: E402
 from crossscore_amd.model import CrossScoreNet  # noqa: E402
+from crossscore_amd.pipeline import ForwardPipeline  # noqa: E402
 from crossscore_amd import parallel  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (the F16 forms take the same cycles), /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
@@ -242,7 +243,7 @@ def timed_steps(step, sync, steps, warmup, dev):
 class Workload:
     """One BASELINE.json configuration on this rank: replica from the seed, this rank's shard of the synthetic batch in HBM."""
 
-    def __init__(self, name, rank, dev, lanes=0, chunk=0, seed=1):
+    def __init__(self, name, rank, dev, lanes=0, chunk=0, seed=1, inflight=1):
         self.name = name
         self.backbone, self.H, self.W, self.N, self.B = WORKLOADS[name]
         self.seed, self.dev = seed, dev
@@ -255,11 +256,20 @@ class Workload:
             self.net.lanes = lanes
         if chunk > 0:
             self.net.enc_chunk_images = chunk
+        # `inflight` batches in flight (crossscore_amd/pipeline.py): replicas over the same parameters fed round-robin on their own streams,
+        # as the predict driver runs its batch loop; 1 = the plain forward on this stream
+        self.pipe = ForwardPipeline(self.net, depth=inflight, lanes=lanes if lanes > 0 else None)
+        self.inflight, self.lanes = inflight, self.net.lanes
         lo = rank * self.B  # weak scaling: rank r scores global items [r*B, (r+1)*B)
         q, r = synth.make_inputs_shard(lo, lo + self.B, self.N, self.H, self.W, seed)
         self.tq, self.tr = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)  # inputs resident in HBM before timing
 
     def step(self):
+        """queues one batch; returns its ticket (pipe.result(ticket) orders the outputs on the current stream)"""
+        return self.pipe.submit(self.tq, self.tr, False, 0, False)
+
+    def direct(self):
+        """one batch through replica 0 on the current stream (per-kernel profiling pass)"""
         return self.net(self.tq, self.tr, False, 0, False)
 
     def describe(self, world):
@@ -309,6 +319,8 @@ def main():
                     "kernel run alone, which is how the per-kernel table below is measured")
     ap.add_argument("--chunk", type=int, default=0, help="encoder chunk in images (0 = library default); the per-kernel table uses "
                     "one chunk for the whole batch")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (crossscore_amd.pipeline.ForwardPipeline, the predict "
+                    "driver's batch loop); 1 = one forward at a time with the library's two encoder lanes")
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo rehearsal of the rank plumbing
     args = ap.parse_args()
 
@@ -327,15 +339,17 @@ def main():
     torch.cuda.set_device(dev)
     sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
 
-    wl = Workload(args.workload, rank, dev, args.lanes, args.chunk)
+    if args.inflight < 1:
+        raise SystemExit("--inflight must be >= 1")
+    wl = Workload(args.workload, rank, dev, args.lanes, args.chunk, inflight=args.inflight)
     net, arch, B, N, H, W = wl.net, wl.arch, wl.B, wl.N, wl.H, wl.W
-    elapsed, out = timed_steps(wl.step, sync, args.steps, args.warmup, dev)
-    score = out["score_map_ref_cross"]
+    elapsed, ticket = timed_steps(wl.step, sync, args.steps, args.warmup, dev)
+    score = wl.pipe.result(ticket)["score_map_ref_cross"]  # the output of the last timed step
 
     # ---- BASELINE.json configs[3] (the scaling configuration) on the same ranks: ViT-B/14, 5 refs, 16 items per GPU ----
     cfg4 = None
     if not args.no_cfg4 and args.workload != "cfg4":
-        w4 = Workload("cfg4", rank, dev)
+        w4 = Workload("cfg4", rank, dev, inflight=args.inflight)
         steps4 = max(3, args.steps // 4)
         e4, _ = timed_steps(w4.step, sync, steps4, 2, dev)
         v4 = world * w4.B * steps4 / e4
@@ -355,11 +369,11 @@ def main():
         saved = (net.lanes, net.enc_chunk_images)
         net.lanes, net.enc_chunk_images = 1, B * (1 + N)
         net._mark_dirty()
-        wl.step()  # rebuilds the handle with the new lane / chunk settings
+        wl.direct()  # rebuilds the handle with the new lane / chunk settings
         net.profile_enable(True)
         prof_steps = 3
         for _ in range(prof_steps):
-            wl.step()
+            wl.direct()
         rows = kernel_table(net)
         net.profile_enable(False)
         net.lanes, net.enc_chunk_images = saved
@@ -375,7 +389,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16", "data": "synthetic",  # 16-bit MFMA operands (IEEE half, the bf16 MFMA rate), fp32 accumulate / softmax / LayerNorm / output
             "config": {"workload": wl.describe(world),
-                       "gflop_per_query": flops_q / 1e9, "parallelism": f"batch-shard x{world} (replicas, no data-path collective)"},
+                       "gflop_per_query": flops_q / 1e9, "parallelism": f"batch-shard x{world} (replicas, no data-path collective); per GPU {wl.inflight} batch(es) in flight x "
+                                      f"{wl.lanes if wl.lanes else 2} encoder lane(s)",
+                       "batches_in_flight": wl.inflight},
             "whole_path": {"achieved_tflops": value * flops_q / 1e12 / world, "peak_tflops": PEAK_BF16_TFLOPS,
                            "frac": value * flops_q / 1e12 / world / PEAK_BF16_TFLOPS},
             "roofline": roofline_of(dom),

@@ -29,6 +29,7 @@ from . import parallel, synth
 from .config import load_config
 from .data import InputStage, ReferenceTokenCache, SimpleReferenceItems, decode_items, load_batch, load_query_batch
 from .model import CrossScoreNet, load_lightning_checkpoint
+from .pipeline import ForwardPipeline
 from .writers import BatchWriter, ScoreSummariser
 
 
@@ -99,16 +100,33 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
     # this_main.cache_reference_tokens (this build's key, default on): every reference image goes through the encoder once per run
     # instead of once per query that samples it; the score maps are bit-identical
     use_cache = bool(cfg.this_main.get("cache_reference_tokens", True)) and int(cfg.data.neighbour_config.cross) > 0
-    cache = ReferenceTokenCache(net, stage, keep_images=bool(writer is not None and cfg.logger.predict.write.flag.image_reference),
+    # this_main.batches_in_flight (this build's key, default 2): the batch loop keeps that many forwards queued on replicas of the
+    # module (pipeline.py), so one batch's decoder runs beside the next batch's encoder; outputs are consumed one submit later,
+    # in batch order, bit-identical to the one-at-a-time loop
+    pipe = ForwardPipeline(net, depth=max(1, int(cfg.this_main.get("batches_in_flight", 2))))
+    cache = ReferenceTokenCache(pipe, stage, keep_images=bool(writer is not None and cfg.logger.predict.write.flag.image_reference),
                                 max_images=int(cfg.this_main.get("reference_cache_max_images", 4096))) if use_cache else None
     cached_paths = lambda: {k[0] for k in cache.tokens} if cache is not None else ()  # noqa: E731
     pending = prefetch.submit(decode_items, batches[0], zero_ref, pool, cached_paths()) if batches else None
-    files, n_done, t_model = [], 0, 0.0
+    need_w, head_id = bool(cfg.model.need_attn_weights), int(cfg.model.need_attn_weights_head_id)
+    files, n_done = [], 0
+
+    def consume(entry):
+        ticket, batch, idx = entry
+        out = pipe.result(ticket)
+        summariser.update(batch, out)
+        if writer is not None:
+            files.extend(writer.write_out(batch, out, local_rank, idx))
+
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    prev = None
     for batch_idx, its in enumerate(batches):
         decoded = pending.result()
         if cache is None:
             pending = prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool) if batch_idx + 1 < len(batches) else None
             batch = load_batch(its, stage, zero_ref, decoded)
+            ticket = pipe.submit(batch["query/img"], batch["reference/cross/imgs"], need_w, head_id, False)
         else:
             batch, size = load_query_batch(its, stage, decoded)
             tokens, ref_imgs = cache.gather([it["reference/cross/imgs"] for it in its], decoded, size, zero_ref)
@@ -116,19 +134,15 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
             # (submitted after gather so that the set of cached paths is current; decoding overlaps the forward below)
             pending = (prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool, cached_paths())
                        if batch_idx + 1 < len(batches) else None)
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        if cache is None:
-            out = net(query_img=batch["query/img"], ref_cross_imgs=batch["reference/cross/imgs"], need_attn_weights=bool(cfg.model.need_attn_weights),
-                      need_attn_weights_head_id=int(cfg.model.need_attn_weights_head_id), norm_img=False)
-        else:
-            out = net.forward_cached(batch["query/img"], tokens, bool(cfg.model.need_attn_weights), int(cfg.model.need_attn_weights_head_id))
-        torch.cuda.synchronize(device)
-        t_model += time.perf_counter() - t0
+            ticket = pipe.submit_cached(batch["query/img"], tokens, need_w, head_id)
         n_done += batch["query/img"].shape[0]
-        summariser.update(batch, out)
-        if writer is not None:
-            files += writer.write_out(batch, out, local_rank, batch_idx)
+        if prev is not None:
+            consume(prev)
+        prev = (ticket, batch, batch_idx)
+    if prev is not None:
+        consume(prev)
+    torch.cuda.synchronize(device)
+    t_loop = time.perf_counter() - t0
     if writer is not None:
         writer.finish()
     files += summariser.summarise()
@@ -136,7 +150,7 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
     pool.shutdown()
     parallel.barrier()
     return {"out_dir": cfg.logger.predict.out_dir, "files": files, "rows": summariser.rows,
-            "query_images_per_sec": n_done / t_model if t_model > 0 else 0.0}
+            "query_images_per_sec": n_done / t_loop if t_loop > 0 else 0.0}  # the whole scoring loop: input stage, forwards, output stage
 
 
 def main(argv: Optional[Iterable[str]] = None) -> int:
@@ -148,7 +162,7 @@ def main(argv: Optional[Iterable[str]] = None) -> int:
         return 2
     with torch.no_grad():
         res = predict(cfg)
-    print(f"[crossscore_amd.predict] {len(res['rows'])} query images, {res['query_images_per_sec']:.1f} query-images/s in the model, "
+    print(f"[crossscore_amd.predict] {len(res['rows'])} query images, {res['query_images_per_sec']:.1f} query-images/s through the scoring loop, "
           f"outputs under {res['out_dir']}")
     return 0
 

@@ -300,6 +300,45 @@ def test_reference_token_cache_is_bit_identical():
     assert torch.equal(cached["attn_weights_map_ref_cross"], full["attn_weights_map_ref_cross"])
 
 
+@pytest.mark.parametrize("depth,backbone,H", [(2, "facebook/dinov2-small", 224), (3, TINY, 98), (1, TINY, 98)])
+def test_batches_in_flight_are_bit_identical_to_one_at_a_time(depth, backbone, H):
+    """crossscore_amd.pipeline.ForwardPipeline: `depth` replicas over the same parameters, fed round-robin on their own streams (one
+    batch's decoder beside the next batch's encoder).  Seven different batches, results fetched one submit later as the predict loop
+    does: every score map equals the plain forward's bit for bit, also through the reference-token cache entry."""
+    from crossscore_amd.pipeline import ForwardPipeline
+
+    net, arch, sd = _net(backbone, 5)
+    batches = []
+    for i in range(7):
+        q, r = synth.make_inputs(2 + (i % 2), 3, H, H, 100 + i)  # batch size alternates: the workspaces are re-planned in flight
+        batches.append((torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()))
+    want = [net(q, r, False, 0, False)["score_map_ref_cross"].clone() for q, r in batches]
+    toks = [net.encode_references(r.reshape(-1, 3, H, H)).reshape(r.shape[0], r.shape[1], -1, arch.hidden) for _, r in batches]
+    torch.cuda.synchronize()
+    pipe = ForwardPipeline(net, depth=depth)
+    assert len(pipe.nets) == depth and all(p.data_ptr() == q.data_ptr() for n in pipe.nets[1:] for p, q in zip(n.parameters(), net.parameters()))
+    got, prev = [], None
+    for q, r in batches:
+        t = pipe.submit(q, r, False, 0, False)
+        if prev is not None:
+            got.append(pipe.result(prev)["score_map_ref_cross"])
+        prev = t
+    got.append(pipe.result(prev)["score_map_ref_cross"])
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i
+    got, prev = [], None
+    for (q, _), tok in zip(batches, toks):
+        t = pipe.submit_cached(q, tok)
+        if prev is not None:
+            got.append(pipe.result(prev)["score_map_ref_cross"])
+        prev = t
+    got.append(pipe.result(prev)["score_map_ref_cross"])
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i
+
+
 def test_layernorm_fold_matches_separate_layernorm_path():
     """ln_fold=1 (LayerNorm applied inside the consuming GEMM epilogue) and the default separate-LayerNorm path are two
     roundings of the same fp32 math: both within tolerance of the oracle; the fold must not be a silent no-op."""
