@@ -20,6 +20,11 @@ import subprocess
 import sys
 import time
 
+# One HIP stream per batch in flight and per encoder lane: with the runtime's default of 4 hardware queues, streams created later in a
+# process can share a queue and lose their overlap (measured: the cfg-4 leg ran 60.9 ms / step after the cfg-2 leg, 46.5 ms alone or with
+# 8 queues).  Must be set before the HIP runtime initialises; crossscore_amd/__init__.py sets the same default for library users.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
@@ -350,7 +355,7 @@ def main():
     cfg4 = None
     if not args.no_cfg4 and args.workload != "cfg4":
         w4 = Workload("cfg4", rank, dev, inflight=args.inflight)
-        steps4 = max(3, args.steps // 4)
+        steps4 = max(3, args.steps // 2)  # 2 batches in flight: the pipeline's fill and drain weigh on very short runs
         e4, _ = timed_steps(w4.step, sync, steps4, 2, dev)
         v4 = world * w4.B * steps4 / e4
         cfg4 = {"metric": w4.metric(), "value": v4, "unit": "query-images/sec", "steps": steps4, "warmup": 2,
