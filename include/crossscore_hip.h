@@ -8,8 +8,10 @@
  * reference code it replaces.  Plain pointers and sizes only: no torch / Python types cross this line.
  *
  * Ownership: the caller (PyTorch) owns every input / output / weight-source buffer; the library owns only its
- * packed fp16 weights and its workspace.  Threading: a handle is not thread-safe; one handle per process per
- * GPU (a handle may be re-created on another GPU of the process: launcher state is kept per device).  All work is enqueued on
+ * packed fp16 weights and its workspace.  Threading: a handle is not thread-safe and serves one forward at a time (its
+ * workspace is shared by consecutive calls); to keep several batches in flight create one handle per batch in flight (the
+ * Python side does: crossscore_amd/pipeline.py) -- handles are independent, also across GPUs of one process (launcher state
+ * is kept per device).  All work is enqueued on
  * the caller's hipStream_t (a forward that arrives on another stream than the previous one waits for it with an event: the
  * workspace is shared).  No entry point waits for the device or a stream except cs_finalize, cs_profile_* and cs_destroy:
  * the first forward of a new shape allocates (hipMalloc: position tables of a new patch grid, a larger workspace -- the old
