@@ -5,8 +5,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 src = os.path.join(REPO, "crossscore_amd", "csrc")
 out = "/tmp/libcs_ablate.so"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCS_ABLATE", "-Wno-unused-value",
-                       "-o", out] + [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "preprocess.hip")])
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCS_ABLATE", "-Wno-unused-value", "-I" + os.path.join(REPO, "include"),
+                       "-o", out] + [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip")])
 from crossscore_amd import _lib
 _lib.LIB_PATH = out
 sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -16,14 +16,15 @@ lib.cs_gemm_dbg_set.argtypes = [C.c_void_p]; lib.cs_gemm_dbg_set.restype = C.c_i
 dev = "cuda"
 MM = int(os.environ.get("CS_ABL_M", "65536"))
 shapes = {"qkv": (MM, 1152, 384, _lib.EPI_BIAS_F16), "outproj": (MM, 384, 384, _lib.EPI_RESID_F32),
-          "fc1": (MM, 1536, 384, _lib.EPI_BIAS_GELU_F16), "fc2": (MM, 384, 1536, _lib.EPI_RESID_F32)}
+          "fc1": (MM, 1536, 384, _lib.EPI_BIAS_GELU_F16), "fc2": (MM, 384, 1536, _lib.EPI_RESID_F32),
+          "qkvB": (MM, 2304, 768, _lib.EPI_BIAS_F16), "fc1B": (MM, 3072, 768, _lib.EPI_BIAS_GELU_F16), "fc2B": (MM, 768, 3072, _lib.EPI_RESID_F32)}
 only = os.environ.get("CS_ABL_SHAPES")
 if only: shapes = {k: v for k, v in shapes.items() if k in only.split(",")}
 dbg = torch.zeros(512 * 4 * 8, dtype=torch.int64, device=dev)
 assert lib.cs_gemm_dbg_set(C.c_void_p(dbg.data_ptr())) == 0
 names = ["vmcnt wait", "barrier", "prefetch+DMA issue", "LDS reads+MFMA", "epilogue step", "between slices", "slices", "total"]
 for sn, (M, N, K, epi) in shapes.items():
-    A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+    A = torch.randn(M, K, device=dev).half(); W = (torch.randn(N, K, device=dev) / K ** 0.5).half()
     b = torch.randn(N, device=dev)
     resid = torch.randn(M, N, device=dev) if epi == _lib.EPI_RESID_F32 else None
     o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.float16)
