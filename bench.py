@@ -261,13 +261,19 @@ class Workload:
             self.net.lanes = lanes
         if chunk > 0:
             self.net.enc_chunk_images = chunk
-        # `inflight` batches in flight (crossscore_amd/pipeline.py): replicas over the same parameters fed round-robin on their own streams,
-        # as the predict driver runs its batch loop; 1 = the plain forward on this stream
-        self.pipe = ForwardPipeline(self.net, depth=inflight, lanes=lanes if lanes > 0 else None)
-        self.inflight, self.lanes = inflight, self.net.lanes
+        self.inflight, self._lanes_arg, self.pipe = inflight, lanes, None
         lo = rank * self.B  # weak scaling: rank r scores global items [r*B, (r+1)*B)
         q, r = synth.make_inputs_shard(lo, lo + self.B, self.N, self.H, self.W, seed)
         self.tq, self.tr = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)  # inputs resident in HBM before timing
+
+    def start_pipeline(self):
+        """`inflight` batches in flight (crossscore_amd/pipeline.py): replicas over the same parameters fed round-robin on their own
+        streams, as the predict driver runs its batch loop; 1 = the plain forward on this stream."""
+        self.pipe = ForwardPipeline(self.net, depth=self.inflight, lanes=self._lanes_arg if self._lanes_arg > 0 else None)
+        self.lanes = self.net.lanes
+        # untimed: checks that the batches in flight really overlap on the chosen streams (hardware-queue placement, pipeline.py)
+        self.calibration = self.pipe.calibrate(self.tq, self.tr)
+        return self
 
     def step(self):
         """queues one batch; returns its ticket (pipe.result(ticket) orders the outputs on the current stream)"""
@@ -348,13 +354,23 @@ def main():
         raise SystemExit("--inflight must be >= 1")
     wl = Workload(args.workload, rank, dev, args.lanes, args.chunk, inflight=args.inflight)
     net, arch, B, N, H, W = wl.net, wl.arch, wl.B, wl.N, wl.H, wl.W
+    # ---- the same workload with ONE batch at a time (no pipeline; the library's two encoder lanes inside the forward): reported beside
+    #      the headline so that the gain of keeping batches in flight is visible in every line.  Timed first, on the module as a
+    #      plain `CrossScoreNet.forward` user finds it. ----
+    single = None
+    if wl.inflight > 1 and args.lanes == 0:
+        s_steps = max(3, args.steps // 2)
+        e1, _ = timed_steps(wl.direct, sync, s_steps, 2, dev)
+        single = {"value": world * B * s_steps / e1, "unit": "query-images/sec", "ms_per_step": 1e3 * e1 / s_steps, "steps": s_steps,
+                  "batches_in_flight": 1, "encoder_lanes": 2}
+    wl.start_pipeline()
     elapsed, ticket = timed_steps(wl.step, sync, args.steps, args.warmup, dev)
     score = wl.pipe.result(ticket)["score_map_ref_cross"]  # the output of the last timed step
 
     # ---- BASELINE.json configs[3] (the scaling configuration) on the same ranks: ViT-B/14, 5 refs, 16 items per GPU ----
     cfg4 = None
     if not args.no_cfg4 and args.workload != "cfg4":
-        w4 = Workload("cfg4", rank, dev, inflight=args.inflight)
+        w4 = Workload("cfg4", rank, dev, inflight=args.inflight).start_pipeline()
         steps4 = max(3, args.steps // 2)  # 2 batches in flight: the pipeline's fill and drain weigh on very short runs
         e4, _ = timed_steps(w4.step, sync, steps4, 2, dev)
         v4 = world * w4.B * steps4 / e4
@@ -396,12 +412,16 @@ def main():
             "config": {"workload": wl.describe(world),
                        "gflop_per_query": flops_q / 1e9, "parallelism": f"batch-shard x{world} (replicas, no data-path collective); per GPU {wl.inflight} batch(es) in flight x "
                                       f"{wl.lanes if wl.lanes else 2} encoder lane(s)",
-                       "batches_in_flight": wl.inflight},
+                       "batches_in_flight": wl.inflight,
+                       "stream_calibration_ms": {"one_at_a_time_one_lane": 1e3 * wl.calibration["serial_s"] if wl.calibration["serial_s"] else None,
+                                                 "in_flight_per_stream_set_tried": [round(1e3 * v, 3) for v in wl.calibration["in_flight_s"]]}},
             "whole_path": {"achieved_tflops": value * flops_q / 1e12 / world, "peak_tflops": PEAK_BF16_TFLOPS,
                            "frac": value * flops_q / 1e12 / world / PEAK_BF16_TFLOPS},
             "roofline": roofline_of(dom),
             "kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in x.items() if k not in ("flops", "bytes")} for x in rows],
         }
+        if single is not None:
+            result["one_batch_at_a_time"] = single
         if cfg4 is not None:
             result["scaling_cfg4"] = cfg4
         if args.kernels:

@@ -54,6 +54,7 @@ SYMBOLS = {
     "cs_op_score_to_rgb": (_i, [_vp, C.c_longlong, C.c_float, C.c_float, _vp, _vp, _vp]),
     "cs_op_preprocess_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _vp]),
     "cs_op_pack_f16": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "cs_op_streams_overlap": (_i, [_vp, _vp, _vp]),
     "cs_op_ln_fold_consts": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cs_gemm_column_tiles": (_i, [_i]),
     "cs_panel_supported": (_i, [_i, _i]),

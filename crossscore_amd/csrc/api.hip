@@ -37,6 +37,7 @@ hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh,
 hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
                                hipStream_t st);
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
+hipError_t cs_spin_launch(unsigned long long ticks, hipStream_t st);
 constexpr float LOG2E = 1.4426950408889634f;
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
@@ -125,7 +126,7 @@ struct cs_model {
   hipStream_t lane_st[CS_MAX_LANES] = {};
   hipStream_t last_stream = nullptr; hipEvent_t ev_done = nullptr;  // ordering of calls that arrive on different streams
   hipEvent_t ev_kv0 = nullptr, ev_kv1 = nullptr;                    // decoder: K/V projection on a side stream
-  hipEvent_t ev_fork = nullptr, ev_join[CS_MAX_LANES] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[CS_MAX_LANES] = {}, ev_stag[CS_MAX_LANES] = {};
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -383,7 +384,11 @@ void cs_destroy(cs_handle h) {
   if (h->ev_done) hipEventDestroy(h->ev_done);
   if (h->ev_kv0) hipEventDestroy(h->ev_kv0);
   if (h->ev_kv1) hipEventDestroy(h->ev_kv1);
-  for (int l = 0; l < CS_MAX_LANES; ++l) { if (h->lane_st[l]) hipStreamDestroy(h->lane_st[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
+  for (int l = 0; l < CS_MAX_LANES; ++l) {
+    if (h->lane_st[l]) hipStreamDestroy(h->lane_st[l]);
+    if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]);
+    if (h->ev_stag[l]) hipEventDestroy(h->ev_stag[l]);
+  }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   delete h;
@@ -576,6 +581,34 @@ size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W) {
   return make_plan(h, B, N, N, H, W, nullptr).total;
 }
 
+// Do kernels queued on streams a and b run side by side?  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues and
+// two streams on one queue serialise.  Probe: a one-wave kernel that idles for 40 us of wall clock on each stream, both released
+// by one event; elapsed (HIP events) ~40 us when they overlap, ~80 us when they do not.  Waits for both streams (set-up only).
+static int streams_overlap(hipStream_t a, hipStream_t b, bool* yes) {
+  const unsigned long long ticks = 4000;  // 40 us at 100 MHz
+  hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+  int rc = 0;
+  float best = 1e30f;
+  for (int rep = 0; rep < 3 && !rc; ++rep) {  // the first round also absorbs the kernel's load
+    hipError_t e = hipEventRecord(e0, a);
+    if (e == hipSuccess) e = hipStreamWaitEvent(b, e0, 0);
+    if (e == hipSuccess) e = cs_spin_launch(ticks, a);
+    if (e == hipSuccess) e = cs_spin_launch(ticks, b);
+    if (e == hipSuccess) e = hipEventRecord(eb, b);
+    if (e == hipSuccess) e = hipStreamWaitEvent(a, eb, 0);
+    if (e == hipSuccess) e = hipEventRecord(e1, a);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "stream overlap probe: %s", hipGetErrorString(e)); break; }
+    if (rep > 0 && ms < best) best = ms;
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(eb);
+  if (!rc) *yes = best < 0.065f;
+  return rc;
+}
+
 // mode 0: full forward (query + reference images); mode 1: query images + cached reference tokens (`ref_tokens`, fp16
 // [B][N][Np][C]); mode 2: encode `B` images as references into `tokens_out` (fp16 [B][Np][C]), no decoder.
 static int forward_body(cs_handle h, int mode, const float* query, const float* refs, const h16_t* ref_tokens, h16_t* tokens_out,
@@ -628,8 +661,27 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   hipStream_t lst[CS_MAX_LANES] = {st, st, st, st};
   if (NL >= 2) {
     for (int l = 0; l < NL; ++l) {
-      if (!h->lane_st[l]) HIPCHK(hipStreamCreateWithFlags(&h->lane_st[l], hipStreamNonBlocking));
+      if (!h->lane_st[l]) {
+        HIPCHK(hipStreamCreateWithFlags(&h->lane_st[l], hipStreamNonBlocking));
+        // a lane that shares a hardware queue with the previous lane would run after it, not beside it: probe, and take another
+        // stream until the two overlap (the rejected streams are released afterwards so that the runtime does not hand the same
+        // queue back at once); one-time set-up cost of ~0.3 ms per probe, with a wait for the probe kernels
+        if (l > 0) {
+          std::vector<hipStream_t> rejected;
+          for (int attempt = 0; attempt < 8; ++attempt) {
+            bool ok = false;
+            if (int r = streams_overlap(h->lane_st[l - 1], h->lane_st[l], &ok)) return r;
+            if (getenv("CS_DEBUG_STREAMS")) fprintf(stderr, "[crossscore_hip] lane %d stream candidate %d: %s\n", l, attempt, ok ? "overlaps" : "serialises");
+            if (ok) break;
+            rejected.push_back(h->lane_st[l]);
+            h->lane_st[l] = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&h->lane_st[l], hipStreamNonBlocking));
+          }
+          for (hipStream_t r : rejected) hipStreamDestroy(r);
+        }
+      }
       if (!h->ev_join[l]) HIPCHK(hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming));
+      if (!h->ev_stag[l]) HIPCHK(hipEventCreateWithFlags(&h->ev_stag[l], hipEventDisableTiming));
       lst[l] = h->lane_st[l];
     }
     if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -845,10 +897,18 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     const int rem = p.I % p.Ic;
     if (rem) { chunks.push_back({0, rem}); i0 = rem; }
     for (; i0 < p.I; i0 += p.Ic) chunks.push_back({i0, p.Ic});
+    // The lanes run the same kernel sequence: started together they stay in lockstep (panel beside panel, attention beside
+    // attention) and overlap nothing useful -- which is what happens whenever their streams sit on separate hardware queues.  Lane l
+    // therefore starts its first chunk when lane l-1 has finished its patch embedding (about half a layer's time): from then on one
+    // lane's QKV + attention runs beside the other's panel kernel.
     for (size_t base = 0; base < chunks.size(); base += NL)
       for (int stage = -1; stage <= c.enc_layers; ++stage)
-        for (int l = 0; l < NL && base + l < chunks.size(); ++l)
+        for (int l = 0; l < NL && base + l < chunks.size(); ++l) {
+          const bool stagger = base == 0 && stage == -1 && NL >= 2;
+          if (stagger && l > 0 && hipStreamWaitEvent(lst[l], h->ev_stag[l - 1], 0) != hipSuccess) return fail(CS_ERR_HIP, "lane stagger wait failed");
           enc_chunk(LL[l], l, chunks[base + l].first, chunks[base + l].second, stage);
+          if (stagger && hipEventRecord(h->ev_stag[l], lst[l]) != hipSuccess) return fail(CS_ERR_HIP, "lane stagger record failed");
+        }
   }
   if (int r = join(NL)) return r;
   if (int r = lanes_rc()) return r;
@@ -1048,6 +1108,14 @@ int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream) {
   if (!pe || !out || ph <= 0 || pw <= 0 || C <= 0 || gh <= 0 || gw <= 0) return fail(CS_ERR_BAD_ARG, "pe_bilinear: bad arguments");
   HIPCHK(cs_pe_bilinear_launch(pe, ph, pw, C, gh, gw, out, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_streams_overlap(cs_stream a, cs_stream b, int* overlap) {
+  if (!overlap || a == b) return fail(CS_ERR_BAD_ARG, "streams_overlap: two different streams and a result pointer are needed");
+  bool yes = false;
+  if (int r = streams_overlap((hipStream_t)a, (hipStream_t)b, &yes)) return r;
+  *overlap = yes ? 1 : 0;
   return 0;
 }
 

@@ -400,6 +400,12 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(CsAttnParams p, int h
   }
 }
 
+// One wave that does nothing for `ticks` of the 100 MHz wall clock: the probe of cs_streams_overlap (api.hip)
+__global__ void spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // per-image mean of the score map (feeds the CSV writer, score_summariser.py:180-192): one block per image
 __global__ __launch_bounds__(256) void score_mean_kernel(const float* __restrict__ score, int n, float* __restrict__ out) {
   __shared__ float part[4];
@@ -512,6 +518,11 @@ hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int 
     case 96: hipLaunchKernelGGL(attn_weights_kernel<96>, grid, dim3(256), 0, st, *p, head, out); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t cs_spin_launch(unsigned long long ticks, hipStream_t st) {
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, ticks);
   return hipGetLastError();
 }
 

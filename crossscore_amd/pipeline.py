@@ -62,8 +62,86 @@ class ForwardPipeline:
                 net.lanes = lanes
                 net._mark_dirty()
             self.nets = [net] + [_replica(net, lanes) for _ in range(depth - 1)]
-            self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+            self.streams = self._overlapping_streams(depth)
+            # new weights loaded into `net` land in the shared tensors: the replicas must re-pack their fp16 images too
+            # (build the pipeline after net.to(device); moving the module afterwards would break the sharing)
+            reps = self.nets[1:]
+
+            def _replicas_dirty(module, incompatible):
+                for r in reps:
+                    r._mark_dirty()
+
+            net.register_load_state_dict_post_hook(_replicas_dirty)
         self._n = 0
+
+    def _overlapping_streams(self, n: int) -> List[Any]:
+        """n streams on which kernels really run side by side.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
+        queues and two streams that land on one queue serialise (the replicas would then run one after another: measured 9.0
+        instead of 6.7 ms per cfg-2 batch); which streams collide depends on what else the process created before.  Each new
+        stream is probed against the ones already chosen (cs_op_streams_overlap: two 40-us idle kernels) and replaced until it
+        overlaps with all of them (8 candidates at most)."""
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            chosen = [torch.cuda.Stream(device=self.device)]
+            rejected = []  # kept alive until the end: a released pool stream would be handed out again
+            while len(chosen) < n:
+                cand = torch.cuda.Stream(device=self.device)
+                for _ in range(8):
+                    ok = True
+                    for c in chosen:
+                        flag = C.c_int(0)
+                        _lib.check(lib.cs_op_streams_overlap(C.c_void_p(c.cuda_stream), C.c_void_p(cand.cuda_stream), C.byref(flag)))
+                        ok = ok and bool(flag.value)
+                    if ok:
+                        break
+                    rejected.append(cand)
+                    cand = torch.cuda.Stream(device=self.device)
+                chosen.append(cand)
+        return chosen
+
+    def calibrate(self, query_img, ref_cross_imgs, tries: int = 4, steps: int = 6) -> Dict[str, Any]:
+        """The HIP runtime multiplexes streams onto a few hardware queues, and two streams that land on one queue serialise: the
+        replicas then run one after another (measured 9.0 instead of 6.7 ms per cfg-2 batch); which streams collide depends on
+        what else the process created before.  This times `steps` batches one at a time on replica 0, then in flight on up to
+        `tries` fresh sets of streams, and keeps the first set that beats the serial time by 15 % (else the fastest seen).  Call
+        it once, outside any timed region, with inputs of the working shape; returns what it measured."""
+        if self.depth == 1:
+            return {"serial_s": None, "in_flight_s": []}
+        import time
+
+        def in_flight(n):
+            last = None
+            for _ in range(n):
+                last = self.submit(query_img, ref_cross_imgs, False, 0, False)
+            self.result(last)
+            torch.cuda.synchronize(self.device)
+
+        in_flight(2 * self.depth)  # handles, workspaces and tables exist from here on
+        t0 = time.perf_counter()
+        with torch.cuda.stream(self.streams[0]):
+            for _ in range(steps):
+                self.nets[0](query_img, ref_cross_imgs, False, 0, False)
+        torch.cuda.synchronize(self.device)
+        serial = (time.perf_counter() - t0) / steps
+        seen, best = [], None
+        for attempt in range(max(1, tries)):
+            if attempt:
+                self.streams = self._overlapping_streams(self.depth)
+                in_flight(self.depth)
+            t0 = time.perf_counter()
+            in_flight(steps)
+            dt = (time.perf_counter() - t0) / steps
+            seen.append(dt)
+            if best is None or dt < best[0]:
+                best = (dt, self.streams)
+            if dt < 0.85 * serial:
+                break
+        self.streams = best[1]
+        return {"serial_s": serial, "in_flight_s": seen}
 
     def _run(self, method: str, args, kwargs) -> Ticket:
         i = self._n % self.depth

@@ -13,7 +13,9 @@
  * Python side does: crossscore_amd/pipeline.py) -- handles are independent, also across GPUs of one process (launcher state
  * is kept per device).  All work is enqueued on
  * the caller's hipStream_t (a forward that arrives on another stream than the previous one waits for it with an event: the
- * workspace is shared).  No entry point waits for the device or a stream except cs_finalize, cs_profile_* and cs_destroy:
+ * workspace is shared).  No entry point waits for the device or a stream except cs_finalize, cs_profile_*, cs_destroy,
+ * cs_op_streams_overlap and the one-time creation of the encoder lanes' streams in a handle's first forward (which probes that
+ * the lanes' streams overlap, ~1 ms):
  * the first forward of a new shape allocates (hipMalloc: position tables of a new patch grid, a larger workspace -- the old
  * one is retired behind an event and freed later), fills what it allocated on the caller's stream, and never overwrites or
  * frees memory that queued work may still read; calls of a shape seen before allocate nothing.  (Only a 17th distinct patch
@@ -156,6 +158,9 @@ int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
 /* fp32 [rows][K] -> fp16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
  * rows of a projection, LayerNorm gamma into its columns */
+/* 1 in *overlap when kernels queued on the two streams run side by side, 0 when the runtime serialises them (streams that share a
+ * hardware queue: GPU_MAX_HW_QUEUES).  Runs two 40-us idle kernels and waits for them: a set-up helper, not for hot loops. */
+int cs_op_streams_overlap(cs_stream a, cs_stream b, int* overlap);
 int cs_op_pack_f16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
                     cs_stream stream);
 /* LayerNorm fold constants of a projection: s[n] = sum_k packed W'[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] */

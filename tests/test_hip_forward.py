@@ -337,6 +337,14 @@ def test_batches_in_flight_are_bit_identical_to_one_at_a_time(depth, backbone, H
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(zip(got, want)):
         assert torch.equal(a, b), i
+    if depth > 1:  # new weights loaded into the module reach every replica (shared tensors, handles re-packed)
+        sd2 = synth.make_state_dict(arch, 6)
+        net.load_numpy_state_dict(sd2)
+        q, r = batches[0]
+        want2 = net(q, r, False, 0, False)["score_map_ref_cross"].clone()
+        assert not torch.equal(want2, want[0])
+        for _ in range(depth):
+            assert torch.equal(pipe.result(pipe.submit(q, r, False, 0, False))["score_map_ref_cross"], want2)
 
 
 def test_layernorm_fold_matches_separate_layernorm_path():

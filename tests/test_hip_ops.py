@@ -448,3 +448,20 @@ def test_pe_bilinear(gh, gw):
     ref = orc.bilinear_resize_grid_align_corners(pe.cpu(), gh, gw).reshape(gh * gw, Cc)
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() < 3e-5
+
+
+def test_streams_overlap_probe():
+    """cs_op_streams_overlap: the probe behind the choice of lane / pipeline streams.  A stream never overlaps with work that must wait for
+    it, so probing a stream against itself is refused; among a handful of fresh streams at least one pair overlaps (8 hardware queues)."""
+    import ctypes as C
+
+    lib = _lib.load()
+    s = [torch.cuda.Stream() for _ in range(4)]
+    flag = C.c_int(-1)
+    assert lib.cs_op_streams_overlap(C.c_void_p(s[0].cuda_stream), C.c_void_p(s[0].cuda_stream), C.byref(flag)) != 0
+    seen = []
+    for i in range(1, 4):
+        _lib.check(lib.cs_op_streams_overlap(C.c_void_p(s[0].cuda_stream), C.c_void_p(s[i].cuda_stream), C.byref(flag)))
+        assert flag.value in (0, 1)
+        seen.append(flag.value)
+    assert any(seen), seen

@@ -6,7 +6,7 @@ import bench
 dev = torch.device("cuda:0")
 sync = lambda: torch.cuda.synchronize(dev)
 def run(name, steps=8, warm=3, inflight=2):
-    w = bench.Workload(name, 0, dev, inflight=inflight)
+    w = bench.Workload(name, 0, dev, inflight=inflight).start_pipeline()
     e, _ = bench.timed_steps(w.step, sync, steps, warm, dev)
     return w, 1e3 * e / steps
 mode = sys.argv[1]
