@@ -126,6 +126,8 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
         if cache is None:
             pending = prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool) if batch_idx + 1 < len(batches) else None
             batch = load_batch(its, stage, zero_ref, decoded)
+            if batch_idx == 0 and len(batches) >= 16:  # a long run: make sure the batches in flight really overlap (pipeline.py)
+                pipe.calibrate(batch["query/img"], batch["reference/cross/imgs"])
             ticket = pipe.submit(batch["query/img"], batch["reference/cross/imgs"], need_w, head_id, False)
         else:
             batch, size = load_query_batch(its, stage, decoded)
