@@ -37,7 +37,7 @@ hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh,
 hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
                                hipStream_t st);
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
-hipError_t cs_spin_launch(unsigned long long ticks, hipStream_t st);
+hipError_t cs_spin_launch(unsigned long long ticks, int blocks, int lds_bytes, hipStream_t st);
 constexpr float LOG2E = 1.4426950408889634f;
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
 hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
@@ -581,31 +581,37 @@ size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W) {
   return make_plan(h, B, N, N, H, W, nullptr).total;
 }
 
-// Do kernels queued on streams a and b run side by side?  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues and
-// two streams on one queue serialise.  Probe: a one-wave kernel that idles for 40 us of wall clock on each stream, both released
-// by one event; elapsed (HIP events) ~40 us when they overlap, ~80 us when they do not.  Waits for both streams (set-up only).
+// Do kernels queued on streams a and b run side by side?  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues,
+// and hardware queues onto the pipes of the compute micro-engine.  Two streams on one queue serialise outright; two queues on one
+// pipe are dispatched one kernel at a time, so a grid that does not fit the chip at once holds back the other stream's kernel until
+// its last round (a two-lane forward then runs at the one-lane time although tiny kernels on the two streams overlap).  Probe, both
+// released by one event: on `a` a grid of 4 workgroups per CU that fit two to a CU (64 KiB of LDS each) and idle 60 us each, i.e.
+// two rounds; on `b` one wave that idles 2 us.  `b` finishes within a few microseconds when the two dispatch side by side and
+// after >= 60 us when it has to wait for a's second round.  Waits for both streams (set-up only, ~0.4 ms).
 static int streams_overlap(hipStream_t a, hipStream_t b, bool* yes) {
-  const unsigned long long ticks = 4000;  // 40 us at 100 MHz
-  hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+  int dev = 0, cus = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  hipEvent_t e0 = nullptr, eb = nullptr, ea = nullptr;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&eb)); HIPCHK(hipEventCreate(&ea));
   int rc = 0;
   float best = 1e30f;
   for (int rep = 0; rep < 3 && !rc; ++rep) {  // the first round also absorbs the kernel's load
     hipError_t e = hipEventRecord(e0, a);
     if (e == hipSuccess) e = hipStreamWaitEvent(b, e0, 0);
-    if (e == hipSuccess) e = cs_spin_launch(ticks, a);
-    if (e == hipSuccess) e = cs_spin_launch(ticks, b);
+    if (e == hipSuccess) e = cs_spin_launch(6000, 4 * cus, 64 * 1024, a);
+    if (e == hipSuccess) e = cs_spin_launch(200, 1, 0, b);
     if (e == hipSuccess) e = hipEventRecord(eb, b);
-    if (e == hipSuccess) e = hipStreamWaitEvent(a, eb, 0);
-    if (e == hipSuccess) e = hipEventRecord(e1, a);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventRecord(ea, a);
+    if (e == hipSuccess) e = hipEventSynchronize(ea);
+    if (e == hipSuccess) e = hipEventSynchronize(eb);
     float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, eb);
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "stream overlap probe: %s", hipGetErrorString(e)); break; }
     if (rep > 0 && ms < best) best = ms;
   }
-  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(eb);
-  if (!rc) *yes = best < 0.065f;
+  hipEventDestroy(e0); hipEventDestroy(eb); hipEventDestroy(ea);
+  if (!rc) *yes = best < 0.040f;
   return rc;
 }
 

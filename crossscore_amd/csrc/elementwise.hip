@@ -400,8 +400,11 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(CsAttnParams p, int h
   }
 }
 
-// One wave that does nothing for `ticks` of the 100 MHz wall clock: the probe of cs_streams_overlap (api.hip)
+// One wave per workgroup that does nothing for `ticks` of the 100 MHz wall clock: the probes of streams_overlap (api.hip).  Launched
+// with dynamic LDS it also limits how many workgroups a CU holds, which is what makes the dispatch of a large grid last.
 __global__ void spin_kernel(unsigned long long ticks) {
+  extern __shared__ char spin_lds[];
+  if (ticks == ~0ull) spin_lds[threadIdx.x] = 0;  // never true: keeps the allocation
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
@@ -521,8 +524,16 @@ hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int 
   return hipGetLastError();
 }
 
-hipError_t cs_spin_launch(unsigned long long ticks, hipStream_t st) {
-  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, ticks);
+hipError_t cs_spin_launch(unsigned long long ticks, int blocks, int lds_bytes, hipStream_t st) {
+  static bool attr_done[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  if (lds_bytes > 48 * 1024 && !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(64), lds_bytes, st, ticks);
   return hipGetLastError();
 }
 

@@ -78,7 +78,7 @@ class ForwardPipeline:
         """n streams on which kernels really run side by side.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
         queues and two streams that land on one queue serialise (the replicas would then run one after another: measured 9.0
         instead of 6.7 ms per cfg-2 batch); which streams collide depends on what else the process created before.  Each new
-        stream is probed against the ones already chosen (cs_op_streams_overlap: two 40-us idle kernels) and replaced until it
+        stream is probed against the ones already chosen (cs_op_streams_overlap: a large idle grid beside one idle wave) and replaced until it
         overlaps with all of them (8 candidates at most)."""
         import ctypes as C
 

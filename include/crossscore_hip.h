@@ -159,7 +159,8 @@ int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, fl
 /* fp32 [rows][K] -> fp16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
  * rows of a projection, LayerNorm gamma into its columns */
 /* 1 in *overlap when kernels queued on the two streams run side by side, 0 when the runtime serialises them (streams that share a
- * hardware queue: GPU_MAX_HW_QUEUES).  Runs two 40-us idle kernels and waits for them: a set-up helper, not for hot loops. */
+ * hardware queue, or hardware queues that share a dispatch pipe: a large grid on `a` then holds back a kernel on `b`).  Runs a two-round
+ * grid of idle workgroups on `a` beside one idle wave on `b` and waits for them (~0.4 ms): a set-up helper, not for hot loops. */
 int cs_op_streams_overlap(cs_stream a, cs_stream b, int* overlap);
 int cs_op_pack_f16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
                     cs_stream stream);
