@@ -101,6 +101,17 @@ def test_forward_refuses_cpu_tensors():
         net(q, None, False, 0, False)
 
 
+def test_pipeline_refuses_a_cpu_module_and_bad_depth():
+    """crossscore_amd.pipeline.ForwardPipeline: batches in flight need the module on a GPU (no CPU fallback) and a depth >= 1."""
+    from crossscore_amd.pipeline import ForwardPipeline
+
+    net = CrossScoreNet(model_config(**{"backbone.from_pretrained": "synthetic/dinov2-tiny"}))
+    with pytest.raises(RuntimeError):
+        ForwardPipeline(net, depth=2)
+    with pytest.raises(ValueError):
+        ForwardPipeline(net, depth=0)
+
+
 def test_invalid_metric_config_raises_like_reference():
     with pytest.raises(ValueError):
         CrossScoreNet(model_config(**{"predict.metric.type": "psnr"}))
@@ -229,3 +240,7 @@ def test_committed_bench_line_follows_the_contract():
     # the eager-reference legs and the scaling configuration ride in the same line
     assert set(r["eager_baseline"]) >= {"fp32_sdpa", "fp16_autocast_sdpa"} and set(r["target_10x_met"]) == set(r["eager_baseline"])
     assert r["scaling_cfg4"]["value"] > 0 and "traffic_source" in rf
+    # batches in flight: the line says how many, what the stream calibration saw, and what one batch at a time gives
+    assert r["config"]["batches_in_flight"] >= 1 and "in flight" in r["config"]["parallelism"]
+    if r["config"]["batches_in_flight"] > 1:
+        assert r["one_batch_at_a_time"]["value"] > 0 and r["config"]["stream_calibration_ms"]["in_flight_per_stream_set_tried"]
