@@ -45,7 +45,7 @@ class ForwardPipeline:
     def __init__(self, net: CrossScoreNet, depth: int = 2, lanes: Optional[int] = None):
         """depth 1 is the plain forward on the caller's stream.  With depth > 1 each replica runs ONE encoder lane by default: the
         batches in flight supply the kernel-level concurrency the two lanes of a single forward otherwise provide (measured: 2 in
-        flight x 1 lane beats 1 x 2 and 2 x 2, DESIGN.md 6)."""
+        flight x 1 lane beats 1 x 2 and 2 x 2, DESIGN.md 4)."""
         if depth < 1:
             raise ValueError("ForwardPipeline: depth must be >= 1")
         dev = next(net.parameters()).device
