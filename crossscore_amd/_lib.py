@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libcrossscore_hip.so")
 CS_OK, CS_ERR_BAD_ARG, CS_ERR_UNSUPPORTED, CS_ERR_STATE, CS_ERR_HIP = range(5)
 
 # CsEpilogue (csrc/cs_common.h)
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2  # cs_set_weight_typed
 (EPI_BIAS_F16, EPI_BIAS_GELU_F16, EPI_BIAS_RELU_F16, EPI_BIAS_LEAKY_F16, EPI_RESID_F32, EPI_PATCH_F32, EPI_HEAD_SCORE,
  EPI_LN_F16, EPI_LN_GELU_F16, EPI_RESID_F32_LN) = range(10)
 
@@ -31,6 +32,7 @@ SYMBOLS = {
     "cs_destroy": (None, [_vp]),
     "cs_last_error": (C.c_char_p, []),
     "cs_set_weight": (_i, [_vp, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64)]),
+    "cs_set_weight_typed": (_i, [_vp, C.c_char_p, _vp, _i, _i, _i, C.POINTER(C.c_int64)]),
     "cs_num_weights": (_i, [_vp]),
     "cs_weight_name": (C.c_char_p, [_vp, _i]),
     "cs_finalize": (_i, [_vp]),

@@ -397,19 +397,42 @@ void cs_destroy(cs_handle h) {
 int cs_num_weights(cs_handle h) { return h ? (int)h->names.size() : 0; }
 const char* cs_weight_name(cs_handle h, int i) { return (h && i >= 0 && i < (int)h->names.size()) ? h->names[i].c_str() : nullptr; }
 
-int cs_set_weight(cs_handle h, const char* name, const float* data, int is_device, int ndim, const int64_t* shape) {
+// dtype: CS_DTYPE_F32 / F16 / BF16 of the SOURCE buffer; the handle keeps fp32 copies (exact for all three) and packs its fp16
+// operand images from those in cs_finalize
+int cs_set_weight_typed(cs_handle h, const char* name, const void* data, int is_device, int dtype, int ndim, const int64_t* shape) {
   if (!h || !name || !data || ndim < 1 || !shape) return fail(CS_ERR_BAD_ARG, "cs_set_weight: null argument");
+  if (dtype != CS_DTYPE_F32 && dtype != CS_DTYPE_F16 && dtype != CS_DTYPE_BF16) return fail(CS_ERR_BAD_ARG, "cs_set_weight: unknown dtype %d", dtype);
   if (h->finalized) return fail(CS_ERR_STATE, "cs_set_weight after cs_finalize");
   if (std::find(h->names.begin(), h->names.end(), name) == h->names.end()) return fail(CS_ERR_BAD_ARG, "unexpected key %s", name);
   Tensor t;
   t.numel = 1;
   for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return fail(CS_ERR_BAD_ARG, "%s: bad shape", name); t.shape.push_back(shape[i]); t.numel *= (size_t)shape[i]; }
   auto it = h->w.find(name);
-  if (it != h->w.end() && it->second.d) { hipFree(it->second.d); }
+  if (it != h->w.end() && it->second.d) { hipFree(it->second.d); it->second.d = nullptr; }
   HIPCHK(hipMalloc(&t.d, t.numel * sizeof(float)));
-  HIPCHK(hipMemcpy(t.d, data, t.numel * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  if (dtype == CS_DTYPE_F32) {
+    HIPCHK(hipMemcpy(t.d, data, t.numel * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  } else {
+    // 16-bit sources are widened on the host (checkpoint loading is set-up work; a device source is read back first)
+    std::vector<uint16_t> src(t.numel);
+    HIPCHK(hipMemcpy(src.data(), data, t.numel * sizeof(uint16_t), is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+    std::vector<float> wide(t.numel);
+    for (size_t i = 0; i < t.numel; ++i) {
+      if (dtype == CS_DTYPE_BF16) {
+        const uint32_t u = (uint32_t)src[i] << 16;
+        std::memcpy(&wide[i], &u, 4);
+      } else {
+        wide[i] = (float)__builtin_bit_cast(_Float16, src[i]);  // host side: IEEE half -> float
+      }
+    }
+    HIPCHK(hipMemcpy(t.d, wide.data(), t.numel * sizeof(float), hipMemcpyHostToDevice));
+  }
   h->w[name] = t;
   return 0;
+}
+
+int cs_set_weight(cs_handle h, const char* name, const float* data, int is_device, int ndim, const int64_t* shape) {
+  return cs_set_weight_typed(h, name, data, is_device, CS_DTYPE_F32, ndim, shape);
 }
 
 int cs_finalize(cs_handle h) {

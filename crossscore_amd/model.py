@@ -111,6 +111,11 @@ class CrossScoreNet(torch.nn.Module):
     def _mark_dirty(self):
         self._dirty = True
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .half() / .bfloat16() replace the parameter tensors: the handle's packed copies are stale afterwards
+        self._mark_dirty()
+        return super()._apply(fn, *args, **kwargs)
+
     def load_numpy_state_dict(self, sd: Dict[str, np.ndarray]) -> None:
         self.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
 
@@ -143,10 +148,12 @@ class CrossScoreNet(torch.nn.Module):
                 msg = _lib.last_error()
                 raise NotImplementedError(msg) if "not in" in msg else ValueError(msg)
             try:
+                kinds = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
                 for name, t in self.state_dict().items():
-                    t = t.detach().to(torch.float32).contiguous()
+                    t = t.detach()
+                    t = (t if t.dtype in kinds else t.to(torch.float32)).contiguous()  # net.half() / net.bfloat16() modules load as they are
                     shape = (C.c_int64 * t.dim())(*t.shape)
-                    _lib.check(lib.cs_set_weight(h, name.encode(), C.c_void_p(t.data_ptr()), int(t.is_cuda), t.dim(), shape))
+                    _lib.check(lib.cs_set_weight_typed(h, name.encode(), C.c_void_p(t.data_ptr()), int(t.is_cuda), kinds[t.dtype], t.dim(), shape))
                 _lib.check(lib.cs_finalize(h))
             except Exception:
                 lib.cs_destroy(h)

@@ -20,8 +20,8 @@
  * one is retired behind an event and freed later), fills what it allocated on the caller's stream, and never overwrites or
  * frees memory that queued work may still read; calls of a shape seen before allocate nothing.  (Only a 17th distinct patch
  * grid, or a 65th distinct resize geometry in cs_preprocess_u8, drops the table cache behind a device synchronisation.)
- * Weights are fp32 at this boundary (cs_set_weight): the reference checkpoint stores fp32, and the library
- * packs its own 16-bit copies in cs_finalize.  Every function returning int returns 0 on success; on failure
+ * Weights are fp32 at this boundary (cs_set_weight; cs_set_weight_typed also takes fp16 / bf16 sources and widens them): the
+ * reference checkpoint stores fp32, and the library packs its own 16-bit copies in cs_finalize.  Every function returning int returns 0 on success; on failure
  * cs_last_error() describes it (CS_ERR_* below) and nothing was launched on the bad-argument paths.
  */
 #ifndef CROSSSCORE_HIP_H
@@ -80,6 +80,10 @@ const char* cs_last_error(void);
 /* Replaces load_state_dict for one tensor: `name` is the checkpoint key without the "model." prefix (ckpt layout:
  * SURVEY.md 8b), `data` fp32, row-major, host or device memory (is_device), `shape[ndim]` as in the state dict. */
 int cs_set_weight(cs_handle h, const char* name, const float* data, int is_device, int ndim, const int64_t* shape);
+/* The same for a source tensor of another storage type (SURVEY.md 8b's `dtype` argument): a half- or bfloat16-precision checkpoint is
+ * widened to fp32 (exactly) on the way in. */
+enum { CS_DTYPE_F32 = 0, CS_DTYPE_F16 = 1, CS_DTYPE_BF16 = 2 };
+int cs_set_weight_typed(cs_handle h, const char* name, const void* data, int is_device, int dtype, int ndim, const int64_t* shape);
 /* Number of tensors cs_finalize expects and the i-th expected name (for loaders / strict checking). */
 int cs_num_weights(cs_handle h);
 const char* cs_weight_name(cs_handle h, int i);

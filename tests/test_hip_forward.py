@@ -347,6 +347,28 @@ def test_batches_in_flight_are_bit_identical_to_one_at_a_time(depth, backbone, H
             assert torch.equal(pipe.result(pipe.submit(q, r, False, 0, False))["score_map_ref_cross"], want2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_precision_checkpoints_load_through_the_typed_entry(dtype):
+    """cs_set_weight_typed (SURVEY.md 8b's dtype argument): a module converted with .half() / .bfloat16() hands its 16-bit tensors to the
+    library as they are; the result equals the fp32 module loaded with the same (rounded) values, bit for bit."""
+    net, arch, sd = _net(TINY, 3)
+    q, r = synth.make_inputs(2, 2, 70, 98, 3)
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    rounded = {k: torch.from_numpy(v).to(dtype).to(torch.float32) for k, v in sd.items()}
+    net.load_state_dict(rounded, strict=True)
+    want = net(tq, tr, False, 0, False)["score_map_ref_cross"].clone()
+    net16 = CrossScoreNet(model_config(**{"backbone.from_pretrained": TINY}))
+    net16.load_state_dict(rounded, strict=True)
+    net16 = net16.cuda().to(dtype)
+    assert next(net16.parameters()).dtype == dtype
+    got = net16(tq, tr, False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # converting the module after its handle was built re-packs the weights
+    net16 = net16.float()
+    assert torch.equal(net16(tq, tr, False, 0, False)["score_map_ref_cross"], want)
+
+
 def test_layernorm_fold_matches_separate_layernorm_path():
     """ln_fold=1 (LayerNorm applied inside the consuming GEMM epilogue) and the default separate-LayerNorm path are two
     roundings of the same fp32 math: both within tolerance of the oracle; the fold must not be a silent no-op."""
