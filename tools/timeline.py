@@ -4,11 +4,19 @@ import collections, csv, glob, os, sys
 fn = glob.glob(os.path.join(sys.argv[1], "**/*kernel_trace.csv"), recursive=True)[0]
 rows = [r for r in csv.DictReader(open(fn))]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-# steady state: from the end of the 6th to the end of the 14th regression-head GEMM (one per forward): back-to-back timed steps
+# steady state: the longest run of back-to-back forwards (one regression-head GEMM each, less than 1.6x the median spacing apart) -- the
+# timed region of the bench; calibration passes, the one-batch-at-a-time leg and the per-kernel pass are other, shorter runs
 heads = sorted(e for s, e, n in ev if "cs_gemm_kernel<6," in n or "cs_gemm_kernel<(CsEpilogue)6" in n)
-if len(heads) < 15: raise SystemExit(f"only {len(heads)} forwards in the trace")
-lo, hi = heads[5], heads[13]
-steps = 8
+if len(heads) < 8: raise SystemExit(f"only {len(heads)} forwards in the trace")
+gaps = [b - a for a, b in zip(heads, heads[1:])]
+med = sorted(gaps)[len(gaps) // 2]
+best, cur = (0, 0), 0
+for i, g in enumerate(gaps + [10 ** 18]):
+    if g > 1.6 * med:
+        if i - cur > best[1] - best[0]: best = (cur, i)
+        cur = i + 1
+lo, hi = heads[best[0] + 1], heads[best[1] - 1]
+steps = best[1] - best[0] - 2
 pts = []
 for s, e, n in ev:
     s2, e2 = max(s, lo), min(e, hi)
