@@ -59,6 +59,7 @@ SYMBOLS = {
     "cs_op_streams_overlap": (_i, [_vp, _vp, _vp]),
     "cs_op_ln_fold_consts": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cs_gemm_column_tiles": (_i, [_i]),
+    "cs_gemm256_enable": (None, [_i]),
     "cs_panel_supported": (_i, [_i, _i]),
     "cs_panel_image_bytes": (_sz, [_i]),
     "cs_op_panel_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

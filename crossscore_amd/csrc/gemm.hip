@@ -777,7 +777,12 @@ extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
 extern "C" int cs_gemm_dbg_set(long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cs_dbg), &buf, sizeof(buf)); }
 #endif
 
+extern "C" int cs_gemm256_supported(const CsGemmParams* p, int epi);
+extern "C" hipError_t cs_gemm256_launch(const CsGemmParams* p, int epi, int bf16, hipStream_t st);
+
 extern "C" hipError_t cs_gemm_launch(const CsGemmParams* p0, int epi, hipStream_t stream) {
+  // K >= 512 with whole 256-column tiles (the ViT-B projections, the decoder's K/V projection at C = 768): the large-tile kernel
+  if (cs_gemm256_supported(p0, epi)) return cs_gemm256_launch(p0, epi, 0, stream);
   CsGemmParams pp = *p0;
 #ifdef CS_ABLATE
   if (const char* e = getenv("CS_GEMM_ABLATE")) pp.ablate = atoi(e);

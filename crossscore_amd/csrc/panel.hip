@@ -88,6 +88,22 @@ __device__ __forceinline__ float gelu_erf1(float x) {
   return x * fmaf(c, q, 0.5f);
 }
 
+// the same fit for two values at once, cut in two halves (5 + 6 instructions per value) that sit in consecutive MFMA gaps
+__device__ __forceinline__ void gelu2_head(float x0, float x1, float (&c)[2], float (&t)[2], float (&q)[2]) {
+  c[0] = __builtin_amdgcn_fmed3f(x0, -4.2f, 4.2f); c[1] = __builtin_amdgcn_fmed3f(x1, -4.2f, 4.2f);
+  t[0] = c[0] * c[0]; t[1] = c[1] * c[1];
+  q[0] = fmaf(-9.6129670387e-10f, t[0], 8.3297297734e-08f); q[1] = fmaf(-9.6129670387e-10f, t[1], 8.3297297734e-08f);
+  q[0] = fmaf(q[0], t[0], -3.1398569575e-06f); q[1] = fmaf(q[1], t[1], -3.1398569575e-06f);
+  q[0] = fmaf(q[0], t[0], 6.8266010957e-05f); q[1] = fmaf(q[1], t[1], 6.8266010957e-05f);
+}
+__device__ __forceinline__ void gelu2_tail(float x0, float x1, const float (&c)[2], const float (&t)[2], const float (&q)[2], float& y0, float& y1) {
+  float a = fmaf(q[0], t[0], -9.6075936689e-04f), b = fmaf(q[1], t[1], -9.6075936689e-04f);
+  a = fmaf(a, t[0], 9.3374518106e-03f); b = fmaf(b, t[1], 9.3374518106e-03f);
+  a = fmaf(a, t[0], -6.5599355124e-02f); b = fmaf(b, t[1], -6.5599355124e-02f);
+  a = fmaf(a, t[0], 3.9850871469e-01f); b = fmaf(b, t[1], 3.9850871469e-01f);
+  y0 = x0 * fmaf(c[0], a, 0.5f); y1 = x1 * fmaf(c[1], b, 0.5f);
+}
+
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4_t pack8(const float (&v)[8]) {
   return u32x4_t{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7])};
@@ -266,6 +282,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     const unsigned bias_addr = lds0 + LDS_B1 + 64 * h;
     const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
     float gv[8];
+    [[maybe_unused]] float g2c[2], g2t[2], g2q[2];
     f32x4_t bb[4];
     auto read_bias = [&](int t) {  // this lane's 16 hidden units of slice t: 32 t + 16 h + r
       const unsigned a = bias_addr + t * 128;
@@ -273,7 +290,9 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     };
     // One tick: per fragment m [counted wait for it; MFMA; read of fragment m + 6 (of the next unit from m = 18 on); a GELU value]; the
     // transition to the next unit sits before fragment 18, when all 24 fragments of this unit are in registers or behind it in the LDS queue.
-    auto tick = [&](auto FC1_, f32x16_t& acc, const f32x16_t& act, int hb_slot, int t_next) {
+    // hb_write = false for tick 0: its "previous slice" does not exist, and hb slot 1 lies inside the norm2 hand-off region (LDS_XF), which
+    // the sibling pairs' A waves may still be reading behind H3 -- nothing may be written there before the first tick's transition
+    auto tick = [&](auto FC1_, f32x16_t& acc, const f32x16_t& act, int hb_slot, int t_next, bool hb_write) {
       constexpr bool FC1 = decltype(FC1_)::value;
       sfor<24>([&](auto M_) {
         constexpr int M = decltype(M_)::value;
@@ -297,9 +316,21 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           if constexpr (M < 18) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
           else lds_read1<(M - 18) * FRAG>(cur, w[M % 6]);
         }
+#ifdef CS_PANEL_GELU2
+        // two values per pair of gaps, their Horner chains interleaved (a lone chain is 11 DEPENDENT VALU instructions: dependent issue
+        // costs ~1.7x independent issue, and the A wave's stream is the tick's critical path)
+        if constexpr (M < 16 && (M & 1) == 0) {
+          if constexpr (ABL & 1) { gv[M & 7] = act[M]; gv[(M + 1) & 7] = act[M + 1]; }
+          else gelu2_head(act[M], act[M + 1], g2c, g2t, g2q);
+        }
+        if constexpr (M < 16 && (M & 1) == 1) {
+          if constexpr (!(ABL & 1)) gelu2_tail(act[M - 1], act[M], g2c, g2t, g2q, gv[(M - 1) & 7], gv[M & 7]);
+        }
+#else
         if constexpr (M < 16) gv[M & 7] = (ABL & 1) ? act[M] : gelu_erf1(act[M]);
-        if constexpr (M == 7) lds_write16<0>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv));
-        if constexpr (M == 15) lds_write16<FRAG>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv));
+#endif
+        if constexpr (M == 7) { if (hb_write) lds_write16<0>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv)); }
+        if constexpr (M == 15) { if (hb_write) lds_write16<FRAG>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv)); }
         CS_SB();
       });
     };
@@ -308,13 +339,13 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acO[i] = 0.f;  // tick 0 "activates" this (slice -1: never read by the partner)
     for (int t = 0; t < NSL; t += 2) {
-      tick(std::true_type{}, acE, acO, 1, t + 1);
-      tick(std::true_type{}, acO, acE, 0, min(t + 2, NSL - 1));
+      tick(std::true_type{}, acE, acO, 1, t + 1, t > 0);
+      tick(std::true_type{}, acO, acE, 0, min(t + 2, NSL - 1), true);
     }
     CS_STAMP(4);
     // tick NSL: only the GELU of the last slice (odd)
     CS_LGKM(0);
-    tick(std::false_type{}, acE, acO, 1, 0);
+    tick(std::false_type{}, acE, acO, 1, 0, true);
     // (this was the transition into the last tick, NTICK - 1: the B waves' last slice)
     CS_VMCNT(0);  // every LDS-DMA has landed before the workgroup can end
     CS_STAMP(5);
@@ -393,23 +424,21 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     int slot_x = 0;  // ring slot of the current unit (its residual tile / attention-output fragments share the index)
     sfor<OUT_CHUNKS>([&](auto C_) {
       constexpr int C = decltype(C_)::value;
-      f32x4_t xs[2];
-      auto add_x = [&](auto Q0_) {  // registers 4 Q0 .. 4 Q0 + 7 of tile C
-        constexpr int Q0 = decltype(Q0_)::value;
-        CS_LGKM(0);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc2[C][4 * (Q0 + q) + i] += xs[q][i];
-        CS_SB();
-      };
+      f32x4_t xs;
       sfor<24>([&](auto M_) {
         constexpr int M = decltype(M_)::value;
-        // the unit's residual-row tile C, two quarters at a time (its LDS slot is refilled after the transition below)
-        if constexpr (M == 12) { const unsigned a = xs_addr + slot_x * (4 * 4 * FRAG); lds_read_f4<0>(a, xs[0]); lds_read_f4<FRAG>(a, xs[1]); }
-        if constexpr (M == 14) add_x(IC<0>{});
-        if constexpr (M == 15) { const unsigned a = xs_addr + slot_x * (4 * 4 * FRAG); lds_read_f4<2 * FRAG>(a, xs[0]); lds_read_f4<3 * FRAG>(a, xs[1]); }
-        if constexpr (M == 17) add_x(IC<2>{});
+        // the unit's residual-row tile C, ONE quarter (4 registers) at a time: quarter q is read at the start of gap 12 + q and added in
+        // gap 13 + q (its LDS slot is refilled after the transition below).  The only LDS read issued after it is weight fragment
+        // M + 5, so lgkmcnt(1) retires it; the phase is bound by the A waves' memory stream, not by this wave's LDS latency.
+        // (Two quarters at a time with their 8 + 16 transient registers pushed this loop over 256 VGPRs: 80 spilled dwords, r2.)
+        if constexpr (M >= 13 && M <= 16) {
+          constexpr int Q = M - 13;
+          CS_LGKM(1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc2[C][4 * Q + i] += xs[i];
+          CS_SB();
+        }
+        if constexpr (M >= 12 && M <= 15) lds_read_f4<(M - 12) * FRAG>(xs_addr + slot_x * (4 * 4 * FRAG), xs);
         if constexpr (M == 18) {
           cur = transition(TB{});
           slot_x = slot_x + 1 >= 3 ? 0 : slot_x + 1;

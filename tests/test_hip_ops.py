@@ -101,6 +101,65 @@ def test_gemm_resid_f32(M, with_scale, with_resid):
     assert (out - ref).abs().max() < 2e-4  # fp32 out; only accumulation order differs
 
 
+# ---- the 256 x 256 x 64-tile kernel (csrc/gemm256.hip): shapes with K >= 512, N % 256 == 0, M >= 256 ----
+def _gemm256(on):
+    _lib.load().cs_gemm256_enable(1 if on else 0)
+
+
+def test_gemm256_exact_integer_layout():
+    """Asymmetric integer operands over several K tiles, ragged M: any row<->column swap, fragment mis-mapping, swizzle error or a K tile
+    read before it landed is an exact mismatch (all products and sums are small integers: exact in fp16 x fp16 -> fp32)."""
+    M, N, K = 700, 512, 1024
+    A = ((torch.arange(M, device=DEV)[:, None] * 5 + torch.arange(K, device=DEV)[None, :] * 3) % 7 - 3.0)
+    W = ((torch.arange(N, device=DEV)[:, None] * 3 + torch.arange(K, device=DEV)[None, :] * 7) % 5 - 2.0)
+    b = (torch.arange(N, device=DEV) % 11 - 5.0)
+    ref = A @ W.t() + b
+    out = hh.gemm(_bf(A), _bf(W), b, _lib.EPI_RESID_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    # one-hot rows: row m selects k = (37 m) % K of W
+    A1 = torch.zeros((M, K), device=DEV)
+    A1[torch.arange(M), (torch.arange(M) * 37) % K] = 1.0
+    out = hh.gemm(_bf(A1), _bf(W), None, _lib.EPI_BIAS_F16)
+    torch.cuda.synchronize()
+    assert torch.equal(out.float(), A1 @ W.t())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (300, 768, 768), (1370, 2304, 768), (10960, 768, 3072), (10960, 3072, 768),
+                                   (2740, 768, 1536), (513, 256, 640)])
+def test_gemm256_matches_reference_and_small_tile_kernel(M, N, K):
+    g = _rng(M + N + K + 1)
+    A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))
+    W = _bf(_t(g.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)))
+    b = _t(g.standard_normal((N,), dtype=np.float32))
+    r = _t(g.standard_normal((M, N), dtype=np.float32))
+    try:
+        outs = {}
+        for on in (True, False):
+            _gemm256(on)
+            o16 = hh.gemm(A, W, b, _lib.EPI_BIAS_F16)
+            og = hh.gemm(A, W, b, _lib.EPI_BIAS_GELU_F16)
+            x = r.clone()
+            o32 = hh.gemm(A, W, b, _lib.EPI_RESID_F32, resid=x, out=x)
+            torch.cuda.synchronize()
+            outs[on] = (o16, og, o32)
+    finally:
+        _gemm256(True)
+    y = A.float() @ W.float().t() + b
+    for on in (True, False):
+        o16, og, o32 = outs[on]
+        err = (o16.float() - y).abs()
+        assert (err <= 6e-4 * y.abs() + 5e-5).all(), (on, float((err - 6e-4 * y.abs()).max()))
+        refg = orc.gelu_erf(y.cpu()).to(DEV)
+        err = (og.float() - refg).abs()
+        assert (err <= 6e-4 * refg.abs() + 3e-4).all(), (on, float((err - 6e-4 * refg.abs()).max()))
+        assert (o32 - (y + r)).abs().max() < 3e-4 * max(1.0, math.sqrt(K / 768)), on
+    # the two kernels differ only in fp32 summation order
+    assert (outs[True][2] - outs[False][2]).abs().max() < 2e-4
+    if K % 128 == 0:  # (K = 640 has an odd number of 64-deep K tiles: not a shape of the large-tile kernel, both runs were the small one)
+        assert not torch.equal(outs[True][2], outs[False][2])  # different summation orders: bitwise equality would mean the toggle did nothing
+
+
 def _row_partials(x, sp):
     """(sum, sumsq) of each row of x over the column ranges the producing epilogue's (column tile, wave) pairs own."""
     M, Cc = x.shape

@@ -12,11 +12,11 @@ def timeit(fn, n=20):
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
-for Mimgs in (48, 12, 96, 8):
+for Mimgs in [int(v) for v in os.environ.get("CS_GVB_IMGS", "48,12,96,8,22").split(",")]:
     M = Mimgs * 1370
     shapes = {"qkv": (M, 1152, 384, _lib.EPI_BIAS_F16), "outproj": (M, 384, 384, _lib.EPI_RESID_F32),
               "fc1": (M, 1536, 384, _lib.EPI_BIAS_GELU_F16), "fc2": (M, 384, 1536, _lib.EPI_RESID_F32)}
-    if Mimgs in (96, 8):  # ViT-B (cfg-4: 96 images per step, 8 per encoder chunk)
+    if Mimgs in (96, 8, 22, 44, 88):  # ViT-B (cfg-4: 96 images per step, 8 per encoder chunk)
         shapes = {"qkvB": (M, 2304, 768, _lib.EPI_BIAS_F16), "outprojB": (M, 768, 768, _lib.EPI_RESID_F32),
                   "fc1B": (M, 3072, 768, _lib.EPI_BIAS_GELU_F16), "fc2B": (M, 768, 3072, _lib.EPI_RESID_F32)}
     for sn, (M, N, K, epi) in shapes.items():
@@ -24,6 +24,10 @@ for Mimgs in (48, 12, 96, 8):
         b = torch.randn(N, device=dev)
         resid = torch.randn(M, N, device=dev) if epi == _lib.EPI_RESID_F32 else None
         o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.float16)
+        lib = _lib.load()
+        lib.cs_gemm256_enable(0)
+        t_old = timeit(lambda: hh.gemm(A, W, b, epi, resid=resid, out=o))
+        lib.cs_gemm256_enable(1)
         t_us = timeit(lambda: hh.gemm(A, W, b, epi, resid=resid, out=o))
         t_plain = timeit(lambda: hh.gemm(A, W, b, _lib.EPI_BIAS_F16, out=o if o.dtype == torch.float16 else None)) if False else 0
         Wt = W.t().contiguous(); ob = torch.empty(M, N, device=dev, dtype=torch.float16)
@@ -31,4 +35,4 @@ for Mimgs in (48, 12, 96, 8):
         t_blas = timeit(lambda: torch.matmul(A, W.t(), out=ob))
         t_blas2 = timeit(lambda: torch.matmul(A, Wt, out=ob))
         fl = 2.0 * M * N * K
-        print(f"M={M} {sn:8s} N={N} K={K}: ours {t_us:7.1f} us ({fl/t_us/1e6:6.0f} TF/s) | hipBLASLt NT {t_blas:7.1f} us ({fl/t_blas/1e6:6.0f}) NN {t_blas2:7.1f} us", flush=True)
+        print(f"M={M} {sn:8s} N={N} K={K}: ours {t_us:7.1f} us ({fl/t_us/1e6:6.0f} TF/s) [128-row kernel {t_old:7.1f} us] | hipBLASLt NT {t_blas:7.1f} us ({fl/t_blas/1e6:6.0f}) NN {t_blas2:7.1f} us", flush=True)
