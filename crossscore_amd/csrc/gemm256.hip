@@ -6,7 +6,7 @@
 // Why a second GEMM kernel: gemm.hip's 128 x 192 x 32 tile stages 1 byte from L2 per 77 FLOP, which at K >= 768 puts the kernel on
 // the L2 -> LDS staging path (measured 0.55-0.70 x hipBLASLt on the ViT-B shapes).  This kernel stages 1 byte per
 // 128 FLOP: a 256 x 256 x 64 tile per workgroup of 8 waves (2 along M x 4 along N, wave tile 128 x 64 = 8 x 4 accumulators of
-// v_mfma_f32_16x16x32), one workgroup per CU.
+// v_mfma_f32_16x16x32), one persistent workgroup per CU walking output tiles in an XCD-aware order.
 //
 // Schedule (a K tile = 4 phases; a phase = [load segment | s_barrier | 16 MFMAs | s_barrier]):
 //   * the two waves of a SIMD (wave w and w + 4: the two M halves) run ONE barrier apart, so while one is in its 16-MFMA cluster
@@ -18,10 +18,14 @@
 //     A0 @ phase 3, W0 @ 4 of tile t, W1 @ phase 1, A1 @ 2 of tile t + 1);
 //   * ONE counted s_waitcnt vmcnt(4) per K tile (phase 4: everything of the next K tile has landed, two half-tiles stay in flight),
 //     never 0 inside the loop; the barrier that follows orders it for every wave's reads one phase later;
+//   * the LDS-DMA stream does not stop at an output tile's end: the K tiles of the NEXT output tile follow in the same slots, and at the
+//     seam the two pieces that would be issued in the new tile's first two phases are issued BEFORE the epilogue's stores, so that the
+//     first waits of the new tile do not have to retire those stores (the vector-memory queue retires in order);
 //   * LDS image: rows of 128 B (64 k), 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7): applied on the DMA's per-lane
 //     SOURCE address and on the ds_read_b128 address, conflict free for the 16x16x32 operand read.
 // The MFMA takes the W fragment as its first operand, so a lane owns 4 consecutive output columns of one row; the epilogue goes
-// through a wave-private LDS patch and stores whole 128-byte lines.
+// through a wave-private LDS patch (inline-asm ds ops: the compiler must not order them against the LDS-DMA in flight) and stores
+// whole 128-byte lines; the bias vector lives in LDS and is the accumulators' initial value.
 #include "cs_common.h"
 #include <type_traits>
 #include <utility>
@@ -31,12 +35,15 @@ namespace {
 constexpr int G_BM = 256, G_BN = 256, G_BK = 64;
 constexpr int G_ROWB = G_BK * 2;            // 128 bytes per staged row
 constexpr int G_OPND = 256 * G_ROWB;        // 32 KiB: one operand's K tile
-constexpr int G_BUF = 2 * G_OPND;           // 64 KiB: A | W
-constexpr int G_RING = 2 * G_BUF;           // 128 KiB
-constexpr int G_PATCH_H = 16 * 144;         // fp16 patch: 16 rows x (128 + 16) B
-constexpr int G_PATCH_F = 16 * 272;         // fp32 patch: 16 rows x (256 + 16) B
-constexpr int G_BIAS = G_RING;              // 1 KiB behind the ring: the tile's 256 bias values (fp32)
-constexpr int G_LDS = G_RING + 1024;        // the epilogue patches live in the ring (idle once the K loop is done)
+constexpr int G_WOFF = 2 * G_OPND;          // ring = [A buffer 0 | A buffer 1 | W buffer 0 | W buffer 1]: every fragment read is one of four
+                                            // per-lane base addresses (operand x k-step) plus an immediate below 64 KiB
+constexpr int G_RING = 4 * G_OPND;          // 128 KiB
+constexpr int G_NMAX = 3072;                // widest N (the bias vector is kept in LDS)
+constexpr int G_BIAS = G_RING;              // 12 KiB
+constexpr int G_PROW = 144;                 // patch row: 128 B + 16 B pad
+constexpr int G_PATCH = 16 * G_PROW;        // one 16-row patch per wave
+constexpr int G_PATCH0 = G_BIAS + G_NMAX * 4;
+constexpr int G_LDS = G_PATCH0 + 8 * G_PATCH;   // 158 KiB
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -60,7 +67,22 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 }
 
 #define G_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define G_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define G_SB() __builtin_amdgcn_sched_barrier(0)
+
+// wave-private patch / bias access by inline asm (invisible to the compiler's LDS-DMA alias ordering; waits are the caller's)
+template <int OFF>
+__device__ __forceinline__ void pw8(unsigned addr, u32x2_t v) { asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void pw16(unsigned addr, f32x4_t v) { asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void pr16(unsigned addr, f32x4_t& v) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory"); }
+// residual rows (fp32 epilogue): 16 bytes per lane at sbase + voff by inline asm, so that the compiler neither counts nor waits for the
+// load (its own wait would be vmcnt(0): every store of the previous step); the epilogue's counted waits cover it
+__device__ __forceinline__ void gl16(f32x4_t& r, unsigned voff, const float* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void touch(f32x4_t& r) { asm volatile("" : "+v"(r)); }
 
 template <int EPI, bool BF>
 __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
@@ -72,67 +94,95 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 2, wn = wv & 3;
 
-  // ---- tile of this workgroup, XCD aware: blocks b, b + 8, .. share an XCD (round-robin dispatch; speed only); XCD x owns the A row
-  //      panels tm == x (mod 8) and walks them n-fastest, so the blocks resident on one L2 share A panels ----
+  // ---- persistent tile walk, XCD aware: blocks b, b + 8, .. share an XCD (round-robin dispatch; speed only); XCD x owns the A row
+  //      panels tm == x (mod 8) and its blocks walk that list n-fastest, so the blocks resident on one L2 share A panels ----
   const int tiles_n = p.N / G_BN;
   const int tiles_m = (p.M + G_BM - 1) / G_BM;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int pl = slot / tiles_n;
-  const int tm = pl * 8 + xcd;
-  if (tm >= tiles_m) return;  // whole workgroup, before any barrier
-  const int m0 = tm * G_BM, n0 = (slot - pl * tiles_n) * G_BN;
-  const int T = p.K / G_BK;   // K tiles (even: cs_gemm256_supported)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int panels_x = (tiles_m - xcd + 7) / 8;
+  const int ntile_x = panels_x * tiles_n;
+  if (slot >= ntile_x) return;  // whole workgroup, before any barrier
+  const int T = p.K / G_BK;     // K tiles per output tile (even, >= 8: cs_gemm256_supported)
+  auto tile_of = [&](int idx, int& m0, int& n0) {
+    const int pl = idx / tiles_n;
+    m0 = (pl * 8 + xcd) * G_BM;
+    n0 = (idx - pl * tiles_n) * G_BN;
+  };
+
+  // ---- bias vector -> LDS once per block (plain accesses: nothing else is in flight yet) ----
+  for (int i = tid * 4; i < p.N; i += 2048) {
+    f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + i);
+    *reinterpret_cast<f32x4_t*>(smem + G_BIAS + i * 4) = b4;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  G_SB();
 
   // ---- LDS-DMA maps.  One instruction = 8 rows x 128 B; lane i writes LDS chunk (i & 7) of row (i >> 3) and fetches source chunk
   //      (i & 7) ^ ((row >> 1) & 7).  Half-tile h of A = rows {wm' * 128 + h * 64 + 0..63}; of W = rows {wn' * 64 + h * 32 + 0..31};
   //      wave wv issues pieces 2 wv, 2 wv + 1 of each half-tile. ----
   const int srow = lane >> 3;
-  unsigned offA[2][2], offW[2][2];   // [half][piece] global byte offsets
-  int ldsA[2][2], ldsW[2][2];        // wave-uniform LDS byte offsets inside a buffer
+  unsigned offA[2][2], offW[2][2];   // [half][piece] global byte offsets of the load cursor's output tile
+  auto set_offsets = [&](int m0, int n0) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int ra0 = (wv >> 2) * 128 + h * 64 + ((16 * wv) & 63) + 8 * e;   // first row of the piece (wave-uniform)
-      const int ra = ra0 + srow;
-      const int gca = (lane & 7) ^ ((ra >> 1) & 7);
-      offA[h][e] = ((unsigned)min(m0 + ra, p.M - 1) * (unsigned)p.lda + (unsigned)gca * 8u) * 2u;
-      ldsA[h][e] = ra0 * G_ROWB;
-      const int rw0 = (wv >> 1) * 64 + h * 32 + ((16 * wv) & 31) + 8 * e;
-      const int rw = rw0 + srow;
-      const int gcw = (lane & 7) ^ ((rw >> 1) & 7);
-      offW[h][e] = ((unsigned)(n0 + rw) * (unsigned)p.ldw + (unsigned)gcw * 8u) * 2u;
-      ldsW[h][e] = G_OPND + rw0 * G_ROWB;
-    }
-  // stage half-tile (which: 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1) of K tile kt into buffer (kt & 1)
-  auto stage = [&](auto WHICH_, int kt) {
+      for (int e = 0; e < 2; ++e) {
+        const int ra = (wv >> 2) * 128 + h * 64 + ((16 * wv) & 63) + 8 * e + srow;
+        const int gca = (lane & 7) ^ ((ra >> 1) & 7);
+        offA[h][e] = ((unsigned)min(m0 + ra, p.M - 1) * (unsigned)p.lda + (unsigned)gca * 8u) * 2u;
+        const int rw = (wv >> 1) * 64 + h * 32 + ((16 * wv) & 31) + 8 * e + srow;
+        const int gcw = (lane & 7) ^ ((rw >> 1) & 7);
+        offW[h][e] = ((unsigned)(n0 + rw) * (unsigned)p.ldw + (unsigned)gcw * 8u) * 2u;
+      }
+  };
+  // load cursor: the K tile whose pieces are being issued (it runs two K tiles ahead of the MFMAs, across output tiles)
+  int l_idx = slot, l_kt = 0;
+  bool l_valid = true;
+  {
+    int m0, n0;
+    tile_of(l_idx, m0, n0);
+    set_offsets(m0, n0);
+  }
+  // piece WHICH (0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1) of the cursor's K tile, into buffer (l_kt & 1)
+  auto stage = [&](auto WHICH_) {
     constexpr int WHICH = decltype(WHICH_)::value;
     constexpr bool isA = WHICH == 0 || WHICH == 3;
     constexpr int h = (WHICH == 0 || WHICH == 1) ? 0 : 1;
-    char* base = smem + (kt & 1) * G_BUF;
-    const char* src = reinterpret_cast<const char*>(isA ? p.A : p.W) + (size_t)kt * G_ROWB;
+    char* base = smem + (l_kt & 1) * G_OPND + (isA ? 0 : G_WOFF);
+    const char* src = reinterpret_cast<const char*>(isA ? p.A : p.W) + (size_t)l_kt * G_ROWB;
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
-      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(src + (isA ? offA[h][e] : offW[h][e])), CS_LDS_PTR(base + (isA ? ldsA[h][e] : ldsW[h][e])), 16, 0, 0);
+    for (int e = 0; e < 2; ++e) {
+      const int r0 = isA ? (wv >> 2) * 128 + h * 64 + ((16 * wv) & 63) + 8 * e : (wv >> 1) * 64 + h * 32 + ((16 * wv) & 31) + 8 * e;
+      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(src + (isA ? offA[h][e] : offW[h][e])), CS_LDS_PTR(base + r0 * G_ROWB), 16, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+    if (++l_kt == T) {
+      l_kt = 0;
+      l_idx += slots;
+      l_valid = l_idx < ntile_x;
+      if (l_valid) {
+        int m0, n0;
+        tile_of(l_idx, m0, n0);
+        set_offsets(m0, n0);
+      }
+    }
   };
 
   // ---- fragment read addressing: lane (fr = lane & 15, cq = lane >> 4) reads row fr, chunk (4 s + cq) ^ ((fr >> 1) & 7) ----
-  const int fr = lane & 15;
-  const int c0 = ((lane >> 4) ^ ((fr >> 1) & 7)) * 16;
+  const int fr = lane & 15, cq = lane >> 4;
+  const int c0 = (cq ^ ((fr >> 1) & 7)) * 16;
   const char* rdA = smem + wm * (128 * G_ROWB) + fr * G_ROWB;           // + buffer + (mh * 64 + 16 i) * 128 + (c0 | c0 ^ 64)
-  const char* rdW = smem + G_OPND + wn * (64 * G_ROWB) + fr * G_ROWB;   // + buffer + (nh * 32 + 16 j) * 128 + ..
+  const char* rdW = smem + G_WOFF + wn * (64 * G_ROWB) + fr * G_ROWB;   // + buffer + (nh * 32 + 16 j) * 128 + ..
 
   f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   h16x8_t fa[4][2], fw[2][2][2];  // A fragments of the current M half [i][s]; W fragments of both N halves [nh][j][s]
   auto ld_a = [&](auto B_, auto MH_) {
     constexpr int B = decltype(B_)::value, MH = decltype(MH_)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const char* r = rdA + B * G_BUF + (MH * 64 + 16 * i) * G_ROWB;
+      const char* r = rdA + B * G_OPND + (MH * 64 + 16 * i) * G_ROWB;
       fa[i][0] = *reinterpret_cast<const h16x8_t*>(r + c0);
       fa[i][1] = *reinterpret_cast<const h16x8_t*>(r + (c0 ^ 64));
     }
@@ -141,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     constexpr int B = decltype(B_)::value, NH = decltype(NH_)::value;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const char* r = rdW + B * G_BUF + (NH * 32 + 16 * j) * G_ROWB;
+      const char* r = rdW + B * G_OPND + (NH * 32 + 16 * j) * G_ROWB;
       fw[NH][j][0] = *reinterpret_cast<const h16x8_t*>(r + c0);
       fw[NH][j][1] = *reinterpret_cast<const h16x8_t*>(r + (c0 ^ 64));
     }
@@ -170,106 +220,167 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     G_SB();
   };
 
-  // ---- prologue: K tile 0 completely, A half 0 and W half 0 of K tile 1 (its other halves are issued by phases 1 and 2 of tile 0) ----
-  stage(IC<0>{}, 0); stage(IC<1>{}, 0); stage(IC<2>{}, 0); stage(IC<3>{}, 0);
-  stage(IC<0>{}, 1); stage(IC<1>{}, 1);
-  // the tile's bias values -> LDS (read back in the epilogue: 16 registers less across the K loop).  Wave 0 only; its load is younger
-  // than its LDS-DMA pieces, so the compiler's wait in front of the LDS write retires those too -- harmless, this is the prologue
-  if (wv == 0) {
-    f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + lane * 4);
-    *reinterpret_cast<f32x4_t*>(smem + G_BIAS + lane * 16) = b4;
-  }
-  G_VMCNT(4);
-  bar();
+  // ---- wave-private patch / bias addressing, recomputed at every seam from an opaque copy of the lane id: hoisted out of the tile loop
+  //      these six registers would be spilled around the K loop (which runs at the 256-register limit) ----
+  const unsigned lds0 = (unsigned)(size_t)CS_LDS_PTR(smem);
+  unsigned pw_addr = 0, pr_addr = 0, bias_addr = 0;
+  int rrow = 0, rch = 0;
+  auto seam_addresses = [&]() {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const unsigned patch = lds0 + G_PATCH0 + wv * G_PATCH;
+    pw_addr = patch + (ln & 15) * G_PROW + (ln >> 4) * (kHalf ? 8 : 16);   // accumulator layout: row fr, 4 columns at 4 cq of a 16-column tile
+    rrow = ln >> 3; rch = ln & 7;
+    pr_addr = patch + rrow * G_PROW + rch * 16;                            // row segments: 8 rows x 8 chunks per read (+ 8 rows: + 8 * G_PROW)
+    bias_addr = lds0 + G_BIAS + (wn * 64 + 4 * (ln >> 4)) * 4;
+  };
+  auto init_acc = [&](int n0) {  // accumulators start at the bias of their columns (16 j + 4 cq .. + 3 of the wave's 64)
+    const unsigned a = bias_addr + n0 * 4;
+    f32x4_t b4[4];
+    pr16<0>(a, b4[0]); pr16<64>(a, b4[1]); pr16<128>(a, b4[2]); pr16<192>(a, b4[3]);
+    G_LGKM(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = b4[j];
+  };
+
+  // ---- prologue: K tiles 0 and 1 of the first output tile completely ----
+  stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); advance();
+  stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); advance();
+  G_VMCNT(8);
+  bar();               // K tile 0 has landed for everyone; the bias vector is in LDS
   if (wm == 1) bar();  // the second M half runs one barrier behind the first
 
-  // ---- K loop, two K tiles (buffers 0 and 1) per iteration ----
-  auto ktile = [&](auto B_, int t) {
+  // ---- one K tile (buffer B).  kt0: the first K tile of an output tile (its successor's late pieces were issued at the seam) ----
+  auto ktile = [&](auto B_, bool kt0) {
     constexpr int B = decltype(B_)::value;
-    const bool more1 = t + 1 < T, more2 = t + 2 < T;
     // phase 1: quadrant (0, 0)
     ld_w(IC<B>{}, IC<0>{}); ld_a(IC<B>{}, IC<0>{});
-    if (more1) stage(IC<2>{}, t + 1);
+    if (!kt0 && l_valid) stage(IC<2>{});
     bar_then_wait(); mma(IC<0>{}, IC<0>{}); bar();
     // phase 2: quadrant (0, 1)
     ld_w(IC<B>{}, IC<1>{});
-    if (more1) stage(IC<3>{}, t + 1);
+    if (!kt0 && l_valid) { stage(IC<3>{}); advance(); }
     bar_then_wait(); mma(IC<0>{}, IC<1>{}); bar();
     // phase 3: quadrant (1, 1)
     ld_a(IC<B>{}, IC<1>{});
-    if (more2) stage(IC<0>{}, t + 2);
+    const bool more = l_valid;
+    if (more) stage(IC<0>{});
     bar_then_wait(); mma(IC<1>{}, IC<1>{}); bar();
-    // phase 4: quadrant (1, 0); the next K tile has landed behind this phase's first barrier
-    if (more2) { stage(IC<1>{}, t + 2); G_VMCNT(4); }
+    // phase 4: quadrant (1, 0); the next K tile has landed behind this phase's first barrier (the two pieces just issued stay in flight)
+    if (more) { stage(IC<1>{}); G_VMCNT(4); }
     else G_VMCNT(0);
     bar_then_wait(); mma(IC<1>{}, IC<0>{}); bar();
   };
-  for (int t = 0; t < T; t += 2) {
-    ktile(IC<0>{}, t);
-    ktile(IC<1>{}, t + 1);
+
+  for (int idx = slot; idx < ntile_x; idx += slots) {
+    int cm0, cn0;
+    tile_of(idx, cm0, cn0);
+    seam_addresses();
+    init_acc(cn0);
+    ktile(IC<0>{}, true);
+    ktile(IC<1>{}, false);
+    for (int t = 2; t < T; t += 2) {
+      ktile(IC<0>{}, false);
+      ktile(IC<1>{}, false);
+    }
+    // ---- seam: the late pieces of the next output tile's K tile 1 go out BEFORE this tile's stores ----
+    if (l_valid) { stage(IC<2>{}); stage(IC<3>{}); advance(); }
+    G_SB();
+    seam_addresses();
+    // ---- epilogue: a 16-row sub-tile goes into the patch in the accumulator layout and comes out as row segments, 16 B per lane,
+    //      whole 128-byte lines to memory.  LDS operations of one wave execute in order, so step i + 1's writes are issued right behind
+    //      step i's reads and a counted lgkmcnt retires the reads. ----
+    const int row_w = cm0 + wm * 128;       // first row of the wave tile
+    const int col_w = cn0 + wn * 64;        // first column
+    if constexpr (kHalf) {
+      auto put = [&](auto I_) {
+        constexpr int i = decltype(I_)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if constexpr (EPI == CS_EPI_BIAS_GELU_F16) gelu_erf4(v);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (EPI == CS_EPI_BIAS_RELU_F16) v[r] = fmaxf(v[r], 0.f);
+            if constexpr (EPI == CS_EPI_BIAS_LEAKY_F16) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+          }
+          const u32x2_t pk = {pack2<BF>(v[0], v[1]), pack2<BF>(v[2], v[3])};
+          if (j == 0) pw8<0>(pw_addr, pk);
+          if (j == 1) pw8<32>(pw_addr, pk);
+          if (j == 2) pw8<64>(pw_addr, pk);
+          if (j == 3) pw8<96>(pw_addr, pk);
+        }
+      };
+      f32x4_t seg[2];
+      auto get = [&]() { pr16<0>(pr_addr, seg[0]); pr16<8 * G_PROW>(pr_addr, seg[1]); };
+      auto out = [&](auto I_) {
+        constexpr int i = decltype(I_)::value;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int m = row_w + 16 * i + q * 8 + rrow;
+          if (m < p.M) *reinterpret_cast<f32x4_t*>(reinterpret_cast<h16_t*>(p.out) + (size_t)m * p.ldc + col_w + rch * 8) = seg[q];
+        }
+      };
+      put(IC<0>{}); get();
+#define G_STEP(I) put(IC<I>{}); G_LGKM(4); out(IC<I - 1>{}); G_SB(); get();
+      G_STEP(1) G_STEP(2) G_STEP(3) G_STEP(4) G_STEP(5) G_STEP(6) G_STEP(7)
+#undef G_STEP
+      G_LGKM(0); out(IC<7>{});
+    } else {
+      // fp32: 16 steps of (16 rows x 32 columns): sub-tile (i, nh) = accumulators [i][2 nh], [i][2 nh + 1].  The residual rows are loaded
+      // one step ahead by inline asm (vector-memory order: L0 L1 | S0 L2 | S1 L3 | ..: when step t's rows are needed, the two loads of
+      // step t + 1 and the two stores of step t - 1 are younger: vmcnt(4); the DMA pieces issued above are older and have to land first)
+      const unsigned r_lane = (unsigned)((rrow * p.ldr + rch * 4) * 4);
+      f32x4_t rb[2][2];
+      auto rload = [&](auto S_, f32x4_t (&r)[2]) {
+        constexpr int st = decltype(S_)::value;
+        constexpr int i = st >> 1, nh = st & 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int m = min(row_w + 16 * i + q * 8, p.M - 8);  // (clamped rows are never stored)
+          gl16(r[q], r_lane, p.resid + (size_t)m * p.ldr + col_w + nh * 32);
+        }
+      };
+      auto put = [&](auto S_) {
+        constexpr int st = decltype(S_)::value;
+        constexpr int i = st >> 1, nh = st & 1;
+        pw16<0>(pw_addr, acc[i][2 * nh]);
+        pw16<64>(pw_addr, acc[i][2 * nh + 1]);
+      };
+      f32x4_t seg[2];
+      auto get = [&]() { pr16<0>(pr_addr, seg[0]); pr16<8 * G_PROW>(pr_addr, seg[1]); };
+      auto out = [&](auto S_, f32x4_t (&r)[2]) {
+        constexpr int st = decltype(S_)::value;
+        constexpr int i = st >> 1, nh = st & 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int m = row_w + 16 * i + q * 8 + rrow;
+          if (p.resid) { touch(r[q]); seg[q] += r[q]; }
+          if (m < p.M) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + col_w + nh * 32 + rch * 4) = seg[q];
+        }
+      };
+      const bool full = cm0 + G_BM <= p.M;  // a ragged tile's masked stores make the store count unknown: its waits are vmcnt(0)
+      if (p.resid) { rload(IC<0>{}, rb[0]); rload(IC<1>{}, rb[1]); }
+      put(IC<0>{}); get();
+#define G_STEPF(S, CUR, NXT)                                                     \
+      put(IC<S>{}); G_LGKM(2);                                                   \
+      if (p.resid) { if (full && S - 1 >= 1) G_VMCNT(4); else if (full) G_VMCNT(2); else G_VMCNT(0); } \
+      G_SB(); out(IC<S - 1>{}, rb[CUR]); G_SB();                                 \
+      if (p.resid && S + 1 < 16) rload(IC<(S + 1 < 16 ? S + 1 : 0)>{}, rb[CUR]); \
+      get();
+      G_STEPF(1, 0, 1) G_STEPF(2, 1, 0) G_STEPF(3, 0, 1) G_STEPF(4, 1, 0) G_STEPF(5, 0, 1) G_STEPF(6, 1, 0) G_STEPF(7, 0, 1)
+      G_STEPF(8, 1, 0) G_STEPF(9, 0, 1) G_STEPF(10, 1, 0) G_STEPF(11, 0, 1) G_STEPF(12, 1, 0) G_STEPF(13, 0, 1) G_STEPF(14, 1, 0)
+      G_STEPF(15, 0, 1)
+#undef G_STEPF
+      G_LGKM(0);
+      if (p.resid) { if (full) G_VMCNT(2); else G_VMCNT(0); }  // step 15's rows: only step 14's two stores are younger
+      G_SB(); out(IC<15>{}, rb[1]);
+    }
+    G_SB();
   }
   if (wm == 0) bar();  // the first half's matching barrier
-
-  // ---- epilogue.  Wave-private LDS patch (in the ring: every read of it is retired and no LDS-DMA is outstanding): a 16-row
-  //      sub-tile goes in in the accumulator layout and comes out as row segments, 16 B per lane, whole 128-byte lines to memory ----
-  char* patch = smem + wv * (2 * G_PATCH_F);
-  f32x4_t bia[4];  // this lane's columns: 16 j + 4 (lane >> 4) .. + 3 of the wave's 64
-#pragma unroll
-  for (int j = 0; j < 4; ++j) bia[j] = *reinterpret_cast<const f32x4_t*>(smem + G_BIAS + (wn * 64 + 16 * j + 4 * (lane >> 4)) * 4);
-  const int row_w = m0 + wm * 128;        // first row of the wave tile
-  const int col_w = n0 + wn * 64;         // first column
-  if constexpr (kHalf) {
-    const int wr_off = fr * 144 + (lane >> 4) * 8;       // + 32 j
-    const int rrow = lane >> 3, rch = lane & 7;          // read: 8 rows x 8 chunks per instruction
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      char* pp = patch + (i & 1) * G_PATCH_H;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v[4] = {acc[i][j][0] + bia[j][0], acc[i][j][1] + bia[j][1], acc[i][j][2] + bia[j][2], acc[i][j][3] + bia[j][3]};
-        if constexpr (EPI == CS_EPI_BIAS_GELU_F16) gelu_erf4(v);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (EPI == CS_EPI_BIAS_RELU_F16) v[r] = fmaxf(v[r], 0.f);
-          if constexpr (EPI == CS_EPI_BIAS_LEAKY_F16) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
-        }
-        *reinterpret_cast<u32x2_t*>(pp + wr_off + 32 * j) = u32x2_t{pack2<BF>(v[0], v[1]), pack2<BF>(v[2], v[3])};
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int rr = q * 8 + rrow;
-        const f32x4_t seg = *reinterpret_cast<const f32x4_t*>(pp + rr * 144 + rch * 16);
-        const int m = row_w + 16 * i + rr;
-        if (m < p.M) *reinterpret_cast<f32x4_t*>(reinterpret_cast<h16_t*>(p.out) + (size_t)m * p.ldc + col_w + rch * 8) = seg;
-      }
-    }
-  } else {
-    const int wr_off = fr * 272 + (lane >> 4) * 16;      // + 64 j
-    const int rrow = lane >> 4, rch = lane & 15;         // read: 4 rows x 16 chunks per instruction
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      char* pp = patch + (i & 1) * G_PATCH_F;
-      f32x4_t res[4];
-      if (p.resid) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int m = min(row_w + 16 * i + q * 4 + rrow, p.M - 1);
-          res[q] = *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m * p.ldr + col_w + rch * 4);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(pp + wr_off + 64 * j) = acc[i][j] + bia[j];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int rr = q * 4 + rrow;
-        f32x4_t seg = *reinterpret_cast<const f32x4_t*>(pp + rr * 272 + rch * 16);
-        if (p.resid) seg += res[q];
-        const int m = row_w + 16 * i + rr;
-        if (m < p.M) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + col_w + rch * 4) = seg;
-      }
-    }
-  }
 }
 
 int g_enabled = 1;
@@ -284,8 +395,18 @@ hipError_t launch256(const CsGemmParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done[dev] = true;
   }
+  static int num_cus[16] = {};
+  if (num_cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return hipErrorUnknown;
+    num_cus[dev] = n;
+  }
   const int tiles_n = p.N / G_BN, tiles_m = (p.M + G_BM - 1) / G_BM;
-  const int grid = ((tiles_m + 7) / 8) * tiles_n * 8;
+  // one persistent workgroup per CU (LDS and registers admit one); the grid is a multiple of 8 so that b % 8 labels the XCD group
+  int grid = (num_cus[dev] / 8) * 8;
+  const int need = ((tiles_m + 7) / 8) * tiles_n * 8;
+  if (grid > need) grid = need;
+  if (grid < 8) grid = 8;
   hipLaunchKernelGGL((cs_gemm256_kernel<EPI, BF>), dim3(grid), dim3(512), G_LDS, st, p);
   return hipGetLastError();
 }
@@ -302,7 +423,7 @@ void cs_gemm256_enable(int on) { g_enabled = on; }
 int cs_gemm256_supported(const CsGemmParams* p, int epi) {
   if (!g_enabled) return 0;
   if (epi > CS_EPI_RESID_F32) return 0;
-  if (p->N % G_BN || p->K % (2 * G_BK) || p->K < 512 || p->M < G_BM) return 0;
+  if (p->N % G_BN || p->N > G_NMAX || p->K % (2 * G_BK) || p->K < 512 || p->M < G_BM) return 0;
   if (p->lda % 8 || p->ldw % 8 || p->ldc % 8) return 0;
   if ((long long)p->M * p->lda * 2 >= (1ll << 32) || (long long)p->N * p->ldw * 2 >= (1ll << 32)) return 0;
   if (epi == CS_EPI_RESID_F32 && p->resid && p->ldr % 4) return 0;

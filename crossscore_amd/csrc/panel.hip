@@ -88,22 +88,6 @@ __device__ __forceinline__ float gelu_erf1(float x) {
   return x * fmaf(c, q, 0.5f);
 }
 
-// the same fit for two values at once, cut in two halves (5 + 6 instructions per value) that sit in consecutive MFMA gaps
-__device__ __forceinline__ void gelu2_head(float x0, float x1, float (&c)[2], float (&t)[2], float (&q)[2]) {
-  c[0] = __builtin_amdgcn_fmed3f(x0, -4.2f, 4.2f); c[1] = __builtin_amdgcn_fmed3f(x1, -4.2f, 4.2f);
-  t[0] = c[0] * c[0]; t[1] = c[1] * c[1];
-  q[0] = fmaf(-9.6129670387e-10f, t[0], 8.3297297734e-08f); q[1] = fmaf(-9.6129670387e-10f, t[1], 8.3297297734e-08f);
-  q[0] = fmaf(q[0], t[0], -3.1398569575e-06f); q[1] = fmaf(q[1], t[1], -3.1398569575e-06f);
-  q[0] = fmaf(q[0], t[0], 6.8266010957e-05f); q[1] = fmaf(q[1], t[1], 6.8266010957e-05f);
-}
-__device__ __forceinline__ void gelu2_tail(float x0, float x1, const float (&c)[2], const float (&t)[2], const float (&q)[2], float& y0, float& y1) {
-  float a = fmaf(q[0], t[0], -9.6075936689e-04f), b = fmaf(q[1], t[1], -9.6075936689e-04f);
-  a = fmaf(a, t[0], 9.3374518106e-03f); b = fmaf(b, t[1], 9.3374518106e-03f);
-  a = fmaf(a, t[0], -6.5599355124e-02f); b = fmaf(b, t[1], -6.5599355124e-02f);
-  a = fmaf(a, t[0], 3.9850871469e-01f); b = fmaf(b, t[1], 3.9850871469e-01f);
-  y0 = x0 * fmaf(c[0], a, 0.5f); y1 = x1 * fmaf(c[1], b, 0.5f);
-}
-
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4_t pack8(const float (&v)[8]) {
   return u32x4_t{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7])};
@@ -282,7 +266,6 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     const unsigned bias_addr = lds0 + LDS_B1 + 64 * h;
     const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
     float gv[8];
-    [[maybe_unused]] float g2c[2], g2t[2], g2q[2];
     f32x4_t bb[4];
     auto read_bias = [&](int t) {  // this lane's 16 hidden units of slice t: 32 t + 16 h + r
       const unsigned a = bias_addr + t * 128;
@@ -316,19 +299,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           if constexpr (M < 18) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
           else lds_read1<(M - 18) * FRAG>(cur, w[M % 6]);
         }
-#ifdef CS_PANEL_GELU2
-        // two values per pair of gaps, their Horner chains interleaved (a lone chain is 11 DEPENDENT VALU instructions: dependent issue
-        // costs ~1.7x independent issue, and the A wave's stream is the tick's critical path)
-        if constexpr (M < 16 && (M & 1) == 0) {
-          if constexpr (ABL & 1) { gv[M & 7] = act[M]; gv[(M + 1) & 7] = act[M + 1]; }
-          else gelu2_head(act[M], act[M + 1], g2c, g2t, g2q);
-        }
-        if constexpr (M < 16 && (M & 1) == 1) {
-          if constexpr (!(ABL & 1)) gelu2_tail(act[M - 1], act[M], g2c, g2t, g2q, gv[(M - 1) & 7], gv[M & 7]);
-        }
-#else
         if constexpr (M < 16) gv[M & 7] = (ABL & 1) ? act[M] : gelu_erf1(act[M]);
-#endif
         if constexpr (M == 7) { if (hb_write) lds_write16<0>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv)); }
         if constexpr (M == 15) { if (hb_write) lds_write16<FRAG>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv)); }
         CS_SB();
