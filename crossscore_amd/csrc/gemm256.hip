@@ -82,11 +82,14 @@ __device__ __forceinline__ void pr16(unsigned addr, f32x4_t& v) { asm volatile("
 __device__ __forceinline__ void gl16(f32x4_t& r, unsigned voff, const float* sbase) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(voff), "s"(sbase) : "memory");
 }
-__device__ __forceinline__ void touch(f32x4_t& r) { asm volatile("" : "+v"(r)); }
+// first use of a register set loaded by gl16 (behind the counted wait that retires it); the marker is what tools/asm_audit.py looks for
+__device__ __forceinline__ void touch(f32x4_t& r) { asm volatile("; GL16_USE %0" : "+v"(r)); }
 
-template <int EPI, bool BF>
+// RES: the fp32 epilogue adds residual rows (compile time: a run-time test would put every in-flight residual register behind phi copies)
+template <int EPI, bool BF, bool RES>
 __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
   constexpr bool kHalf = EPI <= CS_EPI_BIAS_LEAKY_F16;
+  static_assert(!RES || EPI == CS_EPI_RESID_F32, "gemm256: residual rows belong to the fp32 epilogue");
   static_assert(kHalf || EPI == CS_EPI_RESID_F32, "gemm256: bias->16-bit and residual fp32 epilogues only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -332,16 +335,16 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
       // fp32: 16 steps of (16 rows x 32 columns): sub-tile (i, nh) = accumulators [i][2 nh], [i][2 nh + 1].  The residual rows are loaded
       // one step ahead by inline asm (vector-memory order: L0 L1 | S0 L2 | S1 L3 | ..: when step t's rows are needed, the two loads of
       // step t + 1 and the two stores of step t - 1 are younger: vmcnt(4); the DMA pieces issued above are older and have to land first)
-      const unsigned r_lane = (unsigned)((rrow * p.ldr + rch * 4) * 4);
-      f32x4_t rb[2][2];
-      auto rload = [&](auto S_, f32x4_t (&r)[2]) {
+      // The loads' destination registers are written when the data arrives, not at the asm statement: nothing may touch them in between
+      // (tools/asm_audit.py checks the build's .s for that).
+      [[maybe_unused]] const unsigned r_lane = RES ? (unsigned)((rrow * p.ldr + rch * 4) * 4) : 0u;
+      [[maybe_unused]] f32x4_t ra0, ra1, rb0, rb1;
+      auto rload = [&](auto S_, f32x4_t& r0, f32x4_t& r1) {
         constexpr int st = decltype(S_)::value;
         constexpr int i = st >> 1, nh = st & 1;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int m = min(row_w + 16 * i + q * 8, p.M - 8);  // (clamped rows are never stored)
-          gl16(r[q], r_lane, p.resid + (size_t)m * p.ldr + col_w + nh * 32);
-        }
+        const int m0r = min(row_w + 16 * i, p.M - 8), m1r = min(row_w + 16 * i + 8, p.M - 8);  // (clamped rows are never stored)
+        gl16(r0, r_lane, p.resid + (size_t)m0r * p.ldr + col_w + nh * 32);
+        gl16(r1, r_lane, p.resid + (size_t)m1r * p.ldr + col_w + nh * 32);
       };
       auto put = [&](auto S_) {
         constexpr int st = decltype(S_)::value;
@@ -349,34 +352,32 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
         pw16<0>(pw_addr, acc[i][2 * nh]);
         pw16<64>(pw_addr, acc[i][2 * nh + 1]);
       };
-      f32x4_t seg[2];
-      auto get = [&]() { pr16<0>(pr_addr, seg[0]); pr16<8 * G_PROW>(pr_addr, seg[1]); };
-      auto out = [&](auto S_, f32x4_t (&r)[2]) {
+      f32x4_t seg0, seg1;
+      auto get = [&]() { pr16<0>(pr_addr, seg0); pr16<8 * G_PROW>(pr_addr, seg1); };
+      auto out = [&](auto S_, f32x4_t& r0, f32x4_t& r1) {
         constexpr int st = decltype(S_)::value;
         constexpr int i = st >> 1, nh = st & 1;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int m = row_w + 16 * i + q * 8 + rrow;
-          if (p.resid) { touch(r[q]); seg[q] += r[q]; }
-          if (m < p.M) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + col_w + nh * 32 + rch * 4) = seg[q];
-        }
+        if constexpr (RES) { touch(r0); touch(r1); seg0 += r0; seg1 += r1; }
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)(row_w + 16 * i + rrow) * p.ldc + col_w + nh * 32 + rch * 4;
+        if (row_w + 16 * i + rrow < p.M) *reinterpret_cast<f32x4_t*>(o) = seg0;
+        if (row_w + 16 * i + 8 + rrow < p.M) *reinterpret_cast<f32x4_t*>(o + (size_t)8 * p.ldc) = seg1;
       };
       const bool full = cm0 + G_BM <= p.M;  // a ragged tile's masked stores make the store count unknown: its waits are vmcnt(0)
-      if (p.resid) { rload(IC<0>{}, rb[0]); rload(IC<1>{}, rb[1]); }
+      if constexpr (RES) { rload(IC<0>{}, ra0, ra1); rload(IC<1>{}, rb0, rb1); }
       put(IC<0>{}); get();
-#define G_STEPF(S, CUR, NXT)                                                     \
-      put(IC<S>{}); G_LGKM(2);                                                   \
-      if (p.resid) { if (full && S - 1 >= 1) G_VMCNT(4); else if (full) G_VMCNT(2); else G_VMCNT(0); } \
-      G_SB(); out(IC<S - 1>{}, rb[CUR]); G_SB();                                 \
-      if (p.resid && S + 1 < 16) rload(IC<(S + 1 < 16 ? S + 1 : 0)>{}, rb[CUR]); \
+#define G_STEPF(S, R0, R1)                                                                     \
+      put(IC<S>{}); G_LGKM(2);                                                                 \
+      if constexpr (RES) { if (full) { if (S - 1 >= 1) G_VMCNT(4); else G_VMCNT(2); } else G_VMCNT(0); } \
+      G_SB(); out(IC<S - 1>{}, R0, R1); G_SB();                                                \
+      if constexpr (RES && S + 1 < 16) rload(IC<(S + 1 < 16 ? S + 1 : 0)>{}, R0, R1);          \
       get();
-      G_STEPF(1, 0, 1) G_STEPF(2, 1, 0) G_STEPF(3, 0, 1) G_STEPF(4, 1, 0) G_STEPF(5, 0, 1) G_STEPF(6, 1, 0) G_STEPF(7, 0, 1)
-      G_STEPF(8, 1, 0) G_STEPF(9, 0, 1) G_STEPF(10, 1, 0) G_STEPF(11, 0, 1) G_STEPF(12, 1, 0) G_STEPF(13, 0, 1) G_STEPF(14, 1, 0)
-      G_STEPF(15, 0, 1)
+      G_STEPF(1, ra0, ra1) G_STEPF(2, rb0, rb1) G_STEPF(3, ra0, ra1) G_STEPF(4, rb0, rb1) G_STEPF(5, ra0, ra1) G_STEPF(6, rb0, rb1)
+      G_STEPF(7, ra0, ra1) G_STEPF(8, rb0, rb1) G_STEPF(9, ra0, ra1) G_STEPF(10, rb0, rb1) G_STEPF(11, ra0, ra1) G_STEPF(12, rb0, rb1)
+      G_STEPF(13, ra0, ra1) G_STEPF(14, rb0, rb1) G_STEPF(15, ra0, ra1)
 #undef G_STEPF
       G_LGKM(0);
-      if (p.resid) { if (full) G_VMCNT(2); else G_VMCNT(0); }  // step 15's rows: only step 14's two stores are younger
-      G_SB(); out(IC<15>{}, rb[1]);
+      if constexpr (RES) { if (full) G_VMCNT(2); else G_VMCNT(0); }  // step 15's rows: only step 14's two stores are younger
+      G_SB(); out(IC<15>{}, rb0, rb1);
     }
     G_SB();
   }
@@ -385,13 +386,13 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
 
 int g_enabled = 1;
 
-template <int EPI, bool BF>
+template <int EPI, bool BF, bool RES = false>
 hipError_t launch256(const CsGemmParams& p, hipStream_t st) {
   static bool attr_done[16] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm256_kernel<EPI, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm256_kernel<EPI, BF, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;
     attr_done[dev] = true;
   }
@@ -407,7 +408,7 @@ hipError_t launch256(const CsGemmParams& p, hipStream_t st) {
   const int need = ((tiles_m + 7) / 8) * tiles_n * 8;
   if (grid > need) grid = need;
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((cs_gemm256_kernel<EPI, BF>), dim3(grid), dim3(512), G_LDS, st, p);
+  hipLaunchKernelGGL((cs_gemm256_kernel<EPI, BF, RES>), dim3(grid), dim3(512), G_LDS, st, p);
   return hipGetLastError();
 }
 
@@ -434,7 +435,10 @@ int cs_gemm256_supported(const CsGemmParams* p, int epi) {
 hipError_t cs_gemm256_launch(const CsGemmParams* p, int epi, int bf16, hipStream_t st) {
 #define G_CASE(E) case E: return bf16 ? launch256<E, true>(*p, st) : launch256<E, false>(*p, st);
   switch (epi) {
-    G_CASE(CS_EPI_BIAS_F16) G_CASE(CS_EPI_BIAS_GELU_F16) G_CASE(CS_EPI_BIAS_RELU_F16) G_CASE(CS_EPI_BIAS_LEAKY_F16) G_CASE(CS_EPI_RESID_F32)
+    G_CASE(CS_EPI_BIAS_F16) G_CASE(CS_EPI_BIAS_GELU_F16) G_CASE(CS_EPI_BIAS_RELU_F16) G_CASE(CS_EPI_BIAS_LEAKY_F16)
+    case CS_EPI_RESID_F32:
+      if (p->resid) return bf16 ? launch256<CS_EPI_RESID_F32, true, true>(*p, st) : launch256<CS_EPI_RESID_F32, false, true>(*p, st);
+      return bf16 ? launch256<CS_EPI_RESID_F32, true, false>(*p, st) : launch256<CS_EPI_RESID_F32, false, false>(*p, st);
   }
 #undef G_CASE
   return hipErrorInvalidValue;
