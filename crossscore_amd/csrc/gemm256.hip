@@ -337,14 +337,15 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
       // step t + 1 and the two stores of step t - 1 are younger: vmcnt(4); the DMA pieces issued above are older and have to land first)
       // The loads' destination registers are written when the data arrives, not at the asm statement: nothing may touch them in between
       // (tools/asm_audit.py checks the build's .s for that).
-      [[maybe_unused]] const unsigned r_lane = RES ? (unsigned)((rrow * p.ldr + rch * 4) * 4) : 0u;
       [[maybe_unused]] f32x4_t ra0, ra1, rb0, rb1;
       auto rload = [&](auto S_, f32x4_t& r0, f32x4_t& r1) {
         constexpr int st = decltype(S_)::value;
         constexpr int i = st >> 1, nh = st & 1;
-        const int m0r = min(row_w + 16 * i, p.M - 8), m1r = min(row_w + 16 * i + 8, p.M - 8);  // (clamped rows are never stored)
-        gl16(r0, r_lane, p.resid + (size_t)m0r * p.ldr + col_w + nh * 32);
-        gl16(r1, r_lane, p.resid + (size_t)m1r * p.ldr + col_w + nh * 32);
+        // per-lane row, clamped into the matrix (rows past M are never stored); 32-bit byte offsets: M * ldr * 4 < 2^32 (cs_gemm256_supported)
+        const int m = row_w + 16 * i + rrow;
+        const float* sb = p.resid + col_w + nh * 32;
+        gl16(r0, (unsigned)(min(m, p.M - 1) * p.ldr + rch * 4) * 4u, sb);
+        gl16(r1, (unsigned)(min(m + 8, p.M - 1) * p.ldr + rch * 4) * 4u, sb);
       };
       auto put = [&](auto S_) {
         constexpr int st = decltype(S_)::value;
@@ -427,7 +428,7 @@ int cs_gemm256_supported(const CsGemmParams* p, int epi) {
   if (p->N % G_BN || p->N > G_NMAX || p->K % (2 * G_BK) || p->K < 512 || p->M < G_BM) return 0;
   if (p->lda % 8 || p->ldw % 8 || p->ldc % 8) return 0;
   if ((long long)p->M * p->lda * 2 >= (1ll << 32) || (long long)p->N * p->ldw * 2 >= (1ll << 32)) return 0;
-  if (epi == CS_EPI_RESID_F32 && p->resid && p->ldr % 4) return 0;
+  if (epi == CS_EPI_RESID_F32 && p->resid && (p->ldr % 4 || (long long)p->M * p->ldr * 4 >= (1ll << 32))) return 0;
   if (p->pos || p->pmean || p->out_f16 || p->stats_out || p->ln_part) return 0;
   return 1;
 }

@@ -185,7 +185,7 @@ int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, c
                         uint16_t* u_out, int M, float eps, cs_stream stream);
 /* Kernel selection of cs_op_gemm / the forward's linears (tests and tools; process-wide): 1 (default) = shapes with K >= 512, N a multiple of
  * 256 and M >= 256 run on the 256 x 256 x 64-tile kernel (csrc/gemm256.hip), everything else on the 128-row kernel (csrc/gemm.hip);
- * 0 = the 128-row kernel for every shape.  Results of the two kernels agree to fp32 summation order. */
+ * 0 = the 128-row kernel for every shape.  The two kernels add the same products in the same order: their results are bit-identical (tested). */
 void cs_gemm256_enable(int on);
 /* number of column tiles the GEMM launcher uses for N output columns (LayerNorm partial-sum slots per row = 4 x this) */
 int cs_gemm_column_tiles(int N);

@@ -154,10 +154,9 @@ def test_gemm256_matches_reference_and_small_tile_kernel(M, N, K):
         err = (og.float() - refg).abs()
         assert (err <= 6e-4 * refg.abs() + 3e-4).all(), (on, float((err - 6e-4 * refg.abs()).max()))
         assert (o32 - (y + r)).abs().max() < 3e-4 * max(1.0, math.sqrt(K / 768)), on
-    # the two kernels differ only in fp32 summation order
-    assert (outs[True][2] - outs[False][2]).abs().max() < 2e-4
-    if K % 128 == 0:  # (K = 640 has an odd number of 64-deep K tiles: not a shape of the large-tile kernel, both runs were the small one)
-        assert not torch.equal(outs[True][2], outs[False][2])  # different summation orders: bitwise equality would mean the toggle did nothing
+    # both kernels start the accumulators at the bias and add the 32-deep k-steps of v_mfma_f32_16x16x32 in ascending k: the same fp32 sums
+    assert torch.equal(outs[True][2], outs[False][2])
+    assert torch.equal(outs[True][0], outs[False][0])
 
 
 def _row_partials(x, sp):
