@@ -256,7 +256,10 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
   if (wm == 1) bar();  // the second M half runs one barrier behind the first
 
   // ---- one K tile (buffer B).  kt0: the first K tile of an output tile (its successor's late pieces were issued at the seam) ----
-  auto ktile = [&](auto B_, bool kt0) {
+  // last: the output tile's last K tile.  Its final barrier is left to the caller for the second M half (wm == 1), which then runs its seam
+  // (epilogue) BEFORE that barrier, i.e. beside the first half's seam instead of after it: the halves are one barrier apart, and with
+  // the barrier in its usual place the first half would wait for the second's MFMAs and then the second for the first's whole epilogue.
+  auto ktile = [&](auto B_, bool kt0, bool last) {
     constexpr int B = decltype(B_)::value;
     // phase 1: quadrant (0, 0)
     ld_w(IC<B>{}, IC<0>{}); ld_a(IC<B>{}, IC<0>{});
@@ -274,7 +277,8 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     // phase 4: quadrant (1, 0); the next K tile has landed behind this phase's first barrier (the two pieces just issued stay in flight)
     if (more) { stage(IC<1>{}); G_VMCNT(4); }
     else G_VMCNT(0);
-    bar_then_wait(); mma(IC<1>{}, IC<0>{}); bar();
+    bar_then_wait(); mma(IC<1>{}, IC<0>{});
+    if (!(last && wm == 1)) bar();
   };
 
   for (int idx = slot; idx < ntile_x; idx += slots) {
@@ -282,11 +286,11 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     tile_of(idx, cm0, cn0);
     seam_addresses();
     init_acc(cn0);
-    ktile(IC<0>{}, true);
-    ktile(IC<1>{}, false);
+    ktile(IC<0>{}, true, false);
+    ktile(IC<1>{}, false, false);
     for (int t = 2; t < T; t += 2) {
-      ktile(IC<0>{}, false);
-      ktile(IC<1>{}, false);
+      ktile(IC<0>{}, false, false);
+      ktile(IC<1>{}, false, t + 2 >= T);
     }
     // ---- seam: the late pieces of the next output tile's K tile 1 go out BEFORE this tile's stores ----
     if (l_valid) { stage(IC<2>{}); stage(IC<3>{}); advance(); }
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
       G_SB(); out(IC<15>{}, rb0, rb1);
     }
     G_SB();
+    if (wm == 1) bar();  // (the last K tile's final barrier of the second half)
   }
   if (wm == 0) bar();  // the first half's matching barrier
 }
