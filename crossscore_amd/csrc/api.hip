@@ -195,7 +195,9 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
   p.B = B; p.N = N; p.H = H; p.W = W; p.C = c.hidden;
   p.gh = H / c.patch; p.gw = W / c.patch; p.Np = p.gh * p.gw; p.T = p.Np + 1; p.I = B * (1 + N_enc);
   p.lanes = m->prof ? 1 : (c.lanes <= 0 ? 2 : std::min(c.lanes, CS_MAX_LANES));  // profiling times kernels in isolation
-  int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 24 : 8);  // cfg-2: 2 lanes x 24 images measured best (7.51 vs 7.70 ms with 12)
+  // cfg-2: 2 lanes x 24 images measured best (7.51 vs 7.70 ms with 12).  ViT-B: with the 256-row-tile GEMM (gemm256.hip) a chunk has to hold
+  // many row tiles per CU: cfg-4 449 q/s at 48 or 16 images per chunk, 419 at 6, 407 at 12; cfg-3 247 at 44, 248 at 11 (tools/lanes_sweep_b.py, r3)
+  int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 24 : 48);
   // balanced chunks: a multiple of the lane count, near-equal sizes
   if (c.enc_chunk_images > 0) {
     p.Ic = std::min(ic, p.I);  // explicit: used verbatim (a shorter remainder chunk runs first)
