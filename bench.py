@@ -20,15 +20,17 @@ import subprocess
 import sys
 import time
 
-# One HIP stream per batch in flight and per encoder lane: with the runtime's default of 4 hardware queues, streams created later in a
-# process can share a queue and lose their overlap (measured: the cfg-4 leg ran 60.9 ms / step after the cfg-2 leg, 46.5 ms alone or with
-# 8 queues).  Must be set before the HIP runtime initialises; crossscore_amd/__init__.py sets the same default for library users.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 import torch  # noqa: E402
+
+import crossscore_amd  # noqa: E402
+
+# One HIP stream per batch in flight and per encoder lane: with the runtime's default of 4 hardware queues, streams created later in a
+# process can share a queue and lose their overlap (measured: the cfg-4 leg ran 60.9 ms / step after the cfg-2 leg, 46.5 ms alone or with
+# 8 queues).  An explicit driver-side call, before the HIP runtime initialises (importing the package does not touch the environment).
+crossscore_amd.configure_runtime(hw_queues=8)
 
 from crossscore_amd import synth  # noqa: E402
 from crossscore_amd.config import model_config  # noqa: E402
@@ -240,8 +242,10 @@ def timed_steps(step, sync, steps, warmup, dev):
     for _ in range(steps):
         out = step()
     sync()
+    mine = time.perf_counter() - t0  # this rank's own K steps (reported per rank in `ranks_seen`)
     parallel.barrier()
     elapsed = time.perf_counter() - t0
+    timed_steps.last_rank_seconds = mine
     return parallel.max_over_ranks(elapsed, dev), out
 
 
@@ -305,11 +309,12 @@ def plumbing_test(args, rank, world):
 
     elapsed, _ = timed_steps(step, lambda: None, args.steps, args.warmup, dev)
     means = parallel.gather_means(torch.full((2,), float(rank)), 2 * world)
+    census = parallel.rank_census(dev, ms_per_step=1e3 * timed_steps.last_rank_seconds / args.steps)
     if rank == 0:
         print(json.dumps({"metric": "plumbing-test (stub forward, no GPU work)", "value": world * 8 * args.steps / elapsed,
                           "unit": "stub-items/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * elapsed / args.steps, "data": "stub", "scaling": "weak",
-                          "gathered_means": means.tolist()}), flush=True)
+                          "gathered_means": means.tolist(), "ranks_seen": census, "process_group": parallel.backend_info()}), flush=True)
     parallel.barrier()
     parallel.shutdown()
 
@@ -332,6 +337,7 @@ def main():
                     "one chunk for the whole batch")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (crossscore_amd.pipeline.ForwardPipeline, the predict "
                     "driver's batch loop); 1 = one forward at a time with the library's two encoder lanes")
+    ap.add_argument("--no-repeats", action="store_true", help="skip the four extra K-step regions behind the timed one (value_median_of_5)")
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo rehearsal of the rank plumbing
     args = ap.parse_args()
 
@@ -366,6 +372,15 @@ def main():
     wl.start_pipeline()
     elapsed, ticket = timed_steps(wl.step, sync, args.steps, args.warmup, dev)
     score = wl.pipe.result(ticket)["score_map_ref_cross"]  # the output of the last timed step
+    # who took part: one record per rank (device identity + that rank's own time for the K steps), gathered over the process group
+    census = parallel.rank_census(dev, ms_per_step=1e3 * timed_steps.last_rank_seconds / args.steps)
+    # the timed region is short (K steps of a few ms with batches in flight: pipeline fill / drain and clock ramp are inside it), so
+    # four more K-step regions follow and the median of the five is reported beside `value` (which stays the FIRST region's, per the
+    # bench contract: exactly K timed steps after W warm-up steps)
+    repeats = [elapsed]
+    for _ in range(0 if args.no_repeats else 4):
+        e_r, _t = timed_steps(wl.step, sync, args.steps, 1, dev)
+        repeats.append(e_r)
 
     # ---- BASELINE.json configs[3] (the scaling configuration) on the same ranks: ViT-B/14, 5 refs, 16 items per GPU ----
     cfg4 = None
@@ -408,6 +423,9 @@ def main():
             "metric": wl.metric(),
             "value": value, "unit": "query-images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value_median_of_5": (sorted(world * B * args.steps / e for e in repeats)[len(repeats) // 2] if len(repeats) == 5 else None),
+            "value_repeats": [round(world * B * args.steps / e, 1) for e in repeats],
+            "ranks_seen": census, "process_group": parallel.backend_info(),
             "dtype": "fp16", "data": "synthetic",  # 16-bit MFMA operands (IEEE half, the bf16 MFMA rate), fp32 accumulate / softmax / LayerNorm / output
             "config": {"workload": wl.describe(world),
                        "gflop_per_query": flops_q / 1e9, "parallelism": f"batch-shard x{world} (replicas, no data-path collective); per GPU {wl.inflight} batch(es) in flight x "

@@ -766,7 +766,8 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       a.Q = r1; a.K = r1 + C; a.V = r1 + 2 * C;
       a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
       a.q_bs = a.k_bs = a.v_bs = (long long)p.T * 3 * C; a.o_bs = (long long)p.T * C;
-      a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = 1.0f;  // folded into the Q rows of Wqkv (cs_finalize) a.lse = nullptr;
+      a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = 1.0f;  // folded into the Q rows of Wqkv (cs_finalize)
+      a.lse = nullptr;
       if (h->panel) {
         // u = fp16 normalised rows (norm1 without gamma/beta: folded into Wqkv / c_qkv), written by the previous layer's panel
         // kernel; layer 0 gets it from the LayerNorm kernel

@@ -68,6 +68,44 @@ def max_over_ranks(value: float, device: torch.device | str = "cpu") -> float:
     return float(t.item())
 
 
+def rank_census(device: torch.device | str = "cpu", **extra) -> List[dict]:
+    """One record per rank, gathered on every rank in rank order: who took part in this run.  Each record carries the rank, its
+    LOCAL_RANK, host, pid, the device it is bound to (index, name, PCI bus id and UUID for a GPU) and whatever `extra` the caller adds
+    (bench.py: that rank's own ms per step).  With it "did the collective see N ranks on N distinct GPUs" is answerable from rank 0's
+    JSON line alone (task/predict.py:119-135 scales the same way: one process per device)."""
+    import socket
+
+    rec = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+           "host": socket.gethostname(), "pid": os.getpid(), "device": str(device)}
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        rec.update(device_name=pr.name, pci_bus_id=f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}",
+                   uuid=str(getattr(pr, "uuid", "")))
+    rec.update(extra)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [rec]
+    out: List[dict] = [None] * dist.get_world_size()  # type: ignore[list-item]
+    dist.all_gather_object(out, rec)
+    return out
+
+
+def backend_info() -> dict:
+    """Backend of the process group and the collective library's version (torch.cuda.nccl.version() is RCCL's on ROCm)."""
+    info = {"backend": None, "world_size": 1, "collective_library": None}
+    if dist.is_available() and dist.is_initialized():
+        info["backend"] = str(dist.get_backend())
+        info["world_size"] = dist.get_world_size()
+    if info["backend"] == "nccl":
+        try:
+            info["collective_library"] = "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            info["collective_library"] = f"nccl backend (version query failed: {e})"
+    elif info["backend"] == "gloo":
+        info["collective_library"] = "gloo (CPU rehearsal)"
+    return info
+
+
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

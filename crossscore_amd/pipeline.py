@@ -58,14 +58,14 @@ class ForwardPipeline:
             self.streams: List[Any] = [None]
         else:
             lanes = 1 if lanes is None else lanes
-            if net.lanes != lanes:
-                net.lanes = lanes
-                net._mark_dirty()
-            self.nets = [net] + [_replica(net, lanes) for _ in range(depth - 1)]
+            # the caller's module is never re-configured: when it runs another lane count than the pipeline's replicas, replica 0 is a
+            # module of its own over the same parameters (a plain net(...) call afterwards still runs the caller's two lanes)
+            first = net if net.lanes == lanes else _replica(net, lanes)
+            self.nets = [first] + [_replica(net, lanes) for _ in range(depth - 1)]
             self.streams = self._overlapping_streams(depth)
             # new weights loaded into `net` land in the shared tensors: the replicas must re-pack their fp16 images too
             # (build the pipeline after net.to(device); moving the module afterwards would break the sharing)
-            reps = self.nets[1:]
+            reps = [r for r in self.nets if r is not net]
 
             def _replicas_dirty(module, incompatible):
                 for r in reps:
@@ -79,7 +79,7 @@ class ForwardPipeline:
         queues and two streams that land on one queue serialise (the replicas would then run one after another: measured 9.0
         instead of 6.7 ms per cfg-2 batch); which streams collide depends on what else the process created before.  Each new
         stream is probed against the ones already chosen (cs_op_streams_overlap: a large idle grid beside one idle wave) and replaced until it
-        overlaps with all of them (8 candidates at most)."""
+        overlaps with all of them (8 candidates per stream, 24 probes in all; a failing probe accepts the candidate)."""
         import ctypes as C
 
         from . import _lib
@@ -87,28 +87,37 @@ class ForwardPipeline:
         lib = _lib.load()
         with torch.cuda.device(self.device):
             chosen = [torch.cuda.Stream(device=self.device)]
-            rejected = []  # kept alive until the end: a released pool stream would be handed out again
+            budget = 24  # torch hands streams out of a round-robin pool of 32 per device: stay below one lap
             while len(chosen) < n:
                 cand = torch.cuda.Stream(device=self.device)
                 for _ in range(8):
+                    budget -= 1
                     ok = True
                     for c in chosen:
+                        if cand.cuda_stream == c.cuda_stream:  # the pool wrapped around: the same stream cannot run beside itself
+                            ok = False
+                            break
                         flag = C.c_int(0)
-                        _lib.check(lib.cs_op_streams_overlap(C.c_void_p(c.cuda_stream), C.c_void_p(cand.cuda_stream), C.byref(flag)))
+                        try:
+                            _lib.check(lib.cs_op_streams_overlap(C.c_void_p(c.cuda_stream), C.c_void_p(cand.cuda_stream), C.byref(flag)))
+                        except Exception:  # a set-up heuristic must never take the caller down: accept the candidate
+                            flag.value = 1
                         ok = ok and bool(flag.value)
-                    if ok:
+                    if ok or budget <= 0:
                         break
-                    rejected.append(cand)
+                    cand = torch.cuda.Stream(device=self.device)
+                if any(cand.cuda_stream == c.cuda_stream for c in chosen):  # no distinct stream left: a fresh pool entry, unprobed
                     cand = torch.cuda.Stream(device=self.device)
                 chosen.append(cand)
         return chosen
 
-    def calibrate(self, query_img, ref_cross_imgs, tries: int = 4, steps: int = 6) -> Dict[str, Any]:
+    def calibrate(self, query_img, ref_cross_imgs, tries: int = 4, steps: int = 6, cached: bool = False) -> Dict[str, Any]:
         """The HIP runtime multiplexes streams onto a few hardware queues, and two streams that land on one queue serialise: the
         replicas then run one after another (measured 9.0 instead of 6.7 ms per cfg-2 batch); which streams collide depends on
         what else the process created before.  This times `steps` batches one at a time on replica 0, then in flight on up to
         `tries` fresh sets of streams, and keeps the first set that beats the serial time by 15 % (else the fastest seen).  Call
-        it once, outside any timed region, with inputs of the working shape; returns what it measured."""
+        it once, outside any timed region, with inputs of the working shape; returns what it measured.  cached=True: the second argument
+        holds reference TOKENS (submit_cached: the predict driver's default mode)."""
         if self.depth == 1:
             return {"serial_s": None, "in_flight_s": []}
         import time
@@ -116,7 +125,7 @@ class ForwardPipeline:
         def in_flight(n):
             last = None
             for _ in range(n):
-                last = self.submit(query_img, ref_cross_imgs, False, 0, False)
+                last = self.submit_cached(query_img, ref_cross_imgs) if cached else self.submit(query_img, ref_cross_imgs, False, 0, False)
             self.result(last)
             torch.cuda.synchronize(self.device)
 
@@ -124,7 +133,10 @@ class ForwardPipeline:
         t0 = time.perf_counter()
         with torch.cuda.stream(self.streams[0]):
             for _ in range(steps):
-                self.nets[0](query_img, ref_cross_imgs, False, 0, False)
+                if cached:
+                    self.nets[0].forward_cached(query_img, ref_cross_imgs)
+                else:
+                    self.nets[0](query_img, ref_cross_imgs, False, 0, False)
         torch.cuda.synchronize(self.device)
         serial = (time.perf_counter() - t0) / steps
         seen, best = [], None

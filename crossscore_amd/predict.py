@@ -137,6 +137,8 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
             # (submitted after gather so that the set of cached paths is current; decoding overlaps the forward below)
             pending = (prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool, cached_paths())
                        if batch_idx + 1 < len(batches) else None)
+            if batch_idx == 0 and len(batches) >= 16:  # the same check for the (default) cached mode
+                pipe.calibrate(batch["query/img"], tokens, cached=True)
             ticket = pipe.submit_cached(batch["query/img"], tokens, need_w, head_id)
         n_done += batch["query/img"].shape[0]
         queued.append((ticket, batch, batch_idx))
@@ -158,6 +160,8 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
 
 def main(argv: Optional[Iterable[str]] = None) -> int:
     overrides = list(sys.argv[1:] if argv is None else argv)
+    from . import configure_runtime
+    configure_runtime()  # hardware queues for the batches in flight; before the first HIP call (a no-op afterwards)
     cfg = load_config("default_predict", overrides)
     if cfg.data.dataset.query_dir is None or cfg.data.dataset.reference_dir is None:
         print("usage: python -m crossscore_amd.predict data.dataset.query_dir=<dir> data.dataset.reference_dir=<dir> "

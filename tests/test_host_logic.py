@@ -208,6 +208,24 @@ def test_bench_launches_its_own_ranks_and_takes_the_slowest(tmp_path):
     assert r["n_gpus"] == 2 and r["steps"] == 4 and r["data"] == "stub"
     assert r["ms_per_step"] >= 4.0  # rank 1's stub step sleeps 4 ms, rank 0's 2 ms: the slowest rank sets the time
     assert r["gathered_means"] == [0.0, 0.0, 1.0, 1.0]
+    # the line proves by itself which ranks took part: one record per rank, gathered over the process group
+    seen = r["ranks_seen"]
+    assert [x["rank"] for x in seen] == [0, 1] and [x["local_rank"] for x in seen] == [0, 1]
+    assert len({x["pid"] for x in seen}) == 2 and all(x["ms_per_step"] > 0 for x in seen)
+    assert seen[1]["ms_per_step"] > seen[0]["ms_per_step"]  # rank 1's stub is the slow one
+    assert r["process_group"]["backend"] == "gloo" and r["process_group"]["world_size"] == 2
+
+
+def test_import_does_not_edit_the_environment():
+    """Importing the package must not change process-wide runtime configuration; configure_runtime() is the
+    explicit call, and an explicit setting wins."""
+    code = ("import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import crossscore_amd; "
+            "assert 'GPU_MAX_HW_QUEUES' not in os.environ; assert crossscore_amd.configure_runtime(6); "
+            "assert os.environ['GPU_MAX_HW_QUEUES'] == '6'; os.environ['GPU_MAX_HW_QUEUES'] = '3'; crossscore_amd.configure_runtime(8); "
+            "assert os.environ['GPU_MAX_HW_QUEUES'] == '3'; print('OK')")
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-2000:]
 
 
 def test_bench_refuses_more_gpus_than_visible():
