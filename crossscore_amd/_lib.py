@@ -51,6 +51,7 @@ SYMBOLS = {
     "cs_op_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cs_op_patch_embed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pos_bicubic": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "cs_op_pos_bicubic_ex": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pe_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_score_to_gray16": (_i, [_vp, C.c_longlong, _i, _vp, _vp]),
     "cs_op_score_to_rgb": (_i, [_vp, C.c_longlong, C.c_float, C.c_float, _vp, _vp, _vp]),

@@ -1137,6 +1137,12 @@ int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out
   return 0;
 }
 
+int cs_op_pos_bicubic_ex(const float* pos, int G, int C, int gh, int gw, int legacy, float* out, cs_stream stream) {
+  if (!pos || !out || G <= 0 || C <= 0 || gh <= 0 || gw <= 0) return fail(CS_ERR_BAD_ARG, "pos_bicubic: bad arguments");
+  HIPCHK(cs_pos_bicubic_launch(pos, G, C, gh, gw, legacy ? 0.1f : 0.0f, out, (hipStream_t)stream));
+  return 0;
+}
+
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream) {
   if (!pe || !out || ph <= 0 || pw <= 0 || C <= 0 || gh <= 0 || gw <= 0) return fail(CS_ERR_BAD_ARG, "pe_bilinear: bad arguments");
   HIPCHK(cs_pe_bilinear_launch(pe, ph, pw, C, gh, gw, out, (hipStream_t)stream));

@@ -159,6 +159,9 @@ int cs_op_preprocess_u8(const uint8_t* img, int in_h, int in_w, int in_row_bytes
 int cs_op_score_to_gray16(const float* score, long long n, int signed_range, uint16_t* out, cs_stream stream);
 int cs_op_score_to_rgb(const float* score, long long n, float vmin, float vmax, const uint8_t* lut256x3, uint8_t* out, cs_stream stream);
 int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out, cs_stream stream);
+/* the same with the resize convention as an argument: legacy = 0 F.interpolate(size=(gh, gw)) (cs_op_pos_bicubic), 1 the reference's pinned
+ * transformers 4.33.3 form scale_factor=((gh + 0.1) / G, (gw + 0.1) / G) (cs_config.pos_interp_legacy; golden tests/golden/g6_pos_legacy.npz) */
+int cs_op_pos_bicubic_ex(const float* pos, int G, int C, int gh, int gw, int legacy, float* out, cs_stream stream);
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
 /* fp32 [rows][K] -> fp16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
  * rows of a projection, LayerNorm gamma into its columns */

@@ -166,6 +166,51 @@ def main():
         np.savez_compressed(os.path.join(HERE, "g5_tiny_flags.npz"), seed=5, B=1, N=3, H=70, W=70, **res)
         print("g5 done")
 
+    # G6: the encoder position-embedding resize of the reference's PINNED transformers 4.33.3 (environment.yaml:340), which the installed
+    # 5.x no longer runs: F.interpolate(scale_factor=((h + 0.1) / G, (w + 0.1) / G), mode="bicubic", align_corners=False).  The call
+    # is restated here from the published 4.33.3 source and EXECUTED by the installed torch, (a) on the synthetic position tables of
+    # the three backbones at the grids the path sees, (b) end to end: the imported reference model with its embeddings'
+    # interpolate_pos_encoding replaced by that call (tiny net, 75 x 90 -> 5 x 6 patches, so the branch is live).
+    if want("g6"):
+        import math
+
+        def legacy_table(pos, h, w):  # pos (1, 1 + G*G, C) -> (1 + h*w, C)
+            G2 = pos.shape[1] - 1
+            G = int(math.sqrt(G2))
+            dim = pos.shape[-1]
+            cls_pos, patch_pos = pos[:, 0], pos[:, 1:]
+            patch_pos = patch_pos.reshape(1, G, G, dim).permute(0, 3, 1, 2)
+            patch_pos = torch.nn.functional.interpolate(patch_pos, scale_factor=((h + 0.1) / math.sqrt(G2), (w + 0.1) / math.sqrt(G2)),
+                                                        mode="bicubic", align_corners=False)
+            assert patch_pos.shape[-2:] == (h, w), patch_pos.shape
+            return torch.cat([cls_pos.unsqueeze(0), patch_pos.permute(0, 2, 3, 1).reshape(1, -1, dim)], dim=1)[0]
+
+        res = {}
+        for tag, arch, seed, grids in (("tiny", tiny, 3, [(5, 6), (7, 4)]), ("small", small, 4, [(37, 49), (74, 74), (20, 31)]), ("base", base, 2, [(37, 49)])):
+            pos = torch.from_numpy(synth.make_state_dict(arch, seed)["backbone.embeddings.position_embeddings"])
+            for (h, w) in grids:
+                tab = legacy_table(pos, h, w).numpy()
+                # compact form for the big tables: every 41st position row in full + the mean over channels of every position
+                rows = np.arange(0, tab.shape[0], 1 if tab.shape[0] <= 64 else 41)
+                res[f"table_{tag}_{h}x{w}_rows_idx"] = rows
+                res[f"table_{tag}_{h}x{w}_rows"] = tab[rows]
+                res[f"table_{tag}_{h}x{w}_chmean"] = tab.mean(axis=1, dtype=np.float64).astype(np.float32)
+                res[f"table_{tag}_{h}x{w}_seed"] = np.asarray(seed)
+        _patch_backbone(DC, DM, tiny)
+        net = core.CrossScoreNet(make_cfg(tiny)).eval()
+        sd = synth.make_state_dict(tiny, 31)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        emb = net.backbone.embeddings
+        P = tiny.patch
+        emb.interpolate_pos_encoding = lambda embeddings, height, width: legacy_table(emb.position_embeddings, height // P, width // P)[None]
+        q, r = synth.make_inputs(1, 2, 75, 90, 6)
+        with torch.no_grad():
+            out = net(torch.from_numpy(q), torch.from_numpy(r), False, 0, False)
+            lhs = net.backbone(torch.from_numpy(np.concatenate([q[:, None], r], 1).reshape(3, 3, 75, 90))).last_hidden_state
+        np.savez_compressed(os.path.join(HERE, "g6_pos_legacy.npz"), seed=31, input_seed=6, B=1, N=2, H=75, W=90,
+                            score=out["score_map_ref_cross"].numpy(), last_hidden_state=lhs.numpy(), **res)
+        print("g6 done", out["score_map_ref_cross"].shape, sorted(k for k in res if k.endswith("_rows")))
+
     def big(name, arch, seed, B, N, H, W):
         _, out, dt = run_reference(core, DC, DM, arch, seed, B, N, H, W)
         s = out["score_map_ref_cross"].numpy()

@@ -80,11 +80,14 @@ def im2col(x, P, Kp):
     return out
 
 
-def pos_bicubic(pos, G, gh, gw):
+def pos_bicubic(pos, G, gh, gw, legacy=None):
     lib = _lib.load()
     Cc = pos.shape[-1]
     out = torch.zeros((1 + gh * gw, Cc), dtype=torch.float32, device=pos.device)
-    _lib.check(lib.cs_op_pos_bicubic(_p(pos), G, Cc, gh, gw, _p(out), _stream()))
+    if legacy is None:
+        _lib.check(lib.cs_op_pos_bicubic(_p(pos), G, Cc, gh, gw, _p(out), _stream()))
+    else:
+        _lib.check(lib.cs_op_pos_bicubic_ex(_p(pos), G, Cc, gh, gw, int(legacy), _p(out), _stream()))
     return out
 
 

@@ -128,7 +128,8 @@ def test_cfg1_predict_plumbing_518(tmp_path):
     q = po.preprocess_u8(np.array(Image.open(qd / "frame_00000.png")), (518, 690))[None]
     r = np.stack([po.preprocess_u8(np.array(Image.open(rd / f"frame_{i:05}.png")), (518, 690)) for i in range(5)])[None]
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), False, 0)["score_map_ref_cross"][0].numpy()
+    # (the predict driver's default position-embedding resize is the reference environment's scale_factor form: default_predict.yaml)
+    ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads, pos_interp_legacy=True), torch.from_numpy(q), torch.from_numpy(r), False, 0)["score_map_ref_cross"][0].numpy()
     mae = float(np.abs(got - ref).mean())
     print(json.dumps({"cfg1_score_map_mae_vs_oracle_pipeline": mae, "driver_wall_s": round(t_run, 2), "csv_row": res["rows"][0]}))
     assert mae < MAE_TOL

@@ -20,6 +20,9 @@ MAE_TOL = 1e-3     # the north-star bound
 MAE_TARGET = 2e-4  # SURVEY.md 8c target, asserted on the reference's own goldens and the real backbones
 MAX_TOL = 5e-3     # single-pixel worst case of an fp16-operand forward on peaky synthetic weights (measured 6e-4 - 8e-4)
 TINY = "synthetic/dinov2-tiny"
+# optional attention-probability output (a16): fp16 q / k operands with an fp32 log-sum-exp.  PLACEHOLDER bounds, tightened to 3 x measured below
+AW_MAX_TOL = 2e-2
+AW_L1_TOL = 0.05
 
 
 def _net(backbone, seed, **over):
@@ -52,7 +55,9 @@ def test_tiny_nonsquare_vs_oracle_and_golden(golden_dir):
     assert mae < MAE_TOL and mx < MAX_TOL, (mae, mx)
     aw = out["attn_weights_map_ref_cross"]
     assert aw.shape == (2, 5, 6, 2, 5, 6)
-    assert (aw.cpu() - torch.from_numpy(g["attn_head3"])).abs().max() < 2e-2  # probabilities in [0,1]
+    aw_err = float((aw.cpu() - torch.from_numpy(g["attn_head3"])).abs().max())
+    print(f"g0 head-3 attention probabilities: max abs error {aw_err:.2e}")
+    assert aw_err < AW_MAX_TOL  # probabilities in [0,1]
     assert (aw.reshape(2, 30, -1).sum(-1) - 1).abs().max() < 1e-4
     # need_attn_weights must not change the score map (same kernels, extra output only)
     out2 = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)
@@ -168,8 +173,9 @@ def test_attention_weights_full_size_vs_oracle():
     assert (rows.sum(-1) - 1).abs().max() < 1e-4 and rows.min() >= 0
     ref = _oracle(arch, sd, q, r, need_w=True, head=5)["attn_weights_map_ref_cross"].reshape(1369, -1)
     d = (rows.cpu() - ref).abs()
-    assert float(d.sum(-1).max()) < 0.05, float(d.sum(-1).max())   # total-variation-like distance per row (fp16 logits)
-    assert float(d.max()) < 2e-2
+    print(f"attention probabilities 1369 x 2738: max abs error {float(d.max()):.2e}, max per-row L1 {float(d.sum(-1).max()):.2e}")
+    assert float(d.sum(-1).max()) < AW_L1_TOL, float(d.sum(-1).max())   # total-variation-like distance per row (fp16 logits)
+    assert float(d.max()) < AW_MAX_TOL
 
 
 def test_forward_on_a_side_stream_is_stream_ordered():
@@ -251,6 +257,19 @@ def test_pos_embed_scale_factor_interpolation_option():
     assert float((ref_legacy - ref_size).abs().mean()) > 3 * mae
 
 
+def test_pos_embed_scale_factor_end_to_end_golden():
+    """g6: the imported reference with its embeddings' interpolate_pos_encoding replaced by the pinned 4.33.3 call (torch's
+    F.interpolate(scale_factor=..)); the HIP path with model.backbone.pos_embed_interpolation=scale_factor must match its score map."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_pos_legacy.npz"))
+    net, arch, sd = _net(TINY, int(g["seed"]), **{"backbone.pos_embed_interpolation": "scale_factor"})
+    q, r = synth.make_inputs(int(g["B"]), int(g["N"]), int(g["H"]), int(g["W"]), int(g["input_seed"]))
+    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    mae, mx = _compare(out, torch.from_numpy(g["score"]))
+    assert mae < MAE_TOL and mx < 2 * MAX_TOL, (mae, mx)
+
+
 def test_batch8_vits_matches_oracle_per_item_and_is_batch_invariant():
     """cfg-2 (ViT-S, 518^2, N=5, B=8): item 3 of the batch against the oracle; every item must equal the same item run
     alone (batch shard equivalence: shards are independent, so results are bitwise identical)."""
@@ -261,10 +280,14 @@ def test_batch8_vits_matches_oracle_per_item_and_is_batch_invariant():
     part = net(tq[2:4], tr[2:4], False, 0, False)["score_map_ref_cross"]
     torch.cuda.synchronize()
     assert torch.equal(full[2:4], part)
-    ref = _oracle(arch, sd, q[3:4], r[3:4])["score_map_ref_cross"]
-    mae, mx = _compare(full[3:4], ref)
-    print(f"cfg-2 item 3: MAE={mae:.2e} max={mx:.2e}")
-    assert mae < MAE_TOL and mx < MAX_TOL
+    for i in range(8):  # EVERY item alone (a one-item shard: other chunking, other panel / tile boundaries) gives the same bits
+        alone = net(tq[i:i + 1], tr[i:i + 1], False, 0, False)["score_map_ref_cross"]
+        assert torch.equal(full[i:i + 1], alone), i
+    for i in (0, 3, 7):  # first, middle and last item of the batch against the fp32 oracle
+        ref = _oracle(arch, sd, q[i:i + 1], r[i:i + 1])["score_map_ref_cross"]
+        mae, mx = _compare(full[i:i + 1], ref)
+        print(f"cfg-2 item {i}: MAE={mae:.2e} max={mx:.2e}")
+        assert mae < MAE_TARGET and mx < MAX_TOL, (i, mae, mx)
     # determinism: two runs bitwise equal
     again = net(tq, tr, False, 0, False)["score_map_ref_cross"]
     assert torch.equal(full, again)

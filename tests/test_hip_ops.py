@@ -497,6 +497,24 @@ def test_pos_bicubic(G, gh, gw):
     assert (out.cpu() - ref).abs().max() < 3e-5  # fp32, different summation order of the 16 taps
 
 
+@pytest.mark.parametrize("tag,backbone,h,w", [("tiny", "synthetic/dinov2-tiny", 5, 6), ("tiny", "synthetic/dinov2-tiny", 7, 4),
+                                              ("small", "facebook/dinov2-small", 37, 49), ("small", "facebook/dinov2-small", 74, 74),
+                                              ("small", "facebook/dinov2-small", 20, 31), ("base", "facebook/dinov2-base", 37, 49)])
+def test_pos_bicubic_legacy_matches_torch_scale_factor_golden(tag, backbone, h, w):
+    """The scale_factor convention of the reference's pinned transformers 4.33.3 (cs_config.pos_interp_legacy): the kernel's table against
+    tests/golden/g6_pos_legacy.npz = torch's F.interpolate(scale_factor=((h + 0.1) / G, (w + 0.1) / G), bicubic) on the synthetic tables."""
+    import os
+    from crossscore_amd import synth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_pos_legacy.npz"))
+    arch = synth.BACKBONES[backbone]
+    pos = _t(synth.make_state_dict(arch, int(g[f"table_{tag}_{h}x{w}_seed"]))["backbone.embeddings.position_embeddings"][0])
+    out = hh.pos_bicubic(pos, arch.pos_grid, h, w, legacy=True).cpu().numpy()
+    assert np.abs(out[g[f"table_{tag}_{h}x{w}_rows_idx"]] - g[f"table_{tag}_{h}x{w}_rows"]).max() < 3e-5
+    assert np.abs(out.mean(axis=1, dtype=np.float64) - g[f"table_{tag}_{h}x{w}_chmean"]).max() < 3e-6
+    out_size = hh.pos_bicubic(pos, arch.pos_grid, h, w, legacy=False).cpu().numpy()
+    assert np.abs(out_size - out).max() > 1e-3  # the two conventions differ: the switch is live
+
+
 @pytest.mark.parametrize("gh,gw", [(37, 37), (5, 6), (74, 74), (37, 49)])
 def test_pe_bilinear(gh, gw):
     Cc = 64

@@ -216,6 +216,17 @@ def test_bench_launches_its_own_ranks_and_takes_the_slowest(tmp_path):
     assert r["process_group"]["backend"] == "gloo" and r["process_group"]["world_size"] == 2
 
 
+def test_predict_config_defaults_to_the_reference_environments_pos_embed_resize():
+    """default_predict.yaml (the config of the task/predict.py stand-in) selects the scale_factor form of the pinned transformers 4.33.3;
+    a bare model config keeps the installed release's size form; an override wins."""
+    from crossscore_amd.config import load_config
+    assert load_config("default_predict").model.backbone.pos_embed_interpolation == "scale_factor"
+    assert load_config("default_predict").model.backbone.from_pretrained == "facebook/dinov2-small"  # (the group's keys survive the merge)
+    assert "pos_embed_interpolation" not in model_config().model.backbone
+    assert load_config("default_predict", ["model.backbone.pos_embed_interpolation=size"]).model.backbone.pos_embed_interpolation == "size"
+    assert CrossScoreNet(load_config("default_predict"))._pos_legacy and not CrossScoreNet(model_config())._pos_legacy
+
+
 def test_import_does_not_edit_the_environment():
     """Importing the package must not change process-wide runtime configuration; configure_runtime() is the
     explicit call, and an explicit setting wins."""

@@ -84,13 +84,45 @@ def test_full_size_goldens(golden_dir, name, backbone):
     _compact_check(g, out["score_map_ref_cross"].numpy())
 
 
-@pytest.mark.skipif(not os.environ.get("CS_SLOW"), reason="ViT-B / 1036^2 oracle runs take ~10-20 s each; set CS_SLOW=1")
 @pytest.mark.parametrize("name,backbone", [
     ("g2_vitb_518_n10", "facebook/dinov2-base"),
     ("g3_vits_1036_n5", "facebook/dinov2-small"),
 ])
-def test_full_size_goldens_slow(golden_dir, name, backbone):
+def test_full_size_goldens_vitb_and_1036(golden_dir, name, backbone):
+    """ViT-B / 1036^2 pins of the oracle (10-20 s each on 8 cores): part of the default CPU suite (they used to hide behind CS_SLOW)."""
     test_full_size_goldens(golden_dir, name, backbone)
+
+
+G6_TABLES = [("tiny", "synthetic/dinov2-tiny", 5, 6), ("tiny", "synthetic/dinov2-tiny", 7, 4), ("small", "facebook/dinov2-small", 37, 49),
+             ("small", "facebook/dinov2-small", 74, 74), ("small", "facebook/dinov2-small", 20, 31), ("base", "facebook/dinov2-base", 37, 49)]
+
+
+@pytest.mark.parametrize("tag,backbone,h,w", G6_TABLES)
+def test_legacy_pos_embed_table_matches_torch_scale_factor_golden(golden_dir, tag, backbone, h, w):
+    """The scale_factor form of the encoder position-embedding resize (the reference's pinned transformers 4.33.3, environment.yaml:340):
+    g6 holds F.interpolate(scale_factor=((h + 0.1) / G, (w + 0.1) / G), bicubic, align_corners=False) executed by torch on the synthetic
+    tables; the oracle's restatement (encoder_pos_embed(legacy=True)) must reproduce it."""
+    g = _golden(golden_dir, "g6_pos_legacy.npz")
+    arch = synth.BACKBONES[backbone]
+    W = orc.to_torch(synth.make_state_dict(arch, int(g[f"table_{tag}_{h}x{w}_seed"])))
+    tab = orc.encoder_pos_embed(W, h, w, 14 * h, 14 * w + 1, legacy=True).numpy()  # (H != W: the resize branch even on the native grid)
+    assert np.abs(tab[g[f"table_{tag}_{h}x{w}_rows_idx"]] - g[f"table_{tag}_{h}x{w}_rows"]).max() < 2e-6
+    assert np.abs(tab.mean(axis=1, dtype=np.float64) - g[f"table_{tag}_{h}x{w}_chmean"]).max() < 2e-6
+    # and the two conventions really differ (the switch is live)
+    tab_size = orc.encoder_pos_embed(W, h, w, 14 * h, 14 * w + 1, legacy=False).numpy()
+    assert np.abs(tab_size - tab).max() > 1e-3
+
+
+def test_legacy_pos_embed_end_to_end_golden(golden_dir):
+    """g6 end to end: the imported reference with its embeddings' interpolate_pos_encoding replaced by the 4.33.3 call (tiny net,
+    75 x 90 -> 5 x 6 patches); the oracle with pos_interp_legacy=True must match its last_hidden_state and score map."""
+    g = _golden(golden_dir, "g6_pos_legacy.npz")
+    W = orc.to_torch(synth.make_state_dict(TINY, int(g["seed"])))
+    q, r = synth.make_inputs(int(g["B"]), int(g["N"]), int(g["H"]), int(g["W"]), int(g["input_seed"]))
+    out = orc.forward(W, dict(enc_heads=TINY.enc_heads, pos_interp_legacy=True), torch.from_numpy(q), torch.from_numpy(r))
+    assert np.abs(out["score_map_ref_cross"].numpy() - g["score"]).max() < TOL
+    out_size = orc.forward(W, dict(enc_heads=TINY.enc_heads), torch.from_numpy(q), torch.from_numpy(r))
+    assert np.abs(out_size["score_map_ref_cross"].numpy() - g["score"]).max() > 10 * TOL
 
 
 def test_regression_layer_config_errors():

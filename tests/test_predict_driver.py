@@ -160,7 +160,7 @@ def test_predict_run_matches_oracle_pipeline(tmp_path, colour_mode):
     means = []
     for i, qp in enumerate(sorted(os.listdir(qd))):
         q = po.preprocess_u8(np.array(Image.open(os.path.join(qd, qp))), (56, 67))[None]
-        score = orc.forward(W, dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), False, 0)["score_map_ref_cross"][0].numpy()
+        score = orc.forward(W, dict(enc_heads=arch.enc_heads, pos_interp_legacy=True), torch.from_numpy(q), torch.from_numpy(r), False, 0)["score_map_ref_cross"][0].numpy()
         means.append(float(score.mean()))
         B, b = divmod(i, 2)
         name = f"r0_B{B:04}_b{b:03}_s00001_test_ours_1000_renders_frame_{i:05}.png"

@@ -36,7 +36,7 @@ q = po.preprocess_u8(np.array(Image.open(os.path.join(qd, "frame_00000.png"))), 
 r = np.stack([po.preprocess_u8(np.array(Image.open(os.path.join(rd, f"frame_{i:05}.png"))), (518, 690)) for i in range(5)])[None]
 torch.set_num_threads(min(os.cpu_count() or 1, 32))
 t0 = time.perf_counter()
-ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), False, 0)["score_map_ref_cross"][0].numpy()
+ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads, pos_interp_legacy=True), torch.from_numpy(q), torch.from_numpy(r), False, 0)["score_map_ref_cross"][0].numpy()
 t_cpu = time.perf_counter() - t0
 print(json.dumps({"workload": "cfg1 plumbing: 1 query + 5 refs, 540x720 PNG -> 518x690, ViT-S, via crossscore_amd.predict",
                   "score_map_shape": list(got.shape), "score_map_mae_vs_oracle_pipeline": float(np.abs(got - ref).mean()),
