@@ -22,6 +22,7 @@ class CsConfig(C.Structure):
         ("patch", C.c_int), ("pos_grid", C.c_int), ("pe_h", C.c_int), ("pe_w", C.c_int),
         ("dec_layers", C.c_int), ("dec_heads", C.c_int), ("do_self_attn", C.c_int), ("do_short_cut", C.c_int),
         ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int), ("ln_fold", C.c_int), ("lanes", C.c_int), ("pos_interp_legacy", C.c_int), ("enc_fused", C.c_int),
+        ("operand_dtype", C.c_int), ("skip_finite_check", C.c_int),
     ]
 
 
@@ -40,6 +41,8 @@ SYMBOLS = {
     "cs_encode_references": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "cs_forward_cached": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "cs_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "cs_nonfinite_count": (_i, [_vp, C.POINTER(C.c_longlong)]),
+    "cs_op_set_operand_dtype": (_i, [_i]),
     "cs_profile_enable": (_i, [_vp, _i]),
     "cs_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "cs_profile_read_bytes": (_i, [_vp, _i, C.POINTER(C.c_double)]),

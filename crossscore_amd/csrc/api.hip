@@ -21,21 +21,22 @@ hipError_t cs_gemm_launch(const CsGemmParams* p, int epi, hipStream_t stream);
 const char* cs_attn_check(const CsAttnParams* p, int dh, int batch);
 hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, hipStream_t stream);
 hipError_t cs_im2col_launch(const float* q, const float* refs, int N, int img0, h16_t* out, int I, int H, int W, int P, int Kp,
-                            float* pmean, hipStream_t st);
+                            float* pmean, int bf, hipStream_t st);
 hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipStream_t st);
 hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32, h16_t* obf,
-                               hipStream_t st);
+                               int bf, hipStream_t st);
 hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
-                                    const float* pe, float* q_f32, h16_t* q_bf, h16_t* mem_bf, hipStream_t st);
+                                    const float* pe, float* q_f32, h16_t* q_bf, h16_t* mem_bf, int bf, hipStream_t st);
 hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, h16_t* xb, float* stats, int sp,
-                              hipStream_t st);
+                              int bf, hipStream_t st);
 hipError_t cs_ln_fold_consts_launch(const h16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
                                     float* s_out, float* c_out, hipStream_t st);
 int cs_gemm_column_tiles(int N);
 hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float grow, float* out, hipStream_t st);
 hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st);
 hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
-                               hipStream_t st);
+                               int bf, hipStream_t st);
+hipError_t cs_score_check_launch(const float* score, size_t n, unsigned* counter, hipStream_t st);
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
 hipError_t cs_spin_launch(unsigned long long ticks, int blocks, int lds_bytes, hipStream_t st);
 constexpr float LOG2E = 1.4426950408889634f;
@@ -46,7 +47,7 @@ hipError_t cs_score_rgb_launch(const float* score, size_t n, float vmin, float v
 int cs_panel_supported(int C, int mlp_ratio);
 size_t cs_panel_image_bytes(int with_outproj);
 hipError_t cs_panel_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
-                                h16_t* img, hipStream_t st);
+                                h16_t* img, int bf16, hipStream_t st);
 const char* cs_panel_check(const CsPanelParams* p);
 hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st);
 hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int oh,
@@ -127,6 +128,7 @@ struct cs_model {
   hipStream_t last_stream = nullptr; hipEvent_t ev_done = nullptr;  // ordering of calls that arrive on different streams
   hipEvent_t ev_kv0 = nullptr, ev_kv1 = nullptr;                    // decoder: K/V projection on a side stream
   hipEvent_t ev_fork = nullptr, ev_join[CS_MAX_LANES] = {}, ev_stag[CS_MAX_LANES] = {};
+  unsigned* nonfinite = nullptr;  // device counter: non-finite score-map values seen since the last cs_nonfinite_count
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -252,6 +254,7 @@ struct Launcher {
     if (rc) return false;
     if (const char* e = cs_gemm_check(&g, epi)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
     g.bpc = bpc;
+    g.bf16 = m->cfg.operand_dtype;
     // algorithmic HBM bytes of one launch: A and W once (fp16), bias, the output once, the residual / position addend once
     const double mn = (double)g.M * g.N;
     const bool f32out = epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32 || epi == CS_EPI_HEAD_SCORE;
@@ -266,6 +269,7 @@ struct Launcher {
   }
   bool attn(CsAttnParams a, int dh, int batch) {
     if (rc) return false;
+    a.bf16 = m->cfg.operand_dtype;
     if (const char* e = cs_attn_check(&a, dh, batch)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
     // Q and O once, K and V once per (batch, head): 2 bytes each
     begin(16 + dh / 16, 4.0 * batch * a.heads * (double)a.Lq * a.Lk * dh, 2.0 * batch * a.heads * dh * (2.0 * a.Lq + 2.0 * a.Lk));
@@ -274,8 +278,9 @@ struct Launcher {
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "attention launch: %s", hipGetErrorString(e)); return false; }
     return true;
   }
-  bool panel(const CsPanelParams& q) {
+  bool panel(CsPanelParams q) {
     if (rc) return false;
+    q.bf16 = m->cfg.operand_dtype;
     if (const char* e = cs_panel_check(&q)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
     const double M = q.M, C = m->cfg.hidden, F = (double)m->cfg.mlp_ratio * C;
     // algorithmic bytes: x read + written (fp32), attention output read, u written (fp16), the weight stream once
@@ -362,6 +367,8 @@ cs_handle cs_create(const cs_config* cfg) {
   if (c.dec_layers <= 0 || c.patch <= 0 || (c.patch * c.patch) % 4 || c.pos_grid <= 0 || c.pe_h <= 0 || c.pe_w <= 0 || c.mlp_ratio <= 0) { fail(CS_ERR_BAD_ARG, "bad config"); return nullptr; }
   if (c.act != 0 && c.act != 1) { fail(CS_ERR_BAD_ARG, "act must be 0 (sigmoid) or 1 (tanh)"); return nullptr; }
   if (c.act == 1 && c.pow_p != 1.0f) { fail(CS_ERR_BAD_ARG, "power factor applies only to the sigmoid range"); return nullptr; }
+  if (c.operand_dtype != 0 && c.operand_dtype != 1) { fail(CS_ERR_BAD_ARG, "operand_dtype must be 0 (fp16) or 1 (bf16)"); return nullptr; }
+  if (c.operand_dtype == 1 && c.ln_fold == 1) { fail(CS_ERR_UNSUPPORTED, "the LayerNorm-folded epilogues (ln_fold = 1) are built for fp16 operands only"); return nullptr; }
   cs_model* m = new cs_model();
   m->cfg = c;
   m->names = expected_names(c);
@@ -392,6 +399,7 @@ void cs_destroy(cs_handle h) {
     if (h->ev_stag[l]) hipEventDestroy(h->ev_stag[l]);
   }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->nonfinite) hipFree(h->nonfinite);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   delete h;
 }
@@ -457,7 +465,7 @@ int cs_finalize(cs_handle h) {
   hipStream_t st = nullptr;
   auto pack = [&](const float* src, int rows, int K, int ldo, h16_t* dst, const float* row_scale = nullptr,
                   const float* col_scale = nullptr) -> int {
-    HIPCHK(cs_pack_f16_launch(src, rows, K, dst, ldo, row_scale, col_scale, st));
+    HIPCHK(cs_pack_f16_launch(src, rows, K, dst, ldo, row_scale, col_scale, c.operand_dtype, st));
     return 0;
   };
   auto alloc_bf = [&](size_t n) -> h16_t* { void* p = nullptr; if (hipMalloc(&p, n * sizeof(h16_t)) != hipSuccess) return nullptr; h->owned.push_back(p); return (h16_t*)p; };
@@ -523,7 +531,7 @@ int cs_finalize(cs_handle h) {
     L.panel_img = nullptr;
     if (h->panel) {
       ALLOC_BF(img, cs_panel_image_bytes(1) / sizeof(h16_t))
-      HIPCHK(cs_panel_pack_launch(ow->d, l1->d, f1w->d, n2w->d, f2w->d, l2->d, img, st));
+      HIPCHK(cs_panel_pack_launch(ow->d, l1->d, f1w->d, n2w->d, f2w->d, l2->d, img, c.operand_dtype, st));
       L.panel_img = img;
     }
     if (fold) {
@@ -589,6 +597,10 @@ int cs_finalize(cs_handle h) {
     ALLOC_BF(w0, (size_t)C * C) if (int r = pack(h0w->d, (int)C, (int)C, (int)C, w0)) return r;
     ALLOC_BF(w2, (size_t)PP * C) if (int r = pack(h2w->d, (int)PP, (int)C, (int)C, w2)) return r;
     h->Wh0 = w0; h->bh0 = h0b->d; h->Wh2 = w2; h->bh2 = h2b->d;
+  }
+  if (!h->nonfinite) {
+    HIPCHK(hipMalloc(&h->nonfinite, 16));
+    HIPCHK(hipMemset(h->nonfinite, 0, 16));
   }
   HIPCHK(hipDeviceSynchronize());
   // fp32 copies of the big matrices are no longer needed
@@ -683,6 +695,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   const int enc_dh = C / c.enc_heads, dec_dh = C / c.dec_heads;
   const int F = c.mlp_ratio * C;
   const int KV = 2 * C * c.dec_layers;
+  const int bf = c.operand_dtype;  // 16-bit operand type of every activation buffer and packed weight: 0 IEEE half, 1 bfloat16
 
   // ---- lanes: fork from the caller's stream, join back before returning (everything stays stream-ordered on `st`) ----
   const int NL = p.lanes;
@@ -743,11 +756,11 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     // patches are mean-centred per channel before the fp16 rounding; the patch GEMM adds mean * sum(W) back in fp32
     float* pmean = p.pmean[slot];
     if (stage == -1) {
-    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, pmean, s), "im2col"); L.end();
+    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, pmean, bf, s), "im2col"); L.end();
     const bool fold = h->lnfold;
     h16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
     L.begin(32, 0);
-    L.misc(cs_cls_rows_launch(x, ic, p.T, C, h->cls, h->pos_tab, fold ? u : nullptr, fold ? stats : nullptr, h->ln_sp, s), "cls");
+    L.misc(cs_cls_rows_launch(x, ic, p.T, C, h->cls, h->pos_tab, fold ? u : nullptr, fold ? stats : nullptr, h->ln_sp, bf, s), "cls");
     L.end();
     {
       CsGemmParams g = gp(r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, x, C);
@@ -763,6 +776,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       const EncLayer& E = h->enc[l];
       const bool last = l == c.enc_layers - 1;
       CsAttnParams a{};
+      a.bf16 = bf;
       a.Q = r1; a.K = r1 + C; a.V = r1 + 2 * C;
       a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
       a.q_bs = a.k_bs = a.v_bs = (long long)p.T * 3 * C; a.o_bs = (long long)p.T * C;
@@ -771,7 +785,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       if (h->panel) {
         // u = fp16 normalised rows (norm1 without gamma/beta: folded into Wqkv / c_qkv), written by the previous layer's panel
         // kernel; layer 0 gets it from the LayerNorm kernel
-        if (l == 0) { L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, h->ones, h->zeros, 1e-6f, nullptr, u, s), "ln1"); L.end(); }
+        if (l == 0) { L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, h->ones, h->zeros, 1e-6f, nullptr, u, bf, s), "ln1"); L.end(); }
         L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C), CS_EPI_BIAS_F16);
         a.O = u;
         L.attn(a, enc_dh, ic);
@@ -809,7 +823,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         }
         continue;
       }
-      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, u, s), "ln1"); L.end();
+      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, u, bf, s), "ln1"); L.end();
       L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.bqkv, r1, 3 * C), CS_EPI_BIAS_F16);
       a.O = u;
       L.attn(a, enc_dh, ic);
@@ -818,7 +832,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         g.resid = x; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
-      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, u, s), "ln2"); L.end();
+      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, u, bf, s), "ln2"); L.end();
       L.gemm(gp(u, C, E.W1, C, Mc, F, C, E.b1, r1, F), CS_EPI_BIAS_GELU_F16);
       {
         CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);
@@ -829,7 +843,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     if (stage != c.enc_layers) return;
     L.begin(32, 0);
     L.misc(cs_final_ln_split_launch(x, ic, i0, p.Np, C, mode == 2 ? -1 : N_enc, h->lnfg, h->lnfb, 1e-6f, h->pe_tab, p.xq, p.q_bf,
-                                    mode == 2 ? tokens_out : p.mem_bf, s), "final_ln");
+                                    mode == 2 ? tokens_out : p.mem_bf, bf, s), "final_ln");
     L.end();
   };
 
@@ -862,6 +876,8 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       if (c.do_self_attn) {
         L.gemm(gp(q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_F16);
         CsAttnParams a{};
+        a.bf16 = bf;
+      a.bf16 = bf;
         a.Q = dqkv; a.K = dqkv + C; a.V = dqkv + 2 * C; a.O = dob;
         a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
         a.q_bs = a.k_bs = a.v_bs = (long long)p.Np * 3 * C; a.o_bs = (long long)p.Np * C;
@@ -870,11 +886,12 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         CsGemmParams g = gp(dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, y, C);
         g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
-        L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n1g, D.n1b, 1e-5f, xq, q_bf, s), "norm1"); L.end();
+        L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n1g, D.n1b, 1e-5f, xq, q_bf, bf, s), "norm1"); L.end();
       }
       if (kv_side && l == 0 && !L.rc && hipStreamWaitEvent(s, h->ev_kv1, 0) != hipSuccess) L.rc = CS_ERR_HIP;
       L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_F16);
       CsAttnParams a{};
+      a.bf16 = bf;
       a.Q = dq; a.K = kv + (size_t)l * 2 * C; a.V = kv + (size_t)l * 2 * C + C; a.O = dob;
       a.ldq = C; a.ldk = a.ldv = KV; a.ldo = C;
       a.q_bs = (long long)p.Np * C; a.k_bs = a.v_bs = (long long)N * p.Np * KV; a.o_bs = (long long)p.Np * C;
@@ -892,14 +909,14 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
-      L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n2g, D.n2b, 1e-5f, xq, q_bf, s), "norm2"); L.end();
+      L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n2g, D.n2b, 1e-5f, xq, q_bf, bf, s), "norm2"); L.end();
       L.gemm(gp(q_bf, C, D.l1W, C, M, C, C, D.l1b, dhid, C), CS_EPI_BIAS_RELU_F16);
       {
         CsGemmParams g = gp(dhid, C, D.l2W, C, M, C, C, D.l2b, y, C);
         g.resid = xq; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
-      L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n3g, D.n3b, 1e-5f, xq, q_bf, s), "norm3"); L.end();
+      L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n3g, D.n3b, 1e-5f, xq, q_bf, bf, s), "norm3"); L.end();
     }
     // head + RegressionLayer + jigsaw (cross_reference.py:45-50,82-87)
     L.gemm(gp(q_bf, C, h->Wh0, C, M, C, C, h->bh0, dhid, C), CS_EPI_BIAS_LEAKY_F16);
@@ -952,6 +969,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     if (LD.rc) return LD.rc;
   }
   Launcher L{h, st};
+  if (!c.skip_finite_check) L.misc(cs_score_check_launch(score_out, (size_t)B * p.gh * P * p.gw * P, h->nonfinite, st), "score_check");
   if (mean_out) {
     L.begin(32, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();
   }
@@ -1021,9 +1039,30 @@ int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, do
   return 0;
 }
 
+// Non-finite values the score maps of this handle's forwards held since the last call (and resets the count).  Waits for the handle's
+// last forward (an explicit check, not part of the hot loop): an fp16 operand that overflowed upstream reaches the output as NaN.
+int cs_nonfinite_count(cs_handle h, long long* count) {
+  if (!h || !count) return fail(CS_ERR_BAD_ARG, "null argument");
+  *count = 0;
+  if (!h->nonfinite) return 0;
+  if (h->ev_done) HIPCHK(hipEventSynchronize(h->ev_done));
+  unsigned v = 0;
+  HIPCHK(hipMemcpy(&v, h->nonfinite, sizeof v, hipMemcpyDeviceToHost));
+  if (v) HIPCHK(hipMemset(h->nonfinite, 0, sizeof v));
+  *count = (long long)v;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // single-op entry points
 // ---------------------------------------------------------------------------------------------------------
+static int g_op_bf16 = 0;  // operand type of the cs_op_* entry points below (a handle carries its own: cs_config.operand_dtype)
+int cs_op_set_operand_dtype(int dtype) {
+  if (dtype != 0 && dtype != 1) return fail(CS_ERR_BAD_ARG, "operand dtype must be 0 (fp16) or 1 (bf16)");
+  g_op_bf16 = dtype;
+  return 0;
+}
+
 int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
                const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np, int gw, int P, int act,
                float powp, uint16_t* out_f16, float* stats_out, int stats_sp, const float* ln_part, int ln_sp, const float* col_s,
@@ -1032,6 +1071,7 @@ int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, in
   g.out_f16 = out_f16; g.stats_out = stats_out; g.stats_sp = stats_sp; g.ln_part = ln_part; g.ln_sp = ln_sp; g.col_s = col_s;
   g.ln_eps = ln_eps;
   g.resid = resid; g.ldr = ldr; g.pos = pos; g.Np = Np; g.gw = gw; g.P = P; g.act = act; g.powp = powp;
+  g.bf16 = g_op_bf16;
   if (epi < 0 || epi > CS_EPI_RESID_F32_LN) return fail(CS_ERR_BAD_ARG, "gemm: unknown epilogue %d", epi);
   if (const char* e = cs_gemm_check(&g, epi)) return fail(CS_ERR_BAD_ARG, "%s", e);
   HIPCHK(cs_gemm_launch(&g, epi, (hipStream_t)stream));
@@ -1046,6 +1086,7 @@ int cs_op_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* V, uin
   a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs; a.Lq = Lq; a.Lk = Lk; a.heads = heads;
   if (!(q_scale >= 0.f)) return fail(CS_ERR_BAD_ARG, "attention: q_scale must be >= 0 (0 = log2(e)/sqrt(dh))");
   a.scale_log2e = q_scale == 0.f ? LOG2E / std::sqrt((float)dh) : q_scale; a.lse = lse;
+  a.bf16 = g_op_bf16;
   if (const char* e = cs_attn_check(&a, dh, batch)) return fail(CS_ERR_BAD_ARG, "%s", e);
   HIPCHK(cs_attn_launch(&a, dh, batch, (hipStream_t)stream));
   return 0;
@@ -1058,6 +1099,7 @@ int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int l
   CsAttnParams a{};
   a.Q = Q; a.K = K; a.ldq = ldq; a.ldk = ldk; a.q_bs = q_bs; a.k_bs = k_bs; a.Lq = Lq; a.Lk = Lk; a.heads = heads;
   a.scale_log2e = q_scale == 0.f ? LOG2E / std::sqrt((float)dh) : q_scale; a.lse = const_cast<float*>(lse);
+  a.bf16 = g_op_bf16;
   HIPCHK(cs_attn_weights_launch(&a, dh, batch, head, out, (hipStream_t)stream));
   return 0;
 }
@@ -1065,13 +1107,13 @@ int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int l
 int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
                     uint16_t* out_f16, cs_stream stream) {
   if (!x || !gamma || !beta || M <= 0 || C <= 0 || C % 4 || C > 1024) return fail(CS_ERR_BAD_ARG, "layernorm: C must be a multiple of 4 and <= 1024");
-  HIPCHK(cs_layernorm_launch(x, M, C, gamma, beta, eps, out_f32, out_f16, (hipStream_t)stream));
+  HIPCHK(cs_layernorm_launch(x, M, C, gamma, beta, eps, out_f32, out_f16, g_op_bf16, (hipStream_t)stream));
   return 0;
 }
 
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream) {
   if (!x || !out || I <= 0 || P <= 0 || H < P || W < P || Kp % 8 || Kp < 3 * P * P) return fail(CS_ERR_BAD_ARG, "im2col: bad arguments");
-  HIPCHK(cs_im2col_launch(x, nullptr, 0, 0, out, I, H, W, P, Kp, nullptr, (hipStream_t)stream));
+  HIPCHK(cs_im2col_launch(x, nullptr, 0, 0, out, I, H, W, P, Kp, nullptr, g_op_bf16, (hipStream_t)stream));
   return 0;
 }
 
@@ -1091,12 +1133,12 @@ int cs_op_patch_embed(const float* x, const float* w, const float* bias, const f
   HIPCHK(hipMalloc(&wsum, (size_t)3 * C * sizeof(float)));
   int rc = 0;
   auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = fail(CS_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
-  chk(cs_pack_f16_launch(w, C, 3 * P * P, Wp, Kp, nullptr, nullptr, st), "pack");
+  chk(cs_pack_f16_launch(w, C, 3 * P * P, Wp, Kp, nullptr, nullptr, g_op_bf16, st), "pack");
   chk(cs_patch_wsum_launch(w, C, P, wsum, st), "wsum");
-  chk(cs_im2col_launch(x, nullptr, 0, 0, A, I, H, W, P, Kp, centred ? pmean : nullptr, st), "im2col");
+  chk(cs_im2col_launch(x, nullptr, 0, 0, A, I, H, W, P, Kp, centred ? pmean : nullptr, g_op_bf16, st), "im2col");
   if (!rc) {
     CsGemmParams g = gp(A, Kp, Wp, Kp, I * Np, C, Kp, bias, out, C);
-    g.pos = pos; g.Np = Np;
+    g.pos = pos; g.Np = Np; g.bf16 = g_op_bf16;
     if (centred) { g.pmean = pmean; g.wsum = wsum; }
     if (const char* e = cs_gemm_check(&g, CS_EPI_PATCH_F32)) rc = fail(CS_ERR_BAD_ARG, "%s", e);
     else chk(cs_gemm_launch(&g, CS_EPI_PATCH_F32, st), "gemm");
@@ -1160,14 +1202,14 @@ int cs_op_streams_overlap(cs_stream a, cs_stream b, int* overlap) {
 int cs_op_pack_f16(const float* w, int rows, int K, uint16_t* out, int ldo, const float* row_scale, const float* col_scale,
                     cs_stream stream) {
   if (!w || !out || rows <= 0 || K <= 0 || ldo < K) return fail(CS_ERR_BAD_ARG, "pack_f16: bad arguments");
-  HIPCHK(cs_pack_f16_launch(w, rows, K, out, ldo, row_scale, col_scale, (hipStream_t)stream));
+  HIPCHK(cs_pack_f16_launch(w, rows, K, out, ldo, row_scale, col_scale, g_op_bf16, (hipStream_t)stream));
   return 0;
 }
 
 int cs_op_panel_pack(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
                      uint16_t* img, cs_stream stream) {
   if (!w1 || !w2 || !img) return fail(CS_ERR_BAD_ARG, "panel_pack: null argument");
-  HIPCHK(cs_panel_pack_launch(wo, ls1, w1, g2, w2, ls2, img, (hipStream_t)stream));
+  HIPCHK(cs_panel_pack_launch(wo, ls1, w1, g2, w2, ls2, img, g_op_bf16, (hipStream_t)stream));
   return 0;
 }
 
@@ -1175,6 +1217,7 @@ int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, c
                         uint16_t* u_out, int M, float eps, cs_stream stream) {
   CsPanelParams q{};
   q.x = x; q.attn_o = attn_o; q.img = img; q.bo = bo; q.b1 = b1; q.b2 = b2; q.u_out = u_out; q.M = M; q.eps = eps;
+  q.bf16 = g_op_bf16;
   if (const char* e = cs_panel_check(&q)) return fail(CS_ERR_BAD_ARG, "%s", e);
   HIPCHK(cs_panel_launch(&q, (hipStream_t)stream));
   return 0;

@@ -44,7 +44,7 @@ struct AttnCfg {
   static constexpr int NIT = (64 * CH + 255) / 256;  // 16-byte chunks per thread per tile (K and V each)
 };
 
-template <int DH>
+template <int DH, bool BF>
 __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
   using Cfg = AttnCfg<DH>;
   constexpr int KS = Cfg::KS, DT = Cfg::DT, CH = Cfg::CH, NIT = Cfg::NIT;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
 #pragma unroll
       for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[s][j] = (_Float16)((float)qf[s][j] * sc);
+        for (int j = 0; j < 8; ++j) qf[s][j] = __builtin_bit_cast(_Float16, f2o<BF>(o2f<BF>(__builtin_bit_cast(h16_t, qf[s][j])) * sc));
     }
   }
 
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         h16x8_t kf = *reinterpret_cast<const h16x8_t*>(kb + koff + k2 * 32 * Cfg::KROW + s * 32);
-        st[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], s == 0 ? negm : st[k2], 0, 0, 0);
+        st[k2] = mfma_32x32x16<BF>(kf, qf[s], s == 0 ? negm : st[k2]);
       }
     }
     // ---- mask the ragged tail (keys >= Lk) : wave-uniform branch ----
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
           const float pb = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j + 1]);
           ps0 += pa;
           ps1 += pb;
-          pf[k2][s2][j] = (_Float16)pa;
-          pf[k2][s2][j + 1] = (_Float16)pb;
+          pf[k2][s2][j] = __builtin_bit_cast(_Float16, f2o<BF>(pa));
+          pf[k2][s2][j + 1] = __builtin_bit_cast(_Float16, f2o<BF>(pb));
         }
       }
     l_run += ps0 + ps1;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
           short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) short4_t*)(vrow + 8 * Cfg::VROW + d * 64));
           short8_t vf8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8_t, vf8), pf[k2][s2], ot[d], 0, 0, 0);
+          ot[d] = mfma_32x32x16<BF>(__builtin_bit_cast(h16x8_t, vf8), pf[k2][s2], ot[d]);
         }
       }
 
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
         if (dd < DH) {
           const float v0 = ot[d][4 * g4 + 0] * inv, v1 = ot[d][4 * g4 + 1] * inv, v2 = ot[d][4 * g4 + 2] * inv, v3 = ot[d][4 * g4 + 3] * inv;
           uint2 o;
-          o.x = pack_h16x2(v0, v1);
-          o.y = pack_h16x2(v2, v3);
+          o.x = pack_o16x2<BF>(v0, v1);
+          o.y = pack_o16x2<BF>(v2, v3);
           *reinterpret_cast<uint2*>(op + dd) = o;
         }
       }
@@ -295,13 +295,13 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
   }
 }
 
-template <int DH>
+template <int DH, bool BF>
 hipError_t launch(CsAttnParams p, int batch, hipStream_t stream) {
   p.nbatch = batch;
   const int groups = p.heads * batch;
   dim3 grid(((groups + 7) / 8) * 8 * ((p.Lq + 127) / 128));
   const int lds = 2 * AttnCfg<DH>::STAGE + 64;  // +64: the last rows' transposed reads of a padded d tile may run past the image
-  hipLaunchKernelGGL(cs_attn_kernel<DH>, grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((cs_attn_kernel<DH, BF>), grid, dim3(256), lds, stream, p);
   return hipGetLastError();
 }
 
@@ -324,10 +324,10 @@ extern "C" const char* cs_attn_check(const CsAttnParams* p, int dh, int batch) {
 
 extern "C" hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, hipStream_t stream) {
   switch (dh) {
-    case 16: return launch<16>(*p, batch, stream);
-    case 48: return launch<48>(*p, batch, stream);
-    case 64: return launch<64>(*p, batch, stream);
-    case 96: return launch<96>(*p, batch, stream);
+    case 16: return p->bf16 ? launch<16, true>(*p, batch, stream) : launch<16, false>(*p, batch, stream);
+    case 48: return p->bf16 ? launch<48, true>(*p, batch, stream) : launch<48, false>(*p, batch, stream);
+    case 64: return p->bf16 ? launch<64, true>(*p, batch, stream) : launch<64, false>(*p, batch, stream);
+    case 96: return p->bf16 ? launch<96, true>(*p, batch, stream) : launch<96, false>(*p, batch, stream);
   }
   return hipErrorInvalidValue;
 }

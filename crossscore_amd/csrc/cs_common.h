@@ -31,6 +31,44 @@ __device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// ---- operand type of the MFMA kernels: IEEE half (default) or bfloat16 (cs_config.operand_dtype).  Both are 16 bits in memory (h16_t holds
+//      the raw bits either way), both MFMA forms take the same cycles; half carries 11 significant bits and is finite to 65504, bfloat16
+//      8 bits with fp32's range.  Kernels with MFMAs take the choice as a template parameter, the memory-bound ones as an argument. ----
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950; a NaN stays a NaN)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ h16_t f2bf(float x) { return __builtin_bit_cast(h16_t, (__bf16)x); }
+__device__ __forceinline__ float bf2f(h16_t b) { return __uint_as_float((uint32_t)b << 16); }
+template <bool BF> __device__ __forceinline__ uint32_t pack_o16x2(float lo, float hi) {
+  if constexpr (BF) return pack_bf16x2(lo, hi);
+  else return pack_h16x2(lo, hi);
+}
+template <bool BF> __device__ __forceinline__ h16_t f2o(float x) {
+  if constexpr (BF) return f2bf(x);
+  else return f2h(x);
+}
+template <bool BF> __device__ __forceinline__ float o2f(h16_t b) {
+  if constexpr (BF) return bf2f(b);
+  else return h2f(b);
+}
+// run-time forms for the memory-bound kernels (a wave-uniform select)
+__device__ __forceinline__ uint32_t pack_o16x2(float lo, float hi, int bf) { return bf ? pack_bf16x2(lo, hi) : pack_h16x2(lo, hi); }
+__device__ __forceinline__ h16_t f2o(float x, int bf) { return bf ? f2bf(x) : f2h(x); }
+__device__ __forceinline__ float o2f(h16_t b, int bf) { return bf ? bf2f(b) : h2f(b); }
+// fragments are carried as h16x8_t (raw bits) in both modes
+template <bool BF> __device__ __forceinline__ f32x4_t mfma_16x16x32(const h16x8_t& a, const h16x8_t& b, const f32x4_t& c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+template <bool BF> __device__ __forceinline__ f32x16_t mfma_32x32x16(const h16x8_t& a, const h16x8_t& b, const f32x16_t& c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 // wave64 butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -134,6 +172,7 @@ struct CsGemmParams {
   const float* col_s;    // [N] s[n]
   float ln_eps;
   int ablate;         // debug timing builds only (CS_ABLATE); 0 in the product
+  int bf16;           // operand type of A, W and of a 16-bit output: 0 IEEE half, 1 bfloat16
 };
 
 struct CsAttnParams {
@@ -144,6 +183,7 @@ struct CsAttnParams {
   int nbatch;                                          // filled by the launcher
   float scale_log2e;                                   // (1/sqrt(dh)) * log2(e)
   float* lse;                                          // optional [batch][heads][Lq]: m*ln2-scaled log-sum-exp (base 2)
+  int bf16;                                            // operand type of Q, K, V, P and O: 0 IEEE half, 1 bfloat16
 };
 
 // Encoder "token panel" kernel (panel.hip): one launch per DINOv2 layer does, for 128-row panels of the residual stream,
@@ -161,4 +201,5 @@ struct CsPanelParams {
   h16_t* u_out;           // [M][C] or null
   int M;
   float eps;               // LayerNorm eps (1e-6 in DINOv2)
+  int bf16;                // operand type of attn_o, img, the hidden slices and u_out: 0 IEEE half, 1 bfloat16
 };

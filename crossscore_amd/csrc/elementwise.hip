@@ -15,7 +15,7 @@ namespace {
 // Image g = img0 + img of the (B*(1+N)) image batch is the query of item b = g/(1+N) when g%(1+N) == 0, else
 // reference view g%(1+N)-1 of item b: the torch.cat of core.py:134-138 is folded into the addressing.
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ xq, const float* __restrict__ xr, int N, int img0,
-                                                      h16_t* __restrict__ out, int I, int H, int W, int gh, int gw, int P, int Kp) {
+                                                      h16_t* __restrict__ out, int I, int H, int W, int gh, int gw, int P, int Kp, int bf) {
   const int chunks = Kp / 8;
   const long long total = (long long)I * gh * gw * chunks;
   const int KK = 3 * P * P;
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
       v[e] = val;
     }
     uint4 o;
-    o.x = pack_h16x2(v[0], v[1]); o.y = pack_h16x2(v[2], v[3]);
-    o.z = pack_h16x2(v[4], v[5]); o.w = pack_h16x2(v[6], v[7]);
+    o.x = pack_o16x2(v[0], v[1], bf); o.y = pack_o16x2(v[2], v[3], bf);
+    o.z = pack_o16x2(v[4], v[5], bf); o.w = pack_o16x2(v[6], v[7], bf);
     *reinterpret_cast<uint4*>(out + (size_t)m * Kp + c * 8) = o;
   }
 }
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 template <int P>
 __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ xq, const float* __restrict__ xr, int N, int img0,
                                                            h16_t* __restrict__ out, int H, int W, int gh, int gw, int Kp,
-                                                           float* __restrict__ pmean) {
+                                                           float* __restrict__ pmean, int bf) {
   extern __shared__ __attribute__((aligned(16))) char im_smem[];
   h16_t* tile = reinterpret_cast<h16_t*>(im_smem);                                   // [gw][Kp]
   const int Wu = gw * P;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restric
       const float* src = x + ((size_t)ch * H + (pi * P + dy)) * W;
       for (int xx = lane; xx < Wu; xx += 64) {
         const int pj = xx / P, dx = xx - pj * P;
-        tile[pj * Kp + ch * P * P + dy * P + dx] = f2h(src[xx]);
+        tile[pj * Kp + ch * P * P + dy * P + dx] = f2o(src[xx], bf);
       }
     }
   } else {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restric
       for (int dy = wv; dy < P; dy += 4)
         for (int xx = lane; xx < Wu; xx += 64) {
           const int pj = xx / P, dx = xx - pj * P;
-          tile[pj * Kp + ch * P * P + dy * P + dx] = f2h(stage[dy * Wu + xx] - mean[pj]);
+          tile[pj * Kp + ch * P * P + dy * P + dx] = f2o(stage[dy * Wu + xx] - mean[pj], bf);
         }
       __syncthreads();
     }
@@ -173,7 +173,7 @@ __device__ __forceinline__ void ln_normalise(LnRow& r, int C, int C4, int lane, 
     }
   }
 }
-__device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float* of32, h16_t* obf) {
+__device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float* of32, h16_t* obf, int bf) {
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
@@ -181,8 +181,8 @@ __device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float
       if (of32) reinterpret_cast<float4*>(of32)[c] = r.v[i];
       if (obf) {
         uint2 o;
-        o.x = pack_h16x2(r.v[i].x, r.v[i].y);
-        o.y = pack_h16x2(r.v[i].z, r.v[i].w);
+        o.x = pack_o16x2(r.v[i].x, r.v[i].y, bf);
+        o.y = pack_o16x2(r.v[i].z, r.v[i].w, bf);
         reinterpret_cast<uint2*>(obf)[c] = o;
       }
     }
@@ -190,7 +190,7 @@ __device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int M, int C, const float* __restrict__ g,
-                                                         const float* __restrict__ b, float eps, float* of32, h16_t* obf) {
+                                                         const float* __restrict__ b, float eps, float* of32, h16_t* obf, int bf) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   LnRow r;
   ln_load(x + (size_t)row * C, C4, lane, r);
   ln_normalise(r, C, C4, lane, g, b, eps);
-  ln_store(r, C4, lane, of32 ? of32 + (size_t)row * C : nullptr, obf ? obf + (size_t)row * C : nullptr);
+  ln_store(r, C4, lane, of32 ? of32 + (size_t)row * C : nullptr, obf ? obf + (size_t)row * C : nullptr, bf);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __restrict__ x, int I, int img0, int Np, int C, int N,
                                                               const float* __restrict__ g, const float* __restrict__ b, float eps,
                                                               const float* __restrict__ pe, float* q_f32, h16_t* q_bf,
-                                                              h16_t* mem_bf) {
+                                                              h16_t* mem_bf, int bf) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long long)I * Np) return;
@@ -232,24 +232,24 @@ __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __rest
   }
   if (v == 0) {
     const size_t o = ((size_t)bb * Np + pp) * C;
-    ln_store(r, C4, lane, q_f32 + o, q_bf + o);
+    ln_store(r, C4, lane, q_f32 + o, q_bf + o, bf);
   } else {
     const size_t o = (((size_t)bb * (N < 0 ? 0 : N) + (v - 1)) * Np + pp) * C;
-    ln_store(r, C4, lane, nullptr, mem_bf + o);
+    ln_store(r, C4, lane, nullptr, mem_bf + o, bf);
   }
 }
 
 // CLS rows of the residual stream: x[img*T][c] = cls[c] + pos[0][c]  (HF:108-112).  One wave per image.  With the LayerNorm
 // fold the row also gets its fp16 copy and its (sum, sumsq) in partial slot 0 (the other slots are zeroed).
 __global__ __launch_bounds__(64) void cls_rows_kernel(float* x, int I, int T, int C, const float* cls, const float* pos, h16_t* xb,
-                                                      float* stats, int sp) {
+                                                      float* stats, int sp, int bf) {
   const int img = blockIdx.x, lane = threadIdx.x;
   const size_t row = (size_t)img * T;
   float s1 = 0.f, s2 = 0.f;
   for (int c = lane; c < C; c += 64) {
     const float v = cls[c] + pos[c];
     x[row * C + c] = v;
-    if (xb) xb[row * C + c] = f2h(v);
+    if (xb) xb[row * C + c] = f2o(v, bf);
     s1 += v;
     s2 += v * v;
   }
@@ -327,13 +327,13 @@ __global__ void pe_bilinear_kernel(const float* __restrict__ pe, int ph, int pw,
 // fp32 -> fp16 weight packing (K-contiguous rows; optional zero padding of K to ldo; optional per-output-row scale:
 // LayerScale lambda folded into the projection, HF modeling_dinov2.py:277-278, so the GEMM epilogue has no scale operand)
 __global__ void pack_f16_kernel(const float* __restrict__ w, int rows, int K, h16_t* __restrict__ out, int ldo,
-                                 const float* __restrict__ row_scale, const float* __restrict__ col_scale) {
+                                 const float* __restrict__ row_scale, const float* __restrict__ col_scale, int bf) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)rows * ldo) return;
   const int k = (int)(i % ldo);
   const long long rr = i / ldo;
   const float sc = (row_scale ? row_scale[rr] : 1.0f) * ((col_scale && k < K) ? col_scale[k] : 1.0f);
-  out[i] = k < K ? f2h(w[rr * K + k] * sc) : (h16_t)0;
+  out[i] = k < K ? f2o(w[rr * K + k] * sc, bf) : (h16_t)0;
 }
 
 // LayerNorm fold constants of one projection (see CS_EPI_LN_* in cs_common.h), one wave per output row n:
@@ -390,10 +390,11 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(CsAttnParams p, int h
       const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float q0 = h2f((h16_t)(qw[e] & 0xffffu)), q1 = h2f((h16_t)(qw[e] >> 16));
-        if (raw) { q0 = h2f(f2h(q0 * sc)); q1 = h2f(f2h(q1 * sc)); }
-        s += h2f((h16_t)(kw[e] & 0xffffu)) * q0;
-        s += h2f((h16_t)(kw[e] >> 16)) * q1;
+        const int bf = p.bf16;
+        float q0 = o2f((h16_t)(qw[e] & 0xffffu), bf), q1 = o2f((h16_t)(qw[e] >> 16), bf);
+        if (raw) { q0 = o2f(f2o(q0 * sc, bf), bf); q1 = o2f(f2o(q1 * sc, bf), bf); }
+        s += o2f((h16_t)(kw[e] & 0xffffu), bf) * q0;
+        s += o2f((h16_t)(kw[e] >> 16), bf) * q1;
       }
     }
     out[((size_t)bat * p.Lq + q) * p.Lk + key] = __builtin_amdgcn_exp2f(s - lse);
@@ -421,9 +422,27 @@ __global__ __launch_bounds__(256) void score_mean_kernel(const float* __restrict
   if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1] + part[2] + part[3]) / (float)n;
 }
 
+// number of non-finite values of the score map, added to a device counter (cs_nonfinite_count): an fp16 operand that overflowed upstream
+// (|x| > 65504 -> inf -> NaN in the next LayerNorm / softmax) reaches every pixel of its image as NaN, so the output is where it shows
+__global__ __launch_bounds__(256) void score_check_kernel(const float* __restrict__ score, size_t n, unsigned* __restrict__ counter) {
+  unsigned bad = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = score[i];
+    bad += !(fabsf(v) <= 3.0e38f);  // NaN and +-inf
+  }
+  for (int o = 32; o >= 1; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(counter, bad);
+}
+
 }  // namespace
 
 extern "C" {
+
+hipError_t cs_score_check_launch(const float* score, size_t n, unsigned* counter, hipStream_t st) {
+  const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(score_check_kernel, dim3(grid), dim3(256), 0, st, score, n, counter);
+  return hipGetLastError();
+}
 
 hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipStream_t st) {
   hipLaunchKernelGGL(patch_wsum_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, st, w, C, P * P, wsum);
@@ -433,7 +452,7 @@ hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipSt
 // pmean: [I*gh*gw][4] fp32 or nullptr.  With pmean the patches are mean-centred; when the gather fallback has to be used the
 // means are written as zeros (nothing removed, nothing to add back).
 hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, h16_t* out, int I, int H, int W, int P, int Kp,
-                            float* pmean, hipStream_t st) {
+                            float* pmean, int bf, hipStream_t st) {
   const int gh = H / P, gw = W / P;
   const size_t lds = (size_t)gw * Kp * sizeof(h16_t) + (pmean ? ((size_t)P * gw * P + gw + (size_t)gw * P) * sizeof(float) : 0);
   if (P == 14 && Kp >= 3 * P * P && lds <= 156 * 1024 && (long long)I * gh < (1ll << 31) && gw <= 256) {
@@ -445,7 +464,7 @@ hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, h
       if (e != hipSuccess) return e;
       attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(im2col_rows_kernel<14>, dim3(I * gh), dim3(256), lds, st, xq, xr, N, img0, out, H, W, gh, gw, Kp, pmean);
+    hipLaunchKernelGGL(im2col_rows_kernel<14>, dim3(I * gh), dim3(256), lds, st, xq, xr, N, img0, out, H, W, gh, gw, Kp, pmean, bf);
     return hipGetLastError();
   }
   if (pmean) {
@@ -454,29 +473,29 @@ hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, h
   }
   const long long total = (long long)I * gh * gw * (Kp / 8);
   const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, st, xq, xr, N, img0, out, I, H, W, gh, gw, P, Kp);
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, st, xq, xr, N, img0, out, I, H, W, gh, gw, P, Kp, bf);
   return hipGetLastError();
 }
 
 
 
 hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32,
-                               h16_t* obf, hipStream_t st) {
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, g, b, eps, of32, obf);
+                               h16_t* obf, int bf, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, g, b, eps, of32, obf, bf);
   return hipGetLastError();
 }
 
 hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
-                                    const float* pe, float* q_f32, h16_t* q_bf, h16_t* mem_bf, hipStream_t st) {
+                                    const float* pe, float* q_f32, h16_t* q_bf, h16_t* mem_bf, int bf, hipStream_t st) {
   const long long rows = (long long)I * Np;
   hipLaunchKernelGGL(final_ln_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, I, img0, Np, C, N, g, b, eps, pe,
-                     q_f32, q_bf, mem_bf);
+                     q_f32, q_bf, mem_bf, bf);
   return hipGetLastError();
 }
 
 hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, h16_t* xb, float* stats, int sp,
-                              hipStream_t st) {
-  hipLaunchKernelGGL(cls_rows_kernel, dim3(I), dim3(64), 0, st, x, I, T, C, cls, pos, xb, stats, sp);
+                              int bf, hipStream_t st) {
+  hipLaunchKernelGGL(cls_rows_kernel, dim3(I), dim3(64), 0, st, x, I, T, C, cls, pos, xb, stats, sp, bf);
   return hipGetLastError();
 }
 
@@ -499,10 +518,10 @@ hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh,
 }
 
 hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
-                               hipStream_t st) {
+                               int bf, hipStream_t st) {
   const long long total = (long long)rows * ldo;
   hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, rows, K, out, ldo, row_scale,
-                     col_scale);
+                     col_scale, bf);
   return hipGetLastError();
 }
 

@@ -164,7 +164,7 @@ template <int EPI> struct EpiTraits {
 // PIPE (RESID_F32 with a residual, K >= 9 slices): the residual is prefetched in the accumulator layout a slice or more ahead of
 // its epilogue step and added in registers, so no step consumes a load it has just issued (that would wait for every older
 // LDS-DMA: the vector-memory queue retires in order, and the K=384/1536 residual GEMMs were spending a third of their time there).
-template <int EPI, int NSUB, int SPL, bool PIPE>
+template <int EPI, int NSUB, int SPL, bool PIPE, bool BF>
 __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
   static_assert(!PIPE || EPI == CS_EPI_RESID_F32, "PIPE is the RESID_F32 residual prefetch");
   using Cfg = GemmCfg<NSUB>;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
           if constexpr (EPI == CS_EPI_BIAS_LEAKY_F16) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
         }
         if constexpr (kHalf) {
-          patch_write8<j * 32>(pw_addr, u32x2_t{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3])});
+          patch_write8<j * 32>(pw_addr, u32x2_t{pack_o16x2<BF>(v[0], v[1]), pack_o16x2<BF>(v[2], v[3])});
         } else {
           patch_write16<j * 64>(pw_addr, f32x4_t{v[0], v[1], v[2], v[3]});
         }
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
               *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + row * p.ldc + n) = seg[q];
               if constexpr (kLnOut)
                 *reinterpret_cast<u32x2_t*>(p.out_f16 + row * p.ldc + n) =
-                    u32x2_t{pack_h16x2(seg[q][0], seg[q][1]), pack_h16x2(seg[q][2], seg[q][3])};
+                    u32x2_t{pack_o16x2<BF>(seg[q][0], seg[q][1]), pack_o16x2<BF>(seg[q][2], seg[q][3])};
             }
           }
         }
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
             if constexpr (kLnOut)
               if (p.out_f16)
                 *reinterpret_cast<u32x2_t*>(p.out_f16 + row * p.ldc + n) =
-                    u32x2_t{pack_h16x2(seg[q][0], seg[q][1]), pack_h16x2(seg[q][2], seg[q][3])};
+                    u32x2_t{pack_o16x2<BF>(seg[q][0], seg[q][1]), pack_o16x2<BF>(seg[q][2], seg[q][3])};
           }
         }
         if constexpr (kLnOut) {
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NSUB; ++j) acc[i][j] = mfma_16x16x32<BF>(fw[j], fa[i], acc[i][j]);
       // W fragments + LOOK A fragments up front, then one A-fragment read per MFMA group, LOOK-1 groups ahead of its use
       // (the LN-folded consumers are at the 256-register limit: one fragment less in flight avoids spills)
       constexpr int LOOK = ((kLN || PIPE) && NSUB == 3) ? 2 : 3;
@@ -664,15 +664,15 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
 constexpr int CS_MAX_DEVICES = 16;
 int g_num_cus[CS_MAX_DEVICES] = {};  // per device (a handle may be moved to another GPU of the process)
 
-template <int EPI, int NSUB, int SPL, bool PIPE = false>
-hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
+template <int EPI, int NSUB, int SPL, bool PIPE, bool BF>
+hipError_t launch_nb(const CsGemmParams& p, hipStream_t stream) {
   constexpr int BN = 64 * NSUB;
   constexpr int LDS = GemmCfg<NSUB>::LDS;
   static bool attr_done[CS_MAX_DEVICES] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CS_MAX_DEVICES) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm_kernel<EPI, NSUB, SPL, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm_kernel<EPI, NSUB, SPL, PIPE, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_done[dev] = true;
   }
@@ -694,8 +694,17 @@ hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
   const int need = ((tiles_m + 7) / 8) * tiles_n * 8;
   if (grid > need) grid = need;
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((cs_gemm_kernel<EPI, NSUB, SPL, PIPE>), dim3(grid), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((cs_gemm_kernel<EPI, NSUB, SPL, PIPE, BF>), dim3(grid), dim3(256), LDS, stream, p);
   return hipGetLastError();
+}
+
+// operand type at run time (CsGemmParams::bf16).  The LayerNorm-folded epilogues (an opt-in path) are built for IEEE half only.
+template <int EPI, int NSUB, int SPL, bool PIPE = false>
+hipError_t launch_n(const CsGemmParams& p, hipStream_t stream) {
+  if constexpr (EPI < CS_EPI_LN_F16) {
+    if (p.bf16) return launch_nb<EPI, NSUB, SPL, PIPE, true>(p, stream);
+  }
+  return launch_nb<EPI, NSUB, SPL, PIPE, false>(p, stream);
 }
 
 template <int EPI>
@@ -758,6 +767,7 @@ extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
   if (p->lda % 8 || p->ldw % 8) return "gemm: lda/ldw must be multiples of 8 (16-byte rows)";
   if (p->lda < p->K || p->ldw < p->K) return "gemm: lda/ldw smaller than K";
   if (!p->A || !p->W || !p->out) return "gemm: null operand";
+  if (p->bf16 && epi >= CS_EPI_LN_F16) return "gemm: the LayerNorm-folded epilogues are built for fp16 operands only";
   if (p->scale) return "gemm: a per-column scale is folded into the packed weights (cs_op_pack_f16 row_scale), it is not an epilogue operand";
   if ((epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN) && p->resid && p->ldr % 4) return "gemm: ldr must be a multiple of 4";
   if (epi == CS_EPI_RESID_F32_LN && (!p->out_f16 || !p->stats_out)) return "gemm: RESID_F32_LN needs out_f16 and stats_out";
@@ -782,7 +792,7 @@ extern "C" hipError_t cs_gemm256_launch(const CsGemmParams* p, int epi, int bf16
 
 extern "C" hipError_t cs_gemm_launch(const CsGemmParams* p0, int epi, hipStream_t stream) {
   // K >= 512 with whole 256-column tiles (the ViT-B projections, the decoder's K/V projection at C = 768): the large-tile kernel
-  if (cs_gemm256_supported(p0, epi)) return cs_gemm256_launch(p0, epi, 0, stream);
+  if (cs_gemm256_supported(p0, epi)) return cs_gemm256_launch(p0, epi, p0->bf16, stream);
   CsGemmParams pp = *p0;
 #ifdef CS_ABLATE
   if (const char* e = getenv("CS_GEMM_ABLATE")) pp.ablate = atoi(e);

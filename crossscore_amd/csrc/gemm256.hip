@@ -46,25 +46,8 @@ constexpr int G_PATCH0 = G_BIAS + G_NMAX * 4;
 constexpr int G_LDS = G_PATCH0 + 8 * G_PATCH;   // 158 KiB
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 template <int V> using IC = std::integral_constant<int, V>;
-
-template <bool BF>
-__device__ __forceinline__ f32x4_t mfma16(const h16x8_t& w, const h16x8_t& a, const f32x4_t& c) {
-  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, a), c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, a, c, 0, 0, 0);
-}
-template <bool BF>
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  if constexpr (BF) {
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(uint32_t, v);
-  } else {
-    return pack_h16x2(lo, hi);
-  }
-}
 
 #define G_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define G_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -207,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[MH * 4 + i][NH * 2 + j] = mfma16<BF>(fw[NH][j][s], fa[i][s], acc[MH * 4 + i][NH * 2 + j]);
+        for (int j = 0; j < 2; ++j) acc[MH * 4 + i][NH * 2 + j] = mfma_16x16x32<BF>(fw[NH][j][s], fa[i][s], acc[MH * 4 + i][NH * 2 + j]);
     __builtin_amdgcn_s_setprio(0);
   };
   // the barrier between a phase's load segment and its MFMA cluster, and the one behind the cluster
@@ -313,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
             if constexpr (EPI == CS_EPI_BIAS_RELU_F16) v[r] = fmaxf(v[r], 0.f);
             if constexpr (EPI == CS_EPI_BIAS_LEAKY_F16) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
           }
-          const u32x2_t pk = {pack2<BF>(v[0], v[1]), pack2<BF>(v[2], v[3])};
+          const u32x2_t pk = {pack_o16x2<BF>(v[0], v[1]), pack_o16x2<BF>(v[2], v[3])};
           if (j == 0) pw8<0>(pw_addr, pk);
           if (j == 1) pw8<32>(pw_addr, pk);
           if (j == 2) pw8<64>(pw_addr, pk);

@@ -89,8 +89,9 @@ __device__ __forceinline__ float gelu_erf1(float x) {
 }
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <bool BF>
 __device__ __forceinline__ u32x4_t pack8(const float (&v)[8]) {
-  return u32x4_t{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7])};
+  return u32x4_t{pack_o16x2<BF>(v[0], v[1]), pack_o16x2<BF>(v[2], v[3]), pack_o16x2<BF>(v[4], v[5]), pack_o16x2<BF>(v[6], v[7])};
 }
 
 // ---- inline-asm LDS access of the regions the LDS-DMA also writes or that cross waves (hipcc would order every compiler-visible LDS
@@ -128,7 +129,7 @@ __device__ unsigned long long g_panel_dbg[64 * 8 * 16];
 
 // ABL: timing-only ablations (tools/panel_ablate.py builds them with -DCS_PANEL_ABLATE; results are wrong by design):
 //   1 no GELU arithmetic, 2 no weight LDS-DMA after the first two MLP units, 16 no s_barrier per unit, 64 transition-time accounting
-template <bool OUTPROJ, int ABL = 0>
+template <bool OUTPROJ, int ABL = 0, bool BF = false>
 __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -292,16 +293,16 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
             for (int q = 0; q < 4; ++q)
 #pragma unroll
               for (int i = 0; i < 4; ++i) b16[4 * q + i] = bb[q][i];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], xf[0], b16, 0, 0, 0);
+            acc = mfma_32x32x16<BF>(w[0], xf[0], b16);
           } else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], xf[M], acc, 0, 0, 0);
+            acc = mfma_32x32x16<BF>(w[M % 6], xf[M], acc);
           }
           if constexpr (M < 18) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
           else lds_read1<(M - 18) * FRAG>(cur, w[M % 6]);
         }
         if constexpr (M < 16) gv[M & 7] = (ABL & 1) ? act[M] : gelu_erf1(act[M]);
-        if constexpr (M == 7) { if (hb_write) lds_write16<0>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv)); }
-        if constexpr (M == 15) { if (hb_write) lds_write16<FRAG>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8(gv)); }
+        if constexpr (M == 7) { if (hb_write) lds_write16<0>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8<BF>(gv)); }
+        if constexpr (M == 15) { if (hb_write) lds_write16<FRAG>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8<BF>(gv)); }
         CS_SB();
       });
     };
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
         if constexpr (M == 0 && C > 0) lds_read1<FRAG>(of_addr + slot_x * (4 * 2 * FRAG), of[1]);  // (needed from M = 12 on)
         CS_LGKM(5);
         constexpr int T = M % 12;
-        acc2[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], of[M / 12], acc2[T], 0, 0, 0);
+        acc2[T] = mfma_32x32x16<BF>(w[M % 6], of[M / 12], acc2[T]);
         if constexpr (M < 18) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
         else lds_read1<(M - 18) * FRAG>(cur, w[M % 6]);  // (after the last unit: the A half of MLP tick 0, unused)
         CS_SB();
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaf(acc2[T][8 * S + e], rstd, nb);  // (not (x - mean) * rstd: the 192 differences of the variance pass would be kept alive)
-      lds_write16<((2 * T + S) % 12) * FRAG>(r_addr, pack8(v));
+      lds_write16<((2 * T + S) % 12) * FRAG>(r_addr, pack8<BF>(v));
     };
     sfor<6>([&](auto T_) { put(T_, IC<0>{}); put(T_, IC<1>{}); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       }
       if constexpr (M == 5) pend_late = false;
       CS_LGKM(5);
-      acc2[M % 12] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[M % 6], hb[M / 12], acc2[M % 12], 0, 0, 0);
+      acc2[M % 12] = mfma_32x32x16<BF>(w[M % 6], hb[M / 12], acc2[M % 12]);
       if constexpr (M < 18) lds_read1<(24 + M + 6) * FRAG>(cur, w[M % 6]);
       else lds_read1<(24 + M - 18) * FRAG>(cur, w[M % 6]);  // (after the last tick: re-reads of this unit, unused)
       CS_SB();
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaf(acc2[T][8 * Q + e], rstd, nb);
-          lds_write16<T * 64 + 16 * Q>(su, pack8(v));
+          lds_write16<T * 64 + 16 * Q>(su, pack8<BF>(v));
         });
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
 //                                              fragments 24..47 = fc2 slice t - 2, k-step f' / 12, tile f' % 12       (t >= 2)]
 //             [1 padding tick] ----
 __device__ __forceinline__ int panel_perm(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+template <bool BF>
 __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restrict__ wo, const float* __restrict__ ls1,
                                                             const float* __restrict__ w1, const float* __restrict__ g2,
                                                             const float* __restrict__ w2, const float* __restrict__ ls2,
@@ -629,8 +631,23 @@ __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restr
       }
     }
   }
-  const uint4 o = {pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7])};
+  const uint4 o = {pack_o16x2<BF>(v[0], v[1]), pack_o16x2<BF>(v[2], v[3]), pack_o16x2<BF>(v[4], v[5]), pack_o16x2<BF>(v[6], v[7])};
   reinterpret_cast<uint4*>(img)[gi] = o;
+}
+
+template <bool OUTPROJ, bool BF>
+hipError_t panel_launch_t(const CsPanelParams* p, hipStream_t st) {
+  static bool attr_done[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_panel_kernel<OUTPROJ, 0, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  const int grid = (p->M + PANEL_ROWS - 1) / PANEL_ROWS;
+  hipLaunchKernelGGL((cs_panel_kernel<OUTPROJ, 0, BF>), dim3(grid), dim3(512), LDS_BYTES, st, *p);
+  return hipGetLastError();
 }
 
 }  // namespace
@@ -645,9 +662,10 @@ int cs_panel_supported(int C, int mlp_ratio) { return C == PC && mlp_ratio * C =
 size_t cs_panel_image_bytes(int with_outproj) { return (size_t)(with_outproj ? OUT_CHUNKS : 0) * CHUNK + (size_t)(NTICK + PAD_TICKS) * TICK; }
 
 hipError_t cs_panel_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
-                                h16_t* img, hipStream_t st) {
+                                h16_t* img, int bf16, hipStream_t st) {
   const int total = (int)(cs_panel_image_bytes(wo ? 1 : 0) / 16);
-  hipLaunchKernelGGL(cs_panel_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, wo, ls1, w1, g2, w2, ls2, img);
+  if (bf16) hipLaunchKernelGGL(cs_panel_pack_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, st, wo, ls1, w1, g2, w2, ls2, img);
+  else hipLaunchKernelGGL(cs_panel_pack_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, st, wo, ls1, w1, g2, w2, ls2, img);
   return hipGetLastError();
 }
 
@@ -662,20 +680,10 @@ const char* cs_panel_check(const CsPanelParams* p) {
 }
 
 hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st) {
-  static bool attr_done[16][2] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-  const int v = p->attn_o ? 1 : 0;
-  if (!attr_done[dev][v]) {
-    const void* fn = v ? reinterpret_cast<const void*>(cs_panel_kernel<true>) : reinterpret_cast<const void*>(cs_panel_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done[dev][v] = true;
-  }
-  const int grid = (p->M + PANEL_ROWS - 1) / PANEL_ROWS;
 #ifdef CS_PANEL_ABLATE
   if (const char* e = getenv("CS_PANEL_ABL")) {
     const int abl = atoi(e);
+    const int grid = (p->M + PANEL_ROWS - 1) / PANEL_ROWS;
 #define CS_ABL_CASE(N) if (abl == N) { \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cs_panel_kernel<true, N>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
       hipLaunchKernelGGL((cs_panel_kernel<true, N>), dim3(grid), dim3(512), LDS_BYTES, st, *p); return hipGetLastError(); }
@@ -683,9 +691,8 @@ hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st) {
 #undef CS_ABL_CASE
   }
 #endif
-  if (v) hipLaunchKernelGGL(cs_panel_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, st, *p);
-  else hipLaunchKernelGGL(cs_panel_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, st, *p);
-  return hipGetLastError();
+  if (p->attn_o) return p->bf16 ? panel_launch_t<true, true>(p, st) : panel_launch_t<true, false>(p, st);
+  return p->bf16 ? panel_launch_t<false, true>(p, st) : panel_launch_t<false, false>(p, st);
 }
 
 }  // extern "C"

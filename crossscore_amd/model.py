@@ -105,6 +105,11 @@ class CrossScoreNet(torch.nn.Module):
         self._pos_legacy = str(cfg.model.backbone.get("pos_embed_interpolation", "size")) == "scale_factor"
         self.enc_fused = 0         # 0 = token-panel kernel per encoder layer where supported (hidden 384), 1 = unfused kernels
         self.ln_fold = 0           # 1 = fold the encoder LayerNorms into the QKV / fc1 GEMM epilogues (opt-in; slower so far)
+        # 16-bit operand type of the MFMA kernels: "fp16" (default: 11 significant bits, finite to 65504) or "bf16" (8 bits, fp32's range:
+        # the mode for checkpoints whose activations leave the half range; nonfinite_count() tells).  An optional key of THIS build:
+        # model.backbone.operand_dtype; the predict driver derives it from the reference's own trainer.precision key.
+        self.operand_dtype = str(cfg.model.backbone.get("operand_dtype", "fp16"))
+        self.finite_check = True   # every forward counts the non-finite values of its score map on the device (~3 us)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
     # -- weights ----------------------------------------------------------------------------------------------
@@ -118,6 +123,26 @@ class CrossScoreNet(torch.nn.Module):
 
     def load_numpy_state_dict(self, sd: Dict[str, np.ndarray]) -> None:
         self.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+
+    def _operand_code(self) -> int:
+        if self.operand_dtype not in ("fp16", "bf16"):
+            raise ValueError(f"operand_dtype must be 'fp16' or 'bf16', got {self.operand_dtype!r}")
+        return 1 if self.operand_dtype == "bf16" else 0
+
+    @property
+    def token_dtype(self) -> torch.dtype:
+        """dtype of the cached reference tokens (encode_references / forward_cached): the handle's 16-bit operand type"""
+        return torch.bfloat16 if self._operand_code() else torch.float16
+
+    def nonfinite_count(self) -> int:
+        """Non-finite values the score maps of this module's forwards held since the last call (waits for the last forward; resets the
+        count).  With fp16 operands an activation beyond 65504 turns into inf upstream and reaches the score map as NaN: a count > 0
+        says "run this checkpoint with operand_dtype = 'bf16'"."""
+        if self._handle is None:
+            return 0
+        n = C.c_longlong(0)
+        _lib.check(_lib.load().cs_nonfinite_count(self._handle, C.byref(n)))
+        return int(n.value)
 
     def _release(self):
         if self._handle is not None:
@@ -141,7 +166,8 @@ class CrossScoreNet(torch.nn.Module):
                            pos_grid=a.pos_grid, pe_h=a.pe_h, pe_w=a.pe_w, dec_layers=a.dec_layers, dec_heads=a.dec_heads,
                            do_self_attn=int(bool(m.decoder_do_self_attn)), do_short_cut=int(bool(m.decoder_do_short_cut)),
                            act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold),
-                           lanes=int(self.lanes), pos_interp_legacy=int(self._pos_legacy), enc_fused=int(self.enc_fused))
+                           lanes=int(self.lanes), pos_interp_legacy=int(self._pos_legacy), enc_fused=int(self.enc_fused),
+                           operand_dtype=self._operand_code(), skip_finite_check=int(not self.finite_check))
         with torch.cuda.device(device):
             h = lib.cs_create(C.byref(cc))
             if not h:
@@ -230,7 +256,7 @@ class CrossScoreNet(torch.nn.Module):
         P = self.arch.patch
         handle = self._ensure_handle(dev)
         with torch.cuda.device(dev):
-            tok = torch.empty((R, (H // P) * (W // P), self.arch.hidden), dtype=torch.float16, device=dev)
+            tok = torch.empty((R, (H // P) * (W // P), self.arch.hidden), dtype=self.token_dtype, device=dev)
             _lib.check(_lib.load().cs_encode_references(handle, C.c_void_p(x.data_ptr()), R, H, W, C.c_void_p(tok.data_ptr()),
                                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return tok
@@ -244,7 +270,9 @@ class CrossScoreNet(torch.nn.Module):
             raise _lib.CrossScoreHipError("forward_cached needs CUDA(HIP) tensors on one device: the hot path has no CPU fallback")
         dev = query_img.device
         q = query_img.to(torch.float32).contiguous()
-        t = ref_tokens.to(torch.float16).contiguous()
+        if ref_tokens.dtype != self.token_dtype:
+            raise ValueError(f"ref_tokens are {ref_tokens.dtype}, this module's operand type is {self.token_dtype}: encode them with the same module")
+        t = ref_tokens.contiguous()
         B, _, H, W = q.shape
         N = t.shape[1]
         P = self.arch.patch

@@ -34,7 +34,7 @@ def _replica(net: CrossScoreNet, lanes: int) -> CrossScoreNet:
     src.update(dict(net.named_buffers()))
     for name, p in list(rep.named_parameters()) + list(rep.named_buffers()):
         p.data = src[name].data
-    for attr in ("enc_chunk_images", "enc_fused", "ln_fold"):
+    for attr in ("enc_chunk_images", "enc_fused", "ln_fold", "operand_dtype", "finite_check"):
         setattr(rep, attr, getattr(net, attr))
     rep.lanes = lanes
     rep._mark_dirty()
@@ -197,6 +197,10 @@ class ForwardPipeline:
         ref_imgs.record_stream(s)
         tok.record_stream(cur)
         return tok
+
+    def nonfinite_count(self) -> int:
+        """Sum of CrossScoreNet.nonfinite_count() over the replicas (waits for their last forwards)."""
+        return sum(n.nonfinite_count() for n in self.nets)
 
     def result(self, t: Ticket) -> Dict[str, Optional[torch.Tensor]]:
         """The batch's outputs, ordered after its kernels on the CURRENT stream (no host synchronisation)."""

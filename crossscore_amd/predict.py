@@ -75,6 +75,12 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
     items = SimpleReferenceItems(cfg.data.dataset.query_dir, cfg.data.dataset.reference_dir, cfg.data.neighbour_config)
 
     net = CrossScoreNet(cfg)
+    # trainer.precision (config/default_predict.yaml:25, the reference's own key; Lightning names): "16-mixed" (default) / "16" -> IEEE
+    # half MFMA operands, "bf16-mixed" / "bf16" -> bfloat16 operands (fp32's range: for checkpoints whose activations leave the half
+    # range).  "32" / "32-true" have no counterpart here (the MFMA operands are 16 bits wide; everything else is fp32 already) and
+    # select the more accurate of the two, half.  An explicit model.backbone.operand_dtype wins.
+    if "operand_dtype" not in cfg.model.backbone:
+        net.operand_dtype = "bf16" if str(cfg.trainer.precision).startswith("bf16") else "fp16"
     if state_dict is None:
         if cfg.trainer.ckpt_path_to_load is not None:
             state_dict = load_lightning_checkpoint(cfg.trainer.ckpt_path_to_load)
@@ -148,6 +154,10 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
         consume(queued.pop(0))
     torch.cuda.synchronize(device)
     t_loop = time.perf_counter() - t0
+    bad = pipe.nonfinite_count()
+    if bad:  # an activation left the range of the 16-bit operand type somewhere upstream (fp16: |x| > 65504)
+        raise FloatingPointError(f"{bad} non-finite score-map values with {net.operand_dtype} MFMA operands: run with trainer.precision=bf16-mixed "
+                                 "(model.backbone.operand_dtype=bf16)")
     if writer is not None:
         writer.finish()
     files += summariser.summarise()

@@ -70,6 +70,12 @@ typedef struct cs_config {
   int enc_fused;      /* encoder layer structure: 0 = default: with hidden == 384 (ViT-S) each layer is QKV GEMM + attention + ONE
                        * token-panel kernel (out-projection, residual, norm2, fc1, GELU, fc2, residual and the next layer's norm1; the 4C
                        * hidden activations stay in registers), else the unfused kernels; 1 = always the unfused kernels */
+  int operand_dtype;  /* 16-bit operand type of the MFMA kernels (activations between kernels, packed weights): 0 = IEEE half (default: 11 significant
+                       * bits, finite to 65504; score-map MAE 1e-4 vs the fp32 reference), 1 = bfloat16 (8 bits, fp32's range; MAE 8e-4): the
+                       * choice for a checkpoint whose activations leave the half range (trainer.precision = bf16-mixed in the predict driver).
+                       * Accumulation, softmax statistics, LayerNorm, the residual stream and the outputs are fp32 either way. */
+  int skip_finite_check; /* 0 = default: every forward ends with a pass over the score map that counts non-finite values into a device
+                       * counter (cs_nonfinite_count; ~3 us); 1 = skip it */
 } cs_config;
 
 /* Replaces CrossScoreNet.__init__ (task/core.py:27-56). NULL on failure. */
@@ -107,6 +113,10 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
 int cs_encode_references(cs_handle h, const float* imgs, int R, int H, int W, uint16_t* tokens_out, cs_stream stream);
 int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_tokens, int B, int N, int H, int W,
                       float* score_out, float* attn_out, int head_id, float* mean_out, cs_stream stream);
+/* Overflow report.  With fp16 operands an activation beyond 65504 becomes inf and reaches the score map as NaN (nothing clamps in
+ * the hot kernels); every forward counts the non-finite values of its score map on the device.  This call waits for the handle's last
+ * forward, returns the count since the previous call in *count and resets it: > 0 means "switch to operand_dtype = 1 (bf16)". */
+int cs_nonfinite_count(cs_handle h, long long* count);
 /* Bytes of library-owned workspace a forward of this shape needs (grown lazily, never shrunk). */
 size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
 
@@ -119,6 +129,8 @@ int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, do
 int cs_profile_read_bytes(cs_handle h, int family, double* bytes);
 
 /* ---- single-op entry points (used by the parity tests; same kernels the forward launches) ------------- */
+/* 16-bit operand type of the cs_op_* entry points below (process-wide; a handle has its own cs_config.operand_dtype): 0 fp16 (default), 1 bf16 */
+int cs_op_set_operand_dtype(int dtype);
 /* out = epilogue(bias + A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. fp16 = raw uint16. */
 int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
                const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np,

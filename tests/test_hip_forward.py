@@ -20,9 +20,12 @@ MAE_TOL = 1e-3     # the north-star bound
 MAE_TARGET = 2e-4  # SURVEY.md 8c target, asserted on the reference's own goldens and the real backbones
 MAX_TOL = 5e-3     # single-pixel worst case of an fp16-operand forward on peaky synthetic weights (measured 6e-4 - 8e-4)
 TINY = "synthetic/dinov2-tiny"
-# optional attention-probability output (a16): fp16 q / k operands with an fp32 log-sum-exp.  PLACEHOLDER bounds, tightened to 3 x measured below
-AW_MAX_TOL = 2e-2
-AW_L1_TOL = 0.05
+# optional attention-probability output (a16): the kernel recomputes one head's logits from the fp16 q / k operands with the fused kernel's
+# fp32 log-sum-exp.  Measured on MI355X (r3): tiny net g0 head 3 max |dP| 1.02e-3 (peaky rows of a 60-key softmax); ViT-S 1369 x 2738
+# max |dP| 8.4e-5, max per-row L1 1.28e-3.  The bounds are 3 x the measured values (they were 2e-2 / 0.05).
+AW_MAX_TOL_TINY = 3.1e-3
+AW_MAX_TOL = 2.6e-4
+AW_L1_TOL = 4.0e-3
 
 
 def _net(backbone, seed, **over):
@@ -57,7 +60,7 @@ def test_tiny_nonsquare_vs_oracle_and_golden(golden_dir):
     assert aw.shape == (2, 5, 6, 2, 5, 6)
     aw_err = float((aw.cpu() - torch.from_numpy(g["attn_head3"])).abs().max())
     print(f"g0 head-3 attention probabilities: max abs error {aw_err:.2e}")
-    assert aw_err < AW_MAX_TOL  # probabilities in [0,1]
+    assert aw_err < AW_MAX_TOL_TINY  # probabilities in [0,1]
     assert (aw.reshape(2, 30, -1).sum(-1) - 1).abs().max() < 1e-4
     # need_attn_weights must not change the score map (same kernels, extra output only)
     out2 = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)
@@ -240,6 +243,67 @@ def test_fp16_operand_range_on_scaled_up_weights():
     mae, mx = _compare(out, ref)
     print(f"scaled-up weights: MAE {mae:.2e} max {mx:.2e}")
     assert mae < MAE_TOL, (mae, mx)
+
+
+def test_bf16_operand_mode_matches_oracle():
+    """cs_config.operand_dtype = bf16 (north_star / BASELINE cfg-2 say bf16; the path's default is fp16): same kernels with the bf16
+    MFMA forms and bf16 activations / weights.  8 significant bits instead of 11: the budget the oracle's operand-rounding emulation
+    predicts is 8e-4 score-map MAE, inside north_star's 1e-3."""
+    for backbone, seed, (B, N, H, W) in ((TINY, 3, (2, 2, 75, 90)), ("facebook/dinov2-small", 1, (1, 5, 518, 518))):
+        net, arch, sd = _net(backbone, seed)
+        net.operand_dtype = "bf16"
+        q, r = synth.make_inputs(B, N, H, W, seed)
+        out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+        torch.cuda.synchronize()
+        ref = _oracle(arch, sd, q, r)["score_map_ref_cross"]
+        mae, mx = _compare(out, ref)
+        print(f"bf16 operands, {backbone}: MAE {mae:.2e} max {mx:.2e}")
+        assert torch.isfinite(out).all() and mae < 1e-3 and mx < 2e-2, (backbone, mae, mx)
+        assert net.nonfinite_count() == 0
+        # the cached-reference mode carries bf16 tokens and stays bit-identical to the full forward
+        tok = net.encode_references(torch.from_numpy(r).cuda().reshape(-1, 3, H, W)).reshape(B, N, -1, arch.hidden)
+        assert tok.dtype == torch.bfloat16
+        assert torch.equal(net.forward_cached(torch.from_numpy(q).cuda(), tok)["score_map_ref_cross"], out)
+        net.operand_dtype = "fp16"
+        net._mark_dirty()
+        out16 = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+        assert _compare(out16, ref)[0] < mae  # (and the default mode is the more accurate one)
+
+
+def test_fp16_overflow_is_reported_and_bf16_mode_survives():
+    """DINOv2-style outliers at ViT-S width: two residual channels carry +-300 (through the position embeddings), and
+    eight hidden units of two encoder layers' MLPs are scaled so that their pre-activations pass 65504 (fc1 rows x 3e4, the matching fc2
+    columns x 1 / 3e4, so the fp32 model stays sane).  fp16 operands: the hidden overflows to inf, the score map turns NaN and the
+    handle REPORTS it (cs_nonfinite_count > 0) -- nothing clamps silently.  bf16 operands: finite, and inside north_star's bound."""
+    net, arch, sd = _net("facebook/dinov2-small", 1)
+    sd = {k: v.copy() for k, v in sd.items()}
+    sd["backbone.embeddings.position_embeddings"][0, :, 5] += 300.0
+    sd["backbone.embeddings.position_embeddings"][0, :, 200] -= 300.0
+    S = 3.0e4
+    for l in (4, 9):
+        p = f"backbone.encoder.layer.{l}.mlp."
+        sd[p + "fc1.weight"][:8] *= S
+        sd[p + "fc1.bias"][:8] *= S
+        sd[p + "fc2.weight"][:, :8] /= S
+    q, r = synth.make_inputs(1, 5, 518, 518, 1)
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    taps = {}
+    ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), taps=taps)["score_map_ref_cross"]
+    net.load_numpy_state_dict(sd)
+    out16 = net(tq, tr, False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    bad = net.nonfinite_count()
+    print(f"fp16 operands with outliers: {bad} non-finite score values, finite {bool(torch.isfinite(out16).all())}")
+    assert bad > 0 and not torch.isfinite(out16).all()
+    assert net.nonfinite_count() == 0  # (the count is reset by the query)
+    net.operand_dtype = "bf16"
+    net._mark_dirty()
+    outb = net(tq, tr, False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    mae, mx = _compare(outb, ref)
+    print(f"bf16 operands with outliers: MAE {mae:.2e} max {mx:.2e}")
+    assert torch.isfinite(outb).all() and net.nonfinite_count() == 0
+    assert mae < 1e-3, (mae, mx)
 
 
 def test_pos_embed_scale_factor_interpolation_option():

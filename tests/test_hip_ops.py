@@ -159,6 +159,48 @@ def test_gemm256_matches_reference_and_small_tile_kernel(M, N, K):
     assert torch.equal(outs[True][0], outs[False][0])
 
 
+def test_ops_in_bf16_operand_mode():
+    """The single-op entry points with bfloat16 operands (cs_op_set_operand_dtype(1)): both GEMM kernels exact on small integers (which
+    bf16 holds exactly), bias + GELU / residual epilogues and attention against fp32 references at bf16 tolerances."""
+    lib = _lib.load()
+    assert lib.cs_op_set_operand_dtype(1) == 0
+    try:
+        for (M, N, K) in ((300, 384, 256), (700, 512, 1024)):  # 128-row kernel / 256 x 256 x 64-tile kernel
+            A = ((torch.arange(M, device=DEV)[:, None] * 5 + torch.arange(K, device=DEV)[None, :] * 3) % 7 - 3.0)
+            W = ((torch.arange(N, device=DEV)[:, None] * 3 + torch.arange(K, device=DEV)[None, :] * 7) % 5 - 2.0)
+            b = (torch.arange(N, device=DEV) % 11 - 5.0)
+            out = hh.gemm(A.to(torch.bfloat16).view(torch.float16), W.to(torch.bfloat16).view(torch.float16), b, _lib.EPI_RESID_F32)
+            torch.cuda.synchronize()
+            assert torch.equal(out, A @ W.t() + b), (M, N, K)
+        g = _rng(77)
+        M, N, K = 1370, 768, 768
+        A = _t(g.standard_normal((M, K), dtype=np.float32)).to(torch.bfloat16)
+        W = _t(g.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).to(torch.bfloat16)
+        b = _t(g.standard_normal((N,), dtype=np.float32))
+        y = A.float() @ W.float().t() + b
+        og = hh.gemm(A.view(torch.float16), W.view(torch.float16), b, _lib.EPI_BIAS_GELU_F16).view(torch.bfloat16)
+        refg = orc.gelu_erf(y.cpu()).to(DEV)
+        torch.cuda.synchronize()
+        err = (og.float() - refg).abs()
+        assert (err <= 4.2e-3 * refg.abs() + 3e-4).all(), float((err - 4.2e-3 * refg.abs()).max())  # bf16 output: half an ulp = rel 2^-8
+        # attention, dh = 64 and 48
+        for dh, heads in ((64, 6), (48, 8)):
+            B, Lq, Lk = 2, 300, 500
+            Q = _t(g.standard_normal((B, Lq, heads * dh), dtype=np.float32))
+            Kt = _t(g.standard_normal((B, Lk, heads * dh), dtype=np.float32))
+            V = _t(g.standard_normal((B, Lk, heads * dh), dtype=np.float32))
+            Qb, Kb, Vb = (t.to(torch.bfloat16) for t in (Q, Kt, V))
+            O = hh.attention(Qb.view(torch.float16), Kb.view(torch.float16), Vb.view(torch.float16), heads, dh).view(torch.bfloat16)
+            qh, kh, vh = (t.float().view(B, -1, heads, dh).transpose(1, 2) for t in (Qb, Kb, Vb))
+            ref = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(dh), -1) @ vh
+            ref = ref.transpose(1, 2).reshape(B, Lq, heads * dh)
+            torch.cuda.synchronize()
+            d = (O.float() - ref).abs()
+            assert float(d.max()) < 3e-2 and float(d.mean()) < 3e-3, (dh, float(d.max()), float(d.mean()))
+    finally:
+        lib.cs_op_set_operand_dtype(0)
+
+
 def _row_partials(x, sp):
     """(sum, sumsq) of each row of x over the column ranges the producing epilogue's (column tile, wave) pairs own."""
     M, Cc = x.shape
