@@ -189,6 +189,8 @@ def dinov2_encoder(imgs: Tensor, Wt: Dict[str, Tensor], enc_heads: int, P: int, 
         x = x + a * Wt[p + "layer_scale1.lambda1"]
         u = layer_norm(x, Wt[p + "norm2.weight"], Wt[p + "norm2.bias"], 1e-6)
         m = gelu_erf(linear(u, Wt[p + "mlp.fc1.weight"], Wt[p + "mlp.fc1.bias"], rnd))
+        if taps is not None:
+            taps[f"enc_mlp_hidden_absmax_{l}"] = m.abs().amax(dim=(0, 1))  # per hidden unit (range tests of the 16-bit operand types)
         m = linear(m, Wt[p + "mlp.fc2.weight"], Wt[p + "mlp.fc2.bias"], rnd)
         x = x + m * Wt[p + "layer_scale2.lambda1"]
         if taps is not None:

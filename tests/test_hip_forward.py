@@ -272,23 +272,29 @@ def test_bf16_operand_mode_matches_oracle():
 
 def test_fp16_overflow_is_reported_and_bf16_mode_survives():
     """DINOv2-style outliers at ViT-S width: two residual channels carry +-300 (through the position embeddings), and
-    eight hidden units of two encoder layers' MLPs are scaled so that their pre-activations pass 65504 (fc1 rows x 3e4, the matching fc2
-    columns x 1 / 3e4, so the fp32 model stays sane).  fp16 operands: the hidden overflows to inf, the score map turns NaN and the
+    eight hidden units of two encoder layers' MLPs are scaled so that their activations reach 2e5 > 65504 (fc1 rows x S, the matching fc2
+    columns x 1 / S, so the fp32 model stays sane; S from the oracle's own activations).  fp16 operands: the hidden overflows to inf, the score map turns NaN and the
     handle REPORTS it (cs_nonfinite_count > 0) -- nothing clamps silently.  bf16 operands: finite, and inside north_star's bound."""
     net, arch, sd = _net("facebook/dinov2-small", 1)
     sd = {k: v.copy() for k, v in sd.items()}
     sd["backbone.embeddings.position_embeddings"][0, :, 5] += 300.0
     sd["backbone.embeddings.position_embeddings"][0, :, 200] -= 300.0
-    S = 3.0e4
+    q, r = synth.make_inputs(1, 5, 518, 518, 1)
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    # scale chosen from the fp32 oracle itself: the eight units' activations must reach 2e5 (3 x the largest finite half)
     for l in (4, 9):
+        taps = {}
+        orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), taps=taps)
+        S = 2.0e5 / float(taps[f"enc_mlp_hidden_absmax_{l}"][:8].max())
         p = f"backbone.encoder.layer.{l}.mlp."
         sd[p + "fc1.weight"][:8] *= S
         sd[p + "fc1.bias"][:8] *= S
         sd[p + "fc2.weight"][:, :8] /= S
-    q, r = synth.make_inputs(1, 5, 518, 518, 1)
-    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
     taps = {}
     ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), taps=taps)["score_map_ref_cross"]
+    hid = max(float(taps[f"enc_mlp_hidden_absmax_{l}"][:8].max()) for l in (4, 9))
+    print(f"oracle: largest hidden activation of the scaled units {hid:.3g}")
+    assert hid > 1.5e5 and torch.isfinite(ref).all()
     net.load_numpy_state_dict(sd)
     out16 = net(tq, tr, False, 0, False)["score_map_ref_cross"]
     torch.cuda.synchronize()
