@@ -100,23 +100,18 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
     kgo[it] = ((unsigned)skey[it] * (unsigned)p.ldk + (unsigned)sch[it] * 8u) * 2u;
     vgo[it] = ((unsigned)skey[it] * (unsigned)p.ldv + (unsigned)sch[it] * 8u) * 2u;
   }
+  // K / V tiles through buffer loads: scalar tile offset + this thread's 32-bit offset, and the descriptor's range check returns zeros for
+  // keys past Lk (they are masked to -inf in S and multiply p = 0 in PV), so the ragged last tile needs no clamped addresses and no
+  // second code path (cdna_hip_programming T8)
+  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(Kb), 0, (int)(((size_t)(p.Lk - 1) * p.ldk + DH) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(Vb), 0, (int)(((size_t)(p.Lk - 1) * p.ldv + DH) * 2), 0x00020000);
 #define CS_ATTN_LOAD_TILE(T)                                                                       \
-  if ((T) * 64 + 64 <= p.Lk) {                                                                     \
-    const char* kt_ = reinterpret_cast<const char*>(Kb + (size_t)(T) * 64 * p.ldk);                \
-    const char* vt_ = reinterpret_cast<const char*>(Vb + (size_t)(T) * 64 * p.ldv);                \
+  {                                                                                                \
+    const int ks_ = (T) * 64 * p.ldk * 2, vs_ = (T) * 64 * p.ldv * 2;                              \
     _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
       if (kFullLast || it + 1 < NIT || tid + it * 256 < 64 * CH) {                                 \
-        kreg[it] = *reinterpret_cast<const uint4*>(kt_ + kgo[it]);                                 \
-        vreg[it] = *reinterpret_cast<const uint4*>(vt_ + vgo[it]);                                 \
-      }                                                                                            \
-    }                                                                                              \
-  } else {                                                                                         \
-    _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
-      if (kFullLast || it + 1 < NIT || tid + it * 256 < 64 * CH) {                                 \
-        int key_ = (T) * 64 + skey[it];                                                            \
-        key_ = key_ < p.Lk ? key_ : p.Lk - 1;                                                      \
-        kreg[it] = *reinterpret_cast<const uint4*>(Kb + (size_t)key_ * p.ldk + sch[it] * 8);       \
-        vreg[it] = *reinterpret_cast<const uint4*>(Vb + (size_t)key_ * p.ldv + sch[it] * 8);       \
+        kreg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(k_rs, kgo[it], ks_, 0)); \
+        vreg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v_rs, vgo[it], vs_, 0)); \
       }                                                                                            \
     }                                                                                              \
   }
@@ -174,38 +169,40 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
     const char* kb = smem + (t & 1) * Cfg::STAGE;
     const char* vb = kb + Cfg::KTILE;
 
-    // ---- S^T - m = K Q^T - m : two 32-key sub-tiles ----
     f32x16_t st[2];
+    float ps0 = 0.f, ps1 = 0.f;  // two chains of plain v_add_f32 (packed f32 adds cost more issue cycles than they save)
+    h16x8_t pf[2][2];
+    auto scores = [&]() {  // S^T - m = K Q^T - m : two 32-key sub-tiles (-m_run enters through the C operand), ragged tail masked
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
+      for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        h16x8_t kf = *reinterpret_cast<const h16x8_t*>(kb + koff + k2 * 32 * Cfg::KROW + s * 32);
-        st[k2] = mfma_32x32x16<BF>(kf, qf[s], s == 0 ? negm : st[k2]);
-      }
-    }
-    // ---- mask the ragged tail (keys >= Lk) : wave-uniform branch ----
-    if (t == nt - 1 && (p.Lk & 63)) {
-      const int kbase = t * 64 + 4 * hh;
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = kbase + k2 * 32 + (e & 3) + 8 * (e >> 2);
-          if (key >= p.Lk) st[k2][e] = -INFINITY;
+        for (int s = 0; s < KS; ++s) {
+          h16x8_t kf = *reinterpret_cast<const h16x8_t*>(kb + koff + k2 * 32 * Cfg::KROW + s * 32);
+          st[k2] = mfma_32x32x16<BF>(kf, qf[s], s == 0 ? negm : st[k2]);
         }
-    }
-    float tmax = st[0][0];
+      }
+      if (t == nt - 1 && (p.Lk & 63)) {  // keys >= Lk : wave-uniform branch
+        const int kbase = t * 64 + 4 * hh;
 #pragma unroll
-    for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
+        for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));  // the row's maximum of this tile, relative to m_run
-    CS_TS(0);
-    // ---- move the reference (rare after the first tiles): wave-uniform branch ----
-    if (t == 0 || __builtin_amdgcn_ballot_w64(tmax > kTau) != 0) {
-      const float delta = t == 0 ? tmax : fmaxf(tmax, 0.f);  // every tile holds a valid key: finite
-      const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+          for (int e = 0; e < 16; ++e) {
+            const int key = kbase + k2 * 32 + (e & 3) + 8 * (e >> 2);
+            if (key >= p.Lk) st[k2][e] = -INFINITY;
+          }
+      }
+    };
+    auto row_max = [&]() {
+      float tm = st[0][0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) tm = fmaxf(tm, st[0][e]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tm = fmaxf(tm, st[1][e]);
+      return fmaxf(tm, __shfl_xor(tm, 32, 64));  // the row's maximum of this tile, relative to m_run
+    };
+    // moves the reference point by `delta` (st, l and O follow): the rare path
+    auto move_reference = [&](float delta, bool first) {
+      const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
       m_run += delta;
 #pragma unroll
       for (int e = 0; e < 16; ++e) negm[e] = -m_run;
@@ -219,23 +216,33 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
       for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[d][e] *= alpha;
-    }
-    float ps0 = 0.f, ps1 = 0.f;  // two chains of plain v_add_f32 (packed f32 adds cost more issue cycles than they save)
-    h16x8_t pf[2][2];
+    };
+    auto exp_pack = [&]() {
+      ps0 = 0.f; ps1 = 0.f;
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+      for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
+        for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const float pa = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j]);
-          const float pb = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j + 1]);
-          ps0 += pa;
-          ps1 += pb;
-          pf[k2][s2][j] = __builtin_bit_cast(_Float16, f2o<BF>(pa));
-          pf[k2][s2][j + 1] = __builtin_bit_cast(_Float16, f2o<BF>(pb));
+          for (int j = 0; j < 8; j += 2) {
+            const float pa = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j]);
+            const float pb = __builtin_amdgcn_exp2f(st[k2][8 * s2 + j + 1]);
+            ps0 += pa;
+            ps1 += pb;
+            pf[k2][s2][j] = __builtin_bit_cast(_Float16, f2o<BF>(pa));
+            pf[k2][s2][j + 1] = __builtin_bit_cast(_Float16, f2o<BF>(pb));
+          }
         }
-      }
+    };
+    // (Tried, r3: no row maximum on the common pass -- form p at once and let the tile's row sum, needed anyway, tell whether the reference
+    //  point was still good, redoing the tile otherwise.  18 VALU instructions less per tile, but on peaky rows the redo fires often and
+    //  costs a second QK^T: 290 vs 220 us per encoder launch of 48 images.  The lazily moved reference below stays.)
+    scores();
+    const float tmax = row_max();
+    CS_TS(0);
+    // ---- move the reference (rare after the first tiles): wave-uniform branch ----
+    if (t == 0 || __builtin_amdgcn_ballot_w64(tmax > kTau) != 0) move_reference(t == 0 ? tmax : fmaxf(tmax, 0.f), t == 0);
+    exp_pack();
     l_run += ps0 + ps1;
     CS_TS(1);
 
