@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
 #pragma unroll
       for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[s][j] = __builtin_bit_cast(_Float16, f2o<BF>(o2f<BF>(__builtin_bit_cast(h16_t, qf[s][j])) * sc));
+        for (int j = 0; j < 8; ++j) {
+          const _Float16 e = qf[s][j];  // (a scalar copy first: __builtin_bit_cast applied to the vector element itself miscompiles, r3)
+          qf[s][j] = __builtin_bit_cast(_Float16, f2o<BF>(o2f<BF>(__builtin_bit_cast(h16_t, e)) * sc));
+        }
     }
   }
 
