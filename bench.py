@@ -98,7 +98,7 @@ def roofline_of(dom):
     return r
 
 
-TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"
 
 
 def pmc_traffic(kernel_name):

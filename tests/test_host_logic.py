@@ -227,6 +227,27 @@ def test_predict_config_defaults_to_the_reference_environments_pos_embed_resize(
     assert CrossScoreNet(load_config("default_predict"))._pos_legacy and not CrossScoreNet(model_config())._pos_legacy
 
 
+def test_asm_audits_of_the_inline_asm_kernels(tmp_path):
+    """gemm256.hip keeps inline-asm global loads in flight (residual rows) and both gemm256.hip and panel.hip read LDS by inline asm behind
+    counted waits: hipcc does not know when those registers are written.  The audits scan the build's .s for any instruction that touches
+    such a register before its marker / wait (a compiler copy there faulted on the GPU in r3: phi copies of in-flight registers)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    from crossscore_amd import build as b
+    for src, audits in (("gemm256.hip", ("asm_audit_gl.py", "asm_audit.py")), ("panel.hip", ("asm_audit.py",))):
+        out = str(tmp_path / (src + ".s"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + b.EXTRA_FLAGS.get(src, []) + [
+            "-S", "--cuda-device-only", "-o", out, os.path.join(REPO, "crossscore_amd", "csrc", src)]
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert res.returncode == 0, res.stdout[-2000:]
+        text = open(out).read()
+        assert ".vgpr_spill_count: 0" in text and not [ln for ln in text.splitlines() if "vgpr_spill_count" in ln and not ln.strip().endswith(" 0")], src
+        for a in audits:
+            r = subprocess.run([sys.executable, os.path.join(REPO, "tools", a), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert "violations: 0" in r.stdout, (src, a, r.stdout[-1500:])
+
+
 def test_import_does_not_edit_the_environment():
     """Importing the package must not change process-wide runtime configuration; configure_runtime() is the
     explicit call, and an explicit setting wins."""

@@ -1,0 +1,24 @@
+"""Copies the summaries of one tools/profile_round.sh run (gpurun_out/prof_<tag>/) into profiles/<tag>_* and stamps the traffic table with
+the commit it was measured at.  usage: collect_profiles.py r03"""
+import json, os, shutil, subprocess, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+O = os.path.join(R, "gpurun_out", "prof_" + tag)
+P = os.path.join(R, "profiles")
+commit = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip()
+def line(src):  # last JSON line of a bench output
+    return json.loads([l for l in open(src).read().splitlines() if l.startswith("{")][-1])
+for src, dst in (("bench.json", "bench.json"), ("bench_bf16.json", "bench_bf16.json"), ("bench_cfg3.json", "bench_cfg3.json"),
+                 ("bench_cfg4.json", "bench_cfg4.json"), ("bench_cfg5.json", "bench_cfg5.json")):
+    json.dump(line(os.path.join(O, src)), open(os.path.join(P, f"{tag}_{dst}"), "w"), indent=1)
+for src, dst in (("default_kernel_stats.csv", "kernel_stats.csv"), ("alone_kernel_stats.csv", "kernel_stats_alone.csv"),
+                 ("alone_cfg4_kernel_stats.csv", "kernel_stats_alone_cfg4.csv"), ("attn_pmc.json", "attn_pmc.json"),
+                 ("timeline.json", "timeline.json"), ("gemm_vs_blas.log", "gemm_vs_blas.txt")):
+    shutil.copy(os.path.join(O, src), os.path.join(P, f"{tag}_{dst}"))
+for src, dst, cmd in (("alone_hbm_traffic.json", "hbm_traffic.json", "bench.py --no-cpu-baseline --no-eager --no-cfg4 --inflight 1 --lanes 1 --chunk 48 --steps 3 --warmup 1"),
+                      ("alone_cfg4_hbm_traffic.json", "hbm_traffic_cfg4.json", "bench.py --workload cfg4 --no-cpu-baseline --no-eager --no-cfg4 --inflight 1 --lanes 1 --chunk 96 --steps 2 --warmup 1")):
+    t = json.load(open(os.path.join(O, src)))
+    t["_meta"] = {"commit": commit, "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 {cmd} (tools/profile_round.sh)",
+                  "note": "FETCH_SIZE counts 64 B per 128-B request on gfx950 (fetch_bytes_corrected = 2 x); hbm_bytes_per_launch = fetch_bytes_corrected + write_bytes"}
+    json.dump(t, open(os.path.join(P, f"{tag}_{dst}"), "w"), indent=1, sort_keys=True)
+print("collected into", P, "at", commit)

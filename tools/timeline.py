@@ -1,6 +1,6 @@
 """Concurrency timeline of one bench run from a rocprofv3 --kernel-trace CSV: how much of the steady-state time has 0 / 1 / >=2
-kernels in flight, and which kernels run while nothing else does.  usage: timeline.py <dir with *kernel_trace.csv>"""
-import collections, csv, glob, os, sys
+kernels in flight, and which kernels run while nothing else does.  usage: timeline.py <dir with *kernel_trace.csv> [summary.json]"""
+import collections, csv, glob, json, os, sys
 fn = glob.glob(os.path.join(sys.argv[1], "**/*kernel_trace.csv"), recursive=True)[0]
 rows = [r for r in csv.DictReader(open(fn))]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
@@ -37,3 +37,17 @@ print("%d steps, %.2f ms per step" % (steps, (hi - lo) / 1e6 / steps))
 print("steady-state window %.1f ms: idle %.1f %%, one kernel %.1f %%, two %.1f %%, three+ %.1f %%" % (tot / 1e6, *(100 * hist[i] / tot for i in range(4))))
 print("time with exactly one kernel in flight, by kernel:")
 for k, v in solo.most_common(8): print("   %-42s %.1f %%" % (k, 100 * v / tot))
+
+if len(sys.argv) > 2:
+    # per-kernel solo durations of the same window (average wall time of a launch; overlapped launches include their neighbours' work)
+    per = collections.defaultdict(list)
+    for s_, e_, n in ev:
+        if s_ >= lo and e_ <= hi:
+            per[n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]].append((e_ - s_) / 1e3)
+    json.dump({"source": "rocprofv3 --kernel-trace of the default bench.py command; tools/timeline.py", "steps": steps,
+               "ms_per_step": (hi - lo) / 1e6 / steps, "window_ms": tot / 1e6,
+               "fraction_of_time_with_kernels_in_flight": {"0": hist[0] / tot, "1": hist[1] / tot, "2": hist[2] / tot, "3+": hist[3] / tot},
+               "alone_in_flight_by_kernel": {k: v / tot for k, v in solo.most_common(12)},
+               "launch_wall_us_in_this_window": {k: {"launches": len(v), "avg": sum(v) / len(v), "min": min(v), "max": max(v)}
+                                                 for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:14]}},
+              open(sys.argv[2], "w"), indent=1)
