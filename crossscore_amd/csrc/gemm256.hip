@@ -49,6 +49,16 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 template <int V> using IC = std::integral_constant<int, V>;
 
+#ifdef CS_G256_STAMP
+// diagnostic builds only (tools/gemm256_phases.py): per (block < 64, wave) cycles summed over the K loop of
+//   4 p + 0: load segment of phase p (LDS reads, LDS-DMA issue, counted wait)   4 p + 1: its barrier
+//   4 p + 2: LDS wait + 16 MFMAs                                                 4 p + 3: the barrier behind them;    16: seam + epilogue
+__device__ unsigned long long g_g256_dbg[64 * 8 * 20];
+#define G_TS(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+    ph[k] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define G_TS(k) do { } while (0)
+#endif
 #define G_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define G_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define G_SB() __builtin_amdgcn_sched_barrier(0)
@@ -238,6 +248,11 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
   bar();               // K tile 0 has landed for everyone; the bias vector is in LDS
   if (wm == 1) bar();  // the second M half runs one barrier behind the first
 
+#ifdef CS_G256_STAMP
+  unsigned long long ph[20] = {};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long tbegin = tlast, rbegin = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- one K tile (buffer B).  kt0: the first K tile of an output tile (its successor's late pieces were issued at the seam) ----
   // last: the output tile's last K tile.  Its final barrier is left to the caller for the second M half (wm == 1), which then runs its seam
   // (epilogue) BEFORE that barrier, i.e. beside the first half's seam instead of after it: the halves are one barrier apart, and with
@@ -247,21 +262,21 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     // phase 1: quadrant (0, 0)
     ld_w(IC<B>{}, IC<0>{}); ld_a(IC<B>{}, IC<0>{});
     if (!kt0 && l_valid) stage(IC<2>{});
-    bar_then_wait(); mma(IC<0>{}, IC<0>{}); bar();
+    G_TS(0); bar_then_wait(); G_TS(1); mma(IC<0>{}, IC<0>{}); G_TS(2); bar(); G_TS(3);
     // phase 2: quadrant (0, 1)
     ld_w(IC<B>{}, IC<1>{});
     if (!kt0 && l_valid) { stage(IC<3>{}); advance(); }
-    bar_then_wait(); mma(IC<0>{}, IC<1>{}); bar();
+    G_TS(4); bar_then_wait(); G_TS(5); mma(IC<0>{}, IC<1>{}); G_TS(6); bar(); G_TS(7);
     // phase 3: quadrant (1, 1)
     ld_a(IC<B>{}, IC<1>{});
     const bool more = l_valid;
     if (more) stage(IC<0>{});
-    bar_then_wait(); mma(IC<1>{}, IC<1>{}); bar();
+    G_TS(8); bar_then_wait(); G_TS(9); mma(IC<1>{}, IC<1>{}); G_TS(10); bar(); G_TS(11);
     // phase 4: quadrant (1, 0); the next K tile has landed behind this phase's first barrier (the two pieces just issued stay in flight)
     if (more) { stage(IC<1>{}); G_VMCNT(4); }
     else G_VMCNT(0);
-    bar_then_wait(); mma(IC<1>{}, IC<0>{});
-    if (!(last && wm == 1)) bar();
+    G_TS(12); bar_then_wait(); G_TS(13); mma(IC<1>{}, IC<0>{}); G_TS(14);
+    if (!(last && wm == 1)) { bar(); G_TS(15); }
   };
 
   for (int idx = slot; idx < ntile_x; idx += slots) {
@@ -369,7 +384,16 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     }
     G_SB();
     if (wm == 1) bar();  // (the last K tile's final barrier of the second half)
+    G_TS(16);
   }
+#ifdef CS_G256_STAMP
+  if (blockIdx.x < 64 && lane == 0) {
+    unsigned long long* d = g_g256_dbg + (blockIdx.x * 8 + wv) * 20;
+    for (int k = 0; k < 17; ++k) d[k] = ph[k];
+    d[17] = __builtin_amdgcn_s_memtime() - tbegin;
+    d[18] = __builtin_amdgcn_s_memrealtime() - rbegin;
+  }
+#endif
   if (wm == 0) bar();  // the first half's matching barrier
 }
 
@@ -404,6 +428,10 @@ hipError_t launch256(const CsGemmParams& p, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+#ifdef CS_G256_STAMP
+int cs_gemm256_debug_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_g256_dbg), sizeof(g_g256_dbg)); }
+#endif
 
 // tools / tests: 0 routes every GEMM to gemm.hip's kernel again
 void cs_gemm256_enable(int on) { g_enabled = on; }
