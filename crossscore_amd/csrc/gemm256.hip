@@ -335,11 +335,14 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
       G_LGKM(0); out(IC<7>{});
     } else {
       // fp32: 16 steps of (16 rows x 32 columns): sub-tile (i, nh) = accumulators [i][2 nh], [i][2 nh + 1].  The residual rows are loaded
-      // one step ahead by inline asm (vector-memory order: L0 L1 | S0 L2 | S1 L3 | ..: when step t's rows are needed, the two loads of
-      // step t + 1 and the two stores of step t - 1 are younger: vmcnt(4); the DMA pieces issued above are older and have to land first)
+      // FOUR steps ahead by inline asm into four register sets (the operand fragments' registers are free here).  Two steps ahead (r3's
+      // first form) left one 2-KiB request per wave in flight behind each wait: 16 memory latencies per tile, as long as the tile's K loop
+      // at K = 768.  Vector-memory order: L0 L1 L2 L3 | S0 L4 | S1 L5 | .. | S11 L15 | S12 | S13 | S14 | S15 (two instructions each); when
+      // step t's rows are needed the younger instructions number G_RCNT(t) below (the DMA pieces issued above are older: they land first).
       // The loads' destination registers are written when the data arrives, not at the asm statement: nothing may touch them in between
-      // (tools/asm_audit.py checks the build's .s for that).
-      [[maybe_unused]] f32x4_t ra0, ra1, rb0, rb1;
+      // (tools/asm_audit_gl.py checks the build's .s for that).
+#define G_RCNT(t) ((t) <= 3 ? 6 + 2 * (t) : (t) <= 12 ? 12 : 12 - 2 * ((t) - 12))
+      [[maybe_unused]] f32x4_t ra0, ra1, rb0, rb1, rc0, rc1, rd0, rd1;
       auto rload = [&](auto S_, f32x4_t& r0, f32x4_t& r1) {
         constexpr int st = decltype(S_)::value;
         constexpr int i = st >> 1, nh = st & 1;
@@ -366,21 +369,22 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
         if (row_w + 16 * i + 8 + rrow < p.M) *reinterpret_cast<f32x4_t*>(o + (size_t)8 * p.ldc) = seg1;
       };
       const bool full = cm0 + G_BM <= p.M;  // a ragged tile's masked stores make the store count unknown: its waits are vmcnt(0)
-      if constexpr (RES) { rload(IC<0>{}, ra0, ra1); rload(IC<1>{}, rb0, rb1); }
+      if constexpr (RES) { rload(IC<0>{}, ra0, ra1); rload(IC<1>{}, rb0, rb1); rload(IC<2>{}, rc0, rc1); rload(IC<3>{}, rd0, rd1); }
       put(IC<0>{}); get();
 #define G_STEPF(S, R0, R1)                                                                     \
       put(IC<S>{}); G_LGKM(2);                                                                 \
-      if constexpr (RES) { if (full) { if (S - 1 >= 1) G_VMCNT(4); else G_VMCNT(2); } else G_VMCNT(0); } \
+      if constexpr (RES) { if (full) G_VMCNT(G_RCNT(S - 1)); else G_VMCNT(0); }                \
       G_SB(); out(IC<S - 1>{}, R0, R1); G_SB();                                                \
-      if constexpr (RES && S + 1 < 16) rload(IC<(S + 1 < 16 ? S + 1 : 0)>{}, R0, R1);          \
+      if constexpr (RES && S + 3 < 16) rload(IC<(S + 3 < 16 ? S + 3 : 0)>{}, R0, R1);          \
       get();
-      G_STEPF(1, ra0, ra1) G_STEPF(2, rb0, rb1) G_STEPF(3, ra0, ra1) G_STEPF(4, rb0, rb1) G_STEPF(5, ra0, ra1) G_STEPF(6, rb0, rb1)
-      G_STEPF(7, ra0, ra1) G_STEPF(8, rb0, rb1) G_STEPF(9, ra0, ra1) G_STEPF(10, rb0, rb1) G_STEPF(11, ra0, ra1) G_STEPF(12, rb0, rb1)
-      G_STEPF(13, ra0, ra1) G_STEPF(14, rb0, rb1) G_STEPF(15, ra0, ra1)
+      G_STEPF(1, ra0, ra1) G_STEPF(2, rb0, rb1) G_STEPF(3, rc0, rc1) G_STEPF(4, rd0, rd1) G_STEPF(5, ra0, ra1) G_STEPF(6, rb0, rb1)
+      G_STEPF(7, rc0, rc1) G_STEPF(8, rd0, rd1) G_STEPF(9, ra0, ra1) G_STEPF(10, rb0, rb1) G_STEPF(11, rc0, rc1) G_STEPF(12, rd0, rd1)
+      G_STEPF(13, ra0, ra1) G_STEPF(14, rb0, rb1) G_STEPF(15, rc0, rc1)
 #undef G_STEPF
       G_LGKM(0);
-      if constexpr (RES) { if (full) G_VMCNT(2); else G_VMCNT(0); }  // step 15's rows: only step 14's two stores are younger
-      G_SB(); out(IC<15>{}, rb0, rb1);
+      if constexpr (RES) { if (full) G_VMCNT(G_RCNT(15)); else G_VMCNT(0); }
+      G_SB(); out(IC<15>{}, rd0, rd1);
+#undef G_RCNT
     }
     G_SB();
     if (wm == 1) bar();  // (the last K tile's final barrier of the second half)
