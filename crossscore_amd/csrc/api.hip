@@ -15,6 +15,13 @@
 #include <string>
 #include <vector>
 
+// patch.hip (C++ linkage)
+size_t cs_patch_pack_elems(int C);
+hipError_t cs_patch_pack_launch(const float* w, int C, h16_t* out, int bf, hipStream_t st);
+int cs_patch_fused_supported(int H, int W, int P, int C);
+hipError_t cs_patch_fused_launch(const float* xq, const float* xr, int N, int img0, int I, int H, int W, int C, const h16_t* wfrag,
+                                 const float* bias, const float* pos, const float* wsum, float* x, int bf, hipStream_t st);
+
 extern "C" {
 const char* cs_gemm_check(const CsGemmParams* p, int epi);
 hipError_t cs_gemm_launch(const CsGemmParams* p, int epi, hipStream_t stream);
@@ -108,6 +115,7 @@ struct cs_model {
   std::vector<void*> owned;  // device allocations of packed weights
   // packed
   h16_t* Wpatch = nullptr; float* bpatch = nullptr;
+  h16_t* Wpatch_frag = nullptr;  // fragment-ordered copy for the one-launch patch embedding (patch.hip); null when C is not 384 n or P != 14
   float* wsum = nullptr;  // [3][C] fp32 sums of the patch weights per channel (mean-centred patch embedding)
   std::vector<EncLayer> enc;
   std::vector<DecLayer> dec;
@@ -485,6 +493,11 @@ int cs_finalize(cs_handle h) {
   h->cls = t_cls->d; h->pos = t_pos->d; h->bpatch = t_pb->d;
   { ALLOC_BF(wp, (size_t)C * h->Kp) if (int r = pack(t_pw->d, (int)C, (int)(3 * P * P), h->Kp, wp)) return r; h->Wpatch = wp; }
   { ALLOC_F(ws, (size_t)3 * C) HIPCHK(cs_patch_wsum_launch(t_pw->d, (int)C, (int)P, ws, st)); h->wsum = ws; }
+  if (P == 14 && C % 384 == 0) {
+    ALLOC_BF(wf, cs_patch_pack_elems((int)C))
+    HIPCHK(cs_patch_pack_launch(t_pw->d, (int)C, wf, c.operand_dtype, st));
+    h->Wpatch_frag = wf;
+  }
   // softmax scale folded into the Q projections: the attention kernel takes Q pre-multiplied by log2(e)/sqrt(dh) (scale_log2e = 1),
   // so the factor is applied to the fp32 weights and biases before their single fp16 rounding instead of to fp16 Q values
   ALLOC_F(qs_enc, (size_t)C) ALLOC_F(qs_dec, (size_t)C)
@@ -756,18 +769,24 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     // patches are mean-centred per channel before the fp16 rounding; the patch GEMM adds mean * sum(W) back in fp32
     float* pmean = p.pmean[slot];
     if (stage == -1) {
-    L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, pmean, bf, s), "im2col"); L.end();
     const bool fold = h->lnfold;
     h16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
     L.begin(32, 0);
     L.misc(cs_cls_rows_launch(x, ic, p.T, C, h->cls, h->pos_tab, fold ? u : nullptr, fold ? stats : nullptr, h->ln_sp, bf, s), "cls");
     L.end();
-    {
+    if (!fold && h->Wpatch_frag && cs_patch_fused_supported(H, W, P, C)) {
+      // one launch: strip -> centred fp16 tile in LDS -> MFMA -> token rows (patch.hip).  Algorithmic bytes: the images once, the rows once
+      L.begin(CS_EPI_PATCH_F32, 2.0 * ic * p.Np * C * 3.0 * P * P, 12.0 * ic * H * W + 4.0 * ic * p.Np * C + 4.0 * p.Np * C);
+      L.misc(cs_patch_fused_launch(query, refs, N_enc, i0, ic, H, W, C, h->Wpatch_frag, h->bpatch, h->pos_tab, h->wsum, x, bf, s), "patch");
+      L.end();
+    } else {
+      L.begin(32, 0); L.misc(cs_im2col_launch(query, refs, N_enc, i0, r1, ic, H, W, P, h->Kp, pmean, bf, s), "im2col"); L.end();
       CsGemmParams g = gp(r1, h->Kp, h->Wpatch, h->Kp, ic * p.Np, C, h->Kp, h->bpatch, x, C);
       g.pos = h->pos_tab; g.Np = p.Np; g.pmean = pmean; g.wsum = h->wsum;
       if (fold) { g.out_f16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }  // fp16 rows + LayerNorm partial sums for layer 0
       L.gemm(g, CS_EPI_PATCH_F32, 3.0 * P * P);
     }
+    (void)ob;
     }
     const bool fold = h->lnfold;
     h16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
@@ -1117,7 +1136,26 @@ int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int 
   return 0;
 }
 
-// Patch embedding as the forward runs it (im2col -> MFMA GEMM with the PATCH epilogue), for op-level tests of the mean-centred form:
+// Patch embedding in one launch (patch.hip), as the forward runs it for 14-pixel patches and C = 384 n.  Same arguments and result as
+// cs_op_patch_embed(centred = 1); CS_ERR_BAD_ARG for shapes the one-launch form does not take.
+int cs_op_patch_embed_fused(const float* x, const float* w, const float* bias, const float* pos, int I, int H, int W, int P, int C,
+                            float* out, cs_stream stream) {
+  if (!x || !w || !bias || !pos || !out || I <= 0 || !cs_patch_fused_supported(H, W, P, C)) return fail(CS_ERR_BAD_ARG, "patch_embed_fused: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  h16_t* wf = nullptr; float* wsum = nullptr;
+  HIPCHK(hipMalloc(&wf, cs_patch_pack_elems(C) * sizeof(h16_t)));
+  HIPCHK(hipMalloc(&wsum, (size_t)3 * C * sizeof(float)));
+  int rc = 0;
+  auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = fail(CS_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
+  chk(cs_patch_pack_launch(w, C, wf, g_op_bf16, st), "pack");
+  chk(cs_patch_wsum_launch(w, C, P, wsum, st), "wsum");
+  if (!rc) chk(cs_patch_fused_launch(x, nullptr, 0, 0, I, H, W, C, wf, bias, pos, wsum, out, g_op_bf16, st), "patch");
+  chk(hipStreamSynchronize(st), "sync");
+  hipFree(wf); hipFree(wsum);
+  return rc;
+}
+
+// Patch embedding as the forward ran it before patch.hip (im2col -> MFMA GEMM with the PATCH epilogue), for op-level tests of the mean-centred form:
 // centred != 0: every patch's per-channel mean is removed before the fp16 rounding (im2col_rows_kernel) and added back in fp32 as
 // mean_ch * sum_taps W[n][ch] by the epilogue (patch_wsum_kernel).  x (I,3,H,W), w (C,3,P,P), bias (C), pos ((1 + Np), C) -> out (I * (1 + Np), C)
 // fp32 with the patch rows written (CLS rows untouched).  Allocates its temporaries: a test entry point, not a hot path.

@@ -156,6 +156,13 @@ int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int 
  * patch rows only.  Test entry point (allocates and synchronises). */
 int cs_op_patch_embed(const float* x, const float* w, const float* bias, const float* pos, int I, int H, int W, int P, int C, int centred,
                       float* out, cs_stream stream);
+/* The same patch embedding in ONE launch (csrc/patch.hip: image strip -> mean-centred 16-bit tile in LDS -> MFMA -> token rows; no im2col
+ * matrix in memory), the form cs_forward uses for 14-pixel patches when C is a multiple of 384 and the LayerNorm-folded epilogues are off.
+ * Arguments and result as cs_op_patch_embed(centred = 1); CS_ERR_BAD_ARG for other shapes.  Replaces HF modeling_dinov2.py:141-149. */
+int cs_op_patch_embed_fused(const float* x, const float* w, const float* bias, const float* pos, int I, int H, int W, int P, int C,
+                            float* out, cs_stream stream);
+/* 0 = cs_forward goes back to im2col + GEMM for the patch embedding (tests and tools; process-wide; default 1) */
+void cs_patch_fused_enable(int on);
 /* Input stage: device uint8 HWC image (3 channels, rows in_row_bytes apart) -> fp32 CHW [3][out_h][out_w], the
  * tensor cs_forward consumes.  Same operations, in the same order, as the reference's CPU transforms: x/255 (utils/io/images.py:14-29),
  * antialiased bilinear resize to (rs_h, rs_w) (T.Resize, task/predict.py:87-93; skipped when equal to the input size), crop window

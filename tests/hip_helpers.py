@@ -139,6 +139,17 @@ def encoder_panel(x, attn_o, img, bo, b1, b2, want_u=True, eps=1e-6):
     return u
 
 
+def patch_embed_fused(x, w, bias, pos, P):
+    """one-launch form (csrc/patch.hip): same contract as patch_embed(centred=True)"""
+    lib = _lib.load()
+    I, _, H, W = x.shape
+    C_ = w.shape[0]
+    Np = (H // P) * (W // P)
+    out = torch.full((I * (1 + Np), C_), 7.0, dtype=torch.float32, device=x.device)
+    _lib.check(lib.cs_op_patch_embed_fused(_p(x), _p(w), _p(bias), _p(pos), I, H, W, P, C_, _p(out), _stream()))
+    return out
+
+
 def patch_embed(x, w, bias, pos, P, centred):
     """(I,3,H,W) images -> (I * (1 + Np), C) fp32 token rows (patch rows written, CLS rows left at 7.0)."""
     lib = _lib.load()

@@ -324,6 +324,57 @@ def test_patch_embed_mean_centred_vs_fp32_conv():
     assert abs(errs[("noise", 1)] - errs[("noise", 0)]) < 0.2 * errs[("noise", 0)] + 1e-5
 
 
+@pytest.mark.parametrize("I,H,W,Cc", [(3, 518, 518, 384), (2, 518, 686, 384), (1, 1036, 1036, 384), (2, 224, 238, 768), (1, 14, 28, 384)])
+def test_patch_embed_one_launch_matches_two_kernel_path_and_conv(I, H, W, Cc):
+    """csrc/patch.hip (strip -> centred 16-bit tile in LDS -> MFMA -> token rows) against (a) the im2col + GEMM pair it replaces -- the A
+    operand has the same bits (same mean, same rounding), only the fp32 summation order of the products differs -- and (b) an fp64
+    convolution (HF modeling_dinov2.py:141-149).  Shapes: the benchmark's 37-patch rows, rows cut into two runs (49 and 74 patches), a
+    two-pass width (768), a single-patch-row image; smooth images, where the mean term carries most of the value."""
+    P = 14
+    gh, gw = H // P, W // P
+    Np = gh * gw
+    g = _rng(1000 + H + W + Cc)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = np.stack([[1.8 * np.sin(xx / (19.0 + 3 * c) + i) + 1.2 * np.cos(yy / (23.0 + c)) + 0.7 * (c - 1) for c in range(3)] for i in range(I)]).astype(np.float32)
+    img += 0.3 * g.standard_normal(img.shape, dtype=np.float32)
+    x = _t(img)
+    wconv = _t(g.standard_normal((Cc, 3, P, P), dtype=np.float32) / math.sqrt(588))
+    b = _t(g.standard_normal((Cc,), dtype=np.float32))
+    pos = _t(g.standard_normal((1 + Np, Cc), dtype=np.float32))
+    one = hh.patch_embed_fused(x, wconv, b, pos, P).reshape(I, 1 + Np, Cc)
+    two = hh.patch_embed(x, wconv, b, pos, P, 1).reshape(I, 1 + Np, Cc)
+    torch.cuda.synchronize()
+    assert (one[:, 0] == 7.0).all()  # CLS rows are not this kernel's
+    assert torch.isfinite(one).all()
+    d = (one[:, 1:] - two[:, 1:]).abs()
+    assert d.max() < 2e-5, float(d.max())  # fp32 summation order only (measured 4e-6)
+    ref = torch.nn.functional.conv2d(x.double(), wconv.double(), b.double(), stride=P).flatten(2).transpose(1, 2) + pos[None, 1:].double()
+    e1 = (one[:, 1:].double() - ref).abs().mean()
+    e2 = (two[:, 1:].double() - ref).abs().mean()
+    assert e1 < 1.05 * e2 + 1e-7 and e1 < 3e-4, (float(e1), float(e2))
+
+
+def test_patch_embed_one_launch_bf16_operands():
+    I, H, W, Cc, P = 2, 518, 518, 384, 14
+    Np = (H // P) * (W // P)
+    g = _rng(77)
+    x = _t(g.standard_normal((I, 3, H, W), dtype=np.float32))
+    wconv = _t(g.standard_normal((Cc, 3, P, P), dtype=np.float32) / math.sqrt(588))
+    b = _t(g.standard_normal((Cc,), dtype=np.float32))
+    pos = _t(g.standard_normal((1 + Np, Cc), dtype=np.float32))
+    lib = _lib.load()
+    lib.cs_op_set_operand_dtype(1)
+    try:
+        one = hh.patch_embed_fused(x, wconv, b, pos, P).reshape(I, 1 + Np, Cc)
+        two = hh.patch_embed(x, wconv, b, pos, P, 1).reshape(I, 1 + Np, Cc)
+        torch.cuda.synchronize()
+    finally:
+        lib.cs_op_set_operand_dtype(0)
+    assert (one[:, 1:] - two[:, 1:]).abs().max() < 2e-5
+    ref = torch.nn.functional.conv2d(x.double(), wconv.double(), b.double(), stride=P).flatten(2).transpose(1, 2) + pos[None, 1:].double()
+    assert (one[:, 1:].double() - ref).abs().mean() < 4e-3  # bfloat16 operands: 8 significant bits
+
+
 def test_attention_dh96_long_keys():
     """Decoder cross-attention at ViT-B size: dh = 96, Lk = 13 690 (cfg-3: 10 references of 1369 patches), ragged in both directions."""
     dh, heads, Lq, Lk = 96, 8, 300, 13690
