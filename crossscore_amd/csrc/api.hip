@@ -776,7 +776,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     L.end();
     if (!fold && h->Wpatch_frag && cs_patch_fused_supported(H, W, P, C)) {
       // one launch: strip -> centred fp16 tile in LDS -> MFMA -> token rows (patch.hip).  Algorithmic bytes: the images once, the rows once
-      L.begin(CS_EPI_PATCH_F32, 2.0 * ic * p.Np * C * 3.0 * P * P, 12.0 * ic * H * W + 4.0 * ic * p.Np * C + 4.0 * p.Np * C);
+      L.begin(41, 2.0 * ic * p.Np * C * 3.0 * P * P, 12.0 * ic * H * W + 4.0 * ic * p.Np * C + 4.0 * p.Np * C);
       L.misc(cs_patch_fused_launch(query, refs, N_enc, i0, ic, H, W, C, h->Wpatch_frag, h->bpatch, h->pos_tab, h->wsum, x, bf, s), "patch");
       L.end();
     } else {

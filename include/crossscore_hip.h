@@ -121,8 +121,8 @@ int cs_nonfinite_count(cs_handle h, long long* count);
 size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
 
 /* Per-kernel-family timing with HIP events on the launch stream (for bench.py's roofline object).
- * Families = kernel symbols: 0..9 cs_gemm_kernel<epilogue>, 16 + dh/16 cs_attn_kernel<dh>, 40 cs_panel_kernel, 32 everything else
- * (LayerNorm, im2col, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */
+ * Families = kernel symbols: 0..9 cs_gemm_kernel<epilogue> (either GEMM kernel), 16 + dh/16 cs_attn_kernel<dh>, 40 cs_panel_kernel,
+ * 41 cs_patch_fused_kernel, 32 everything else (LayerNorm, im2col, CLS rows, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */
 int cs_profile_enable(cs_handle h, int on);
 int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, double* flops);
 /* algorithmic HBM bytes (operands and results once each) of the recorded launches of one family */
