@@ -4,7 +4,8 @@
 #   bench lines for every BASELINE workload (+ the bf16 operand mode of cfg-2), rocprofv3 kernel stats of the default command and of the
 #   every-kernel-alone command (cfg-2 and cfg-4), the kernel-concurrency timeline of the default command, FETCH_SIZE / WRITE_SIZE PMC
 #   passes (separate runs, --kernel-trace only beside --pmc) of the every-kernel-alone commands, two SQ counter passes over the
-#   encoder-shaped attention launch (tools/attn_pmc.py), the GEMM kernels against hipBLASLt.
+#   encoder-shaped attention launch (tools/attn_pmc.py), the GEMM kernels against hipBLASLt, what the chip sustains on bare MFMA loops
+#   (tools/mfma_peak.py) and the phase clocks of the 256 x 256 x 64 GEMM (tools/gemm256_phases.py).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$1
@@ -31,4 +32,6 @@ cd $R && python3 tools/summarise_prof.py $O/stats_alone $O/pmc_fetch $O/pmc_writ
   && python3 tools/summarise_prof.py $O/stats_alone_cfg4 $O/pmc_fetch_cfg4 $O/pmc_write_cfg4 $O/alone_cfg4 || exit 1
 cd $R && python3 tools/timeline.py $O/stats_default $O/timeline.json > $O/timeline.txt 2>&1 || exit 1
 cd $R && CS_GVB_IMGS=96,22,8 python3 tools/gemm_vs_blas.py > $O/gemm_vs_blas.log 2>&1 || exit 1
+cd $R && python3 tools/mfma_peak.py > $O/mfma_peak.log 2>&1 || exit 1
+cd $R && python3 tools/gemm256_phases.py > $O/gemm256_phases.log 2>&1 || exit 1
 echo done
