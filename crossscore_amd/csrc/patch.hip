@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
   extern __shared__ __attribute__((aligned(16))) char pf_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CS_PF_EMPTY  // timing only: what the launch itself costs (same registers, same LDS, no work)
+  if (p.H > 0) return;
+#endif
   int b = blockIdx.x;
   const int sx = b % p.nsx; b /= p.nsx;
   const int pi = b % p.gh;
@@ -116,6 +119,10 @@ __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
       }
       const f32x2_t t2 = *reinterpret_cast<const f32x2_t*>(src + 12);
       v[i][12] = t2[0]; v[i][13] = t2[1];
+#ifdef CS_PF_NOLOAD  // timing only (tools/patch_ab.py): the strip loads become one load per segment
+#pragma unroll
+      for (int e = 1; e < PF_P; ++e) v[i][e] = v[i][0] + (float)e;
+#endif
     }
   }
 #pragma unroll
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
         }
     };
     static_assert(PF_KS == 19, "k loop below: 4 x 4 steps + 3");
+#ifndef CS_PF_NOMMA  // (timing-only ablation: no W stream, no MFMAs)
     wload(IC<0>{}, 0); wload(IC<1>{}, 1); wload(IC<2>{}, 2);
 #pragma unroll 1
     for (int s = 0; s < 16; s += 4) {
@@ -195,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
       wload(IC<2>{}, s + 6); kstep(IC<3>{}, s + 3);
     }
     kstep(IC<0>{}, 16); kstep(IC<1>{}, 17); kstep(IC<2>{}, 18);
+#endif
     // ---- phase C ----
     int tok0 = 1 + pi * p.gw + p0;            // first token row of the run
     asm volatile("" : "+s"(tok0));            // (opaque: hoisted out of the pass loop, the 24 row addresses below were spilled around the k loop)
@@ -220,12 +229,17 @@ __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
             if (m < np) {
               const int tok = tok0 + m;
               f32x4_t r = *reinterpret_cast<const f32x4_t*>(patch + rl * PF_PPITCH + c4 * 16) + b4;
+#ifndef CS_PF_NOPOS  // (timing-only ablation)
               r += *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)tok * p.C + n);
+#endif
               const f32x4_t mu = *reinterpret_cast<const f32x4_t*>(mean_s + m * 4);
               f32x4_t dc = mu[0] * w0;
               dc += mu[1] * w1;
               dc += mu[2] * w2;
               r += dc;
+#ifdef CS_PF_NOSTORE  // (timing-only ablation: one lane in 2^20 stores)
+              if (r[0] == 123.456f)
+#endif
               *reinterpret_cast<f32x4_t*>(p.x + ((size_t)img * T + tok) * p.C + n) = r;
             }
           }
@@ -274,7 +288,8 @@ hipError_t cs_patch_fused_launch(const float* xq, const float* xr, int N, int im
     if (e != hipSuccess) return e;
     attr_done[dev][bf ? 1 : 0] = true;
   }
-  if (bf) hipLaunchKernelGGL(cs_patch_fused_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(cs_patch_fused_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, p);
+  const unsigned grid = (unsigned)blocks;
+  if (bf) hipLaunchKernelGGL(cs_patch_fused_kernel<true>, dim3(grid), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(cs_patch_fused_kernel<false>, dim3(grid), dim3(256), lds, st, p);
   return hipGetLastError();
 }

@@ -4,6 +4,7 @@ Uses the handle-free op entry points, which allocate and synchronise: so the ker
 import os, sys, math, torch, numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+if os.environ.get("CS_PB_ROOT"): sys.path.insert(0, os.environ["CS_PB_ROOT"])  # a variant build (tools/patch_ab.py)
 import hip_helpers as hh
 I, H, W, C, P = int(os.environ.get("CS_PB_IMGS", 48)), 518, 518, int(os.environ.get("CS_PB_C", 384)), 14
 g = np.random.default_rng(0)
