@@ -369,9 +369,12 @@ def main():
     single = None
     if wl.inflight > 1 and args.lanes == 0:
         s_steps = max(3, args.steps // 2)
+        lane_cal = wl.net.calibrate_lanes(wl.tq, wl.tr)  # untimed: the two-lane forward must beat the one-lane one, or its streams are re-drawn
         e1, _ = timed_steps(wl.direct, sync, s_steps, 2, dev)
         single = {"value": world * B * s_steps / e1, "unit": "query-images/sec", "ms_per_step": 1e3 * e1 / s_steps, "steps": s_steps,
-                  "batches_in_flight": 1, "encoder_lanes": 2}
+                  "batches_in_flight": 1, "encoder_lanes": 2,
+                  "lane_calibration_ms": {"one_lane": 1e3 * lane_cal["one_lane_s"] if lane_cal["one_lane_s"] else None,
+                                          "lanes_per_stream_set_tried": [round(1e3 * v, 3) for v in lane_cal["lanes_s"]]}}
     wl.start_pipeline()
     elapsed, ticket = timed_steps(wl.step, sync, args.steps, args.warmup, dev)
     score = wl.pipe.result(ticket)["score_map_ref_cross"]  # the output of the last timed step

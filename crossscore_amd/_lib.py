@@ -55,6 +55,8 @@ SYMBOLS = {
     "cs_op_patch_embed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_patch_embed_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_patch_fused_enable": (None, [_i]),
+    "cs_set_lanes": (_i, [_vp, _i]),
+    "cs_redraw_lane_streams": (_i, [_vp]),
     "cs_op_pos_bicubic": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pos_bicubic_ex": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pe_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

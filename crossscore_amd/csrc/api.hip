@@ -133,6 +133,7 @@ struct cs_model {
   // lanes: internal streams that run independent image chunks / batch groups concurrently (forked from and joined to
   // the caller's stream with events), so one kernel's tail and the memory-bound stages overlap another's MFMA work
   hipStream_t lane_st[CS_MAX_LANES] = {};
+  int lanes_now = 0;  // cs_set_lanes: lanes of the next forwards (0 = as configured)
   hipStream_t last_stream = nullptr; hipEvent_t ev_done = nullptr;  // ordering of calls that arrive on different streams
   hipEvent_t ev_kv0 = nullptr, ev_kv1 = nullptr;                    // decoder: K/V projection on a side stream
   hipEvent_t ev_fork = nullptr, ev_join[CS_MAX_LANES] = {}, ev_stag[CS_MAX_LANES] = {};
@@ -205,6 +206,7 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
   p.B = B; p.N = N; p.H = H; p.W = W; p.C = c.hidden;
   p.gh = H / c.patch; p.gw = W / c.patch; p.Np = p.gh * p.gw; p.T = p.Np + 1; p.I = B * (1 + N_enc);
   p.lanes = m->prof ? 1 : (c.lanes <= 0 ? 2 : std::min(c.lanes, CS_MAX_LANES));  // profiling times kernels in isolation
+  if (m->lanes_now > 0) p.lanes = std::min(p.lanes, m->lanes_now);               // cs_set_lanes (the workspace holds the configured number)
   // cfg-2: 2 lanes x 24 images measured best (7.51 vs 7.70 ms with 12).  ViT-B: with the 256-row-tile GEMM (gemm256.hip) a chunk has to hold
   // many row tiles per CU: cfg-4 449 q/s at 48 or 16 images per chunk, 419 at 6, 407 at 12; cfg-3 247 at 44, 248 at 11 (tools/lanes_sweep_b.py, r3)
   int ic = c.enc_chunk_images > 0 ? c.enc_chunk_images : (c.hidden <= 384 ? 24 : 48);
@@ -1030,6 +1032,27 @@ int cs_profile_enable(cs_handle h, int on) {
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   h->recs.clear();
   h->prof = on != 0;
+  return 0;
+}
+
+// Lanes of the following forwards: 0 = as configured (cs_config.lanes), n >= 1 = at most n.  Same launches either way (score maps are
+// bit-identical); for CrossScoreNet.calibrate_lanes, which times the two-lane forward against the one-lane one on the same handle.
+int cs_set_lanes(cs_handle h, int lanes) {
+  if (!h || lanes < 0 || lanes > CS_MAX_LANES) return fail(CS_ERR_BAD_ARG, "cs_set_lanes: bad arguments");
+  h->lanes_now = lanes;
+  return 0;
+}
+
+// Gives the handle's lane streams back; the next forward draws new ones (and probes them, cs_forward).  A set-up call: waits for the
+// lanes' work.  The remedy when a two-lane forward turns out not to overlap although its streams passed the probe.
+int cs_redraw_lane_streams(cs_handle h) {
+  if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
+  for (int l = 0; l < CS_MAX_LANES; ++l)
+    if (h->lane_st[l]) {
+      HIPCHK(hipStreamSynchronize(h->lane_st[l]));
+      HIPCHK(hipStreamDestroy(h->lane_st[l]));
+      h->lane_st[l] = nullptr;
+    }
   return 0;
 }
 

@@ -135,6 +135,8 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
             batch = load_batch(its, stage, zero_ref, decoded)
             if batch_idx == 0 and len(batches) >= 16:  # a long run: make sure the batches in flight really overlap (pipeline.py)
                 pipe.calibrate(batch["query/img"], batch["reference/cross/imgs"])
+                if pipe.depth == 1:  # one batch at a time: then it is the forward's two lanes that have to overlap (model.py)
+                    net.calibrate_lanes(batch["query/img"], batch["reference/cross/imgs"])
             ticket = pipe.submit(batch["query/img"], batch["reference/cross/imgs"], need_w, head_id, False)
         else:
             batch, size = load_query_batch(its, stage, decoded)

@@ -120,6 +120,14 @@ int cs_nonfinite_count(cs_handle h, long long* count);
 /* Bytes of library-owned workspace a forward of this shape needs (grown lazily, never shrunk). */
 size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
 
+/* Lanes (internal streams that run independent image chunks of ONE forward side by side): cs_set_lanes limits the following forwards
+ * to at most `lanes` (0 = as configured by cs_config.lanes; same launches, bit-identical results); cs_redraw_lane_streams gives the
+ * handle's lane streams back so that the next forward draws and probes new ones (a set-up call: it waits for the lanes' work).  Together
+ * they let the host check that a two-lane forward really beats the one-lane one and repair it if not (CrossScoreNet.calibrate_lanes):
+ * two streams that passed the overlap probe can still end up serialised when other queues were created in between. */
+int cs_set_lanes(cs_handle h, int lanes);
+int cs_redraw_lane_streams(cs_handle h);
+
 /* Per-kernel-family timing with HIP events on the launch stream (for bench.py's roofline object).
  * Families = kernel symbols: 0..9 cs_gemm_kernel<epilogue> (either GEMM kernel), 16 + dh/16 cs_attn_kernel<dh>, 40 cs_panel_kernel,
  * 41 cs_patch_fused_kernel, 32 everything else (LayerNorm, im2col, CLS rows, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */

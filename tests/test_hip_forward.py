@@ -375,6 +375,34 @@ def test_encoder_chunking_is_invisible():
         assert torch.equal(net(tq, tr, False, 0, False)["score_map_ref_cross"], base), chunk
 
 
+def test_lane_calibration_and_stream_redraw_keep_results_bitwise():
+    """CrossScoreNet.calibrate_lanes (times the two-lane forward against the one-lane one on the same handle and re-draws the lane streams
+    if it does not win) and the two entry points under it, cs_set_lanes / cs_redraw_lane_streams: same launches whatever the lanes and
+    whichever streams carry them, so the score map stays bitwise the same."""
+    from crossscore_amd import _lib
+
+    net, arch, sd = _net(TINY, 5)
+    q, r = synth.make_inputs(4, 2, 70, 98, 5)
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    base = net(tq, tr, False, 0, False)["score_map_ref_cross"].clone()
+    cal = net.calibrate_lanes(tq, tr, tries=2, steps=2)
+    assert cal["one_lane_s"] > 0 and 1 <= len(cal["lanes_s"]) <= 2 and all(v > 0 for v in cal["lanes_s"])
+    assert torch.equal(net(tq, tr, False, 0, False)["score_map_ref_cross"], base)
+    lib = _lib.load()
+    _lib.check(lib.cs_set_lanes(net._handle, 1))
+    one = net(tq, tr, False, 0, False)["score_map_ref_cross"].clone()
+    _lib.check(lib.cs_set_lanes(net._handle, 0))
+    _lib.check(lib.cs_redraw_lane_streams(net._handle))
+    again = net(tq, tr, False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    assert torch.equal(one, base) and torch.equal(again, base)
+    with pytest.raises((ValueError, RuntimeError)):
+        _lib.check(lib.cs_set_lanes(net._handle, 99))
+    net.lanes = 1
+    net._mark_dirty()
+    assert net.calibrate_lanes(tq, tr) == {"one_lane_s": None, "lanes_s": []}  # nothing to calibrate with one lane
+
+
 def test_reference_token_cache_is_bit_identical():
     """encode each reference image once, gather per query -> the same score map bit for bit (encoder results
     per image do not depend on the batch they ran in), including when two queries share a reference."""
