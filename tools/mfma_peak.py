@@ -5,7 +5,7 @@ import ctypes as C, os, subprocess, sys, tempfile
 import numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 so = os.path.join(tempfile.mkdtemp(prefix="mfma_peak_"), "libmfma_peak.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, os.path.join(R, "tools", "mfma_peak.hip")])
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", "-o", so, os.path.join(R, "tools", "mfma_peak.hip")])
 lib = C.CDLL(so)
 src = (torch.randn(65536 * 8, device="cuda") * 1.0).to(torch.float16)
 out = torch.zeros(512 * 512, device="cuda"); clk = torch.zeros(512, dtype=torch.int64, device="cuda"); ms = C.c_float()
