@@ -48,6 +48,7 @@ WORKLOADS = {
     "cfg3": ("facebook/dinov2-base", 518, 518, 10, 8),
     "cfg4": ("facebook/dinov2-base", 518, 518, 5, 16),
     "cfg5": ("facebook/dinov2-small", 1036, 1036, 5, 2),
+    "large": ("facebook/dinov2-large", 518, 518, 5, 8),  # not a BASELINE configuration: the third DINOv2 width the path takes
 }
 
 
@@ -63,7 +64,7 @@ def algorithmic_flops_per_query(C, L, H, W, N, P=14, dec_layers=2):
 
 def kernel_table(net):
     rows = []
-    for fam in list(range(10)) + [16 + d // 16 for d in (16, 48, 64, 96)] + [40, 41, 32]:
+    for fam in list(range(10)) + [16 + d // 16 for d in (16, 48, 64, 96, 128)] + [40, 41, 32]:
         ms, n, fl = net.profile_read(fam)
         if n == 0:
             continue

@@ -178,7 +178,7 @@ std::vector<std::string> expected_names(const cs_config& c) {
   return n;
 }
 
-bool supported_dh(int dh) { return dh == 16 || dh == 48 || dh == 64 || dh == 96; }
+bool supported_dh(int dh) { return dh == 16 || dh == 48 || dh == 64 || dh == 96 || dh == 128; }
 
 struct Arena {  // carve 256-byte aligned pieces out of the workspace
   char* base; size_t off = 0;

@@ -37,7 +37,8 @@ struct AttnCfg {
   static constexpr int DT = (DH + 31) / 32;          // 32-wide d tiles of O^T
   static constexpr int CH = DH / 8;                  // 16-byte chunks per K/V row
   static constexpr int KROW = DH * 2 + 16;           // bytes; odd multiple of 16 -> ds_read_b128 conflict free
-  static constexpr int VROW = (DH <= 16) ? 64 : 192; // bytes; >= DT*64 and == 16 or 48 dwords (mod 64)
+  static constexpr int VROW = (DH <= 16) ? 64 : (DH <= 96 ? 192 : 320); // bytes; >= DT*64 and == 16 or 48 dwords (mod 64)
+  static_assert(VROW >= DT * 64 && (VROW / 4) % 32 == 16, "V row pitch");
   static constexpr int KTILE = 64 * KROW;
   static constexpr int VTILE = 64 * VROW;
   static constexpr int STAGE = KTILE + VTILE;
@@ -311,6 +312,16 @@ hipError_t launch(CsAttnParams p, int batch, hipStream_t stream) {
   const int groups = p.heads * batch;
   dim3 grid(((groups + 7) / 8) * 8 * ((p.Lq + 127) / 128));
   const int lds = 2 * AttnCfg<DH>::STAGE + 64;  // +64: the last rows' transposed reads of a padded d tile may run past the image
+  if (lds > 48 * 1024) {  // (dh = 128: 74 KiB)
+    static bool attr_done[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_attn_kernel<DH, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+      attr_done[dev] = true;
+    }
+  }
   hipLaunchKernelGGL((cs_attn_kernel<DH, BF>), grid, dim3(256), lds, stream, p);
   return hipGetLastError();
 }
@@ -322,7 +333,7 @@ extern "C" int cs_attn_debug_read(unsigned long long* dst) { return (int)hipMemc
 #endif
 
 extern "C" const char* cs_attn_check(const CsAttnParams* p, int dh, int batch) {
-  if (dh != 16 && dh != 48 && dh != 64 && dh != 96) return "attention: head dim must be 16, 48, 64 or 96";
+  if (dh != 16 && dh != 48 && dh != 64 && dh != 96 && dh != 128) return "attention: head dim must be 16, 48, 64, 96 or 128";
   if (p->Lq <= 0 || p->Lk <= 0 || p->heads <= 0 || batch <= 0) return "attention: empty shape";
   if ((long long)batch * p->heads * ((p->Lq + 127) / 128) > (1ll << 30)) return "attention: grid too large";
   if (p->ldq % 8 || p->ldk % 8 || p->ldv % 8 || p->ldo % 4) return "attention: row strides must keep 16-byte rows";
@@ -338,6 +349,7 @@ extern "C" hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, h
     case 48: return p->bf16 ? launch<48, true>(*p, batch, stream) : launch<48, false>(*p, batch, stream);
     case 64: return p->bf16 ? launch<64, true>(*p, batch, stream) : launch<64, false>(*p, batch, stream);
     case 96: return p->bf16 ? launch<96, true>(*p, batch, stream) : launch<96, false>(*p, batch, stream);
+    case 128: return p->bf16 ? launch<128, true>(*p, batch, stream) : launch<128, false>(*p, batch, stream);
   }
   return hipErrorInvalidValue;
 }

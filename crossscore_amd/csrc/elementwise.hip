@@ -538,6 +538,7 @@ hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int 
     case 48: hipLaunchKernelGGL(attn_weights_kernel<48>, grid, dim3(256), 0, st, *p, head, out); break;
     case 64: hipLaunchKernelGGL(attn_weights_kernel<64>, grid, dim3(256), 0, st, *p, head, out); break;
     case 96: hipLaunchKernelGGL(attn_weights_kernel<96>, grid, dim3(256), 0, st, *p, head, out); break;
+    case 128: hipLaunchKernelGGL(attn_weights_kernel<128>, grid, dim3(256), 0, st, *p, head, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

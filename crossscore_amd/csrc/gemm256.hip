@@ -38,7 +38,8 @@ constexpr int G_OPND = 256 * G_ROWB;        // 32 KiB: one operand's K tile
 constexpr int G_WOFF = 2 * G_OPND;          // ring = [A buffer 0 | A buffer 1 | W buffer 0 | W buffer 1]: every fragment read is one of four
                                             // per-lane base addresses (operand x k-step) plus an immediate below 64 KiB
 constexpr int G_RING = 4 * G_OPND;          // 128 KiB
-constexpr int G_NMAX = 3072;                // widest N (the bias vector is kept in LDS)
+constexpr int G_NMAX = 3072;                // widest N whose bias vector is kept in LDS (wider: read from memory at every tile start)
+constexpr int G_NLIM = 8192;                // widest N taken
 constexpr int G_BIAS = G_RING;              // 12 KiB
 constexpr int G_PROW = 144;                 // patch row: 128 B + 16 B pad
 constexpr int G_PATCH = 16 * G_PROW;        // one 16-row patch per wave
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
   };
 
   // ---- bias vector -> LDS once per block (plain accesses: nothing else is in flight yet) ----
-  for (int i = tid * 4; i < p.N; i += 2048) {
+  for (int i = tid * 4; i < min(p.N, G_NMAX); i += 2048) {
     f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + i);
     *reinterpret_cast<f32x4_t*>(smem + G_BIAS + i * 4) = b4;
@@ -231,10 +232,18 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     bias_addr = lds0 + G_BIAS + (wn * 64 + 4 * (ln >> 4)) * 4;
   };
   auto init_acc = [&](int n0) {  // accumulators start at the bias of their columns (16 j + 4 cq .. + 3 of the wave's 64)
-    const unsigned a = bias_addr + n0 * 4;
     f32x4_t b4[4];
-    pr16<0>(a, b4[0]); pr16<64>(a, b4[1]); pr16<128>(a, b4[2]); pr16<192>(a, b4[3]);
-    G_LGKM(0);
+    if (p.N <= G_NMAX) {
+      const unsigned a = bias_addr + n0 * 4;
+      pr16<0>(a, b4[0]); pr16<64>(a, b4[1]); pr16<128>(a, b4[2]); pr16<192>(a, b4[3]);
+      G_LGKM(0);
+    } else {
+      // N > 3072 (dinov2-large's fc1): the vector does not fit beside the ring; four plain loads per tile (the compiler waits for them
+      // with vmcnt(0), i.e. for the DMA pieces in flight too: once per output tile)
+      const float* bp = p.bias ? p.bias + n0 + (int)((bias_addr - (lds0 + G_BIAS)) >> 2) : nullptr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b4[j] = bp ? *reinterpret_cast<const f32x4_t*>(bp + 16 * j) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -445,7 +454,7 @@ void cs_gemm256_enable(int on) { g_enabled = on; }
 int cs_gemm256_supported(const CsGemmParams* p, int epi) {
   if (!g_enabled) return 0;
   if (epi > CS_EPI_RESID_F32) return 0;
-  if (p->N % G_BN || p->N > G_NMAX || p->K % (2 * G_BK) || p->K < 512 || p->M < G_BM) return 0;
+  if (p->N % G_BN || p->N > G_NLIM || p->K % (2 * G_BK) || p->K < 512 || p->M < G_BM) return 0;
   if (p->lda % 8 || p->ldw % 8 || p->ldc % 8) return 0;
   if ((long long)p->M * p->lda * 2 >= (1ll << 32) || (long long)p->N * p->ldw * 2 >= (1ll << 32)) return 0;
   if (epi == CS_EPI_RESID_F32 && p->resid && (p->ldr % 4 || (long long)p->M * p->ldr * 4 >= (1ll << 32))) return 0;

@@ -134,3 +134,21 @@ def test_cfg1_predict_plumbing_518(tmp_path):
     print(json.dumps({"cfg1_score_map_mae_vs_oracle_pipeline": mae, "driver_wall_s": round(t_run, 2), "csv_row": res["rows"][0]}))
     assert mae < MAE_TOL
     assert abs(float(res["rows"][0][-1]) - float(ref.mean())) < 1e-3  # the per-image mean the CSV row carries
+
+
+def test_dinov2_large_518_vs_oracle_and_batch_invariance():
+    """Beyond BASELINE's two backbones: facebook/dinov2-large (C = 1024, 24 layers, 16 heads; decoder heads of 128 channels) at 518x518.
+    B=1, N=1 against the fp32 oracle on the host (two images through 24 layers: ~20 s), then B=3, N=2: item-wise bitwise invariance."""
+    net, arch, sd = _net("facebook/dinov2-large", 9)
+    q, r = synth.make_inputs_shard(0, 1, 1, 518, 518, 9)
+    score = _run(net, q, r)
+    assert net.nonfinite_count() == 0
+    W = orc.to_torch(sd)
+    ref = orc.forward(W, dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r))["score_map_ref_cross"]
+    d = (score.cpu() - ref).abs()
+    assert float(d.mean()) < MAE_TOL and float(d.max()) < 2 * MAX_TOL, (float(d.mean()), float(d.max()))
+    q3, r3 = synth.make_inputs_shard(0, 3, 2, 518, 518, 10)
+    s3 = _run(net, q3, r3)
+    one = _run(net, q3[1:2].copy(), r3[1:2].copy())
+    assert torch.equal(one[0], s3[1])
+    _properties(net, q3, r3, s3)

@@ -136,6 +136,24 @@ def test_tiny_shape_sweep_vs_oracle(B, N, H, W):
     assert torch.equal(out, again)
 
 
+def test_dinov2_large_width_vs_oracle():
+    """Every kernel shape of facebook/dinov2-large (C = 1024, 16 encoder heads of 64, decoder heads of 128, fc1 4096 wide: the
+    256 x 256-tile GEMM for the 1024-wide linears, the 128-row one for fc1, im2col + GEMM for the patch embedding) on a two-layer encoder of
+    that width against the fp32 oracle, with the attention-weights map, and the registered large architecture itself."""
+    net, arch, sd = _net("synthetic/dinov2-wide", 21)
+    assert (arch.hidden, arch.enc_heads, arch.hidden // arch.dec_heads) == (1024, 16, 128)
+    q, r = synth.make_inputs(2, 2, 84, 98, 21)
+    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), True, 5, False)
+    torch.cuda.synchronize()
+    ref = _oracle(arch, sd, q, r, True, 5)
+    mae, mx = _compare(out["score_map_ref_cross"], ref["score_map_ref_cross"])
+    assert mae < MAE_TOL and mx < 2 * MAX_TOL, (mae, mx)
+    aw = (out["attn_weights_map_ref_cross"].cpu() - ref["attn_weights_map_ref_cross"]).abs()
+    assert aw.max() < AW_MAX_TOL_TINY and torch.isfinite(out["attn_weights_map_ref_cross"]).all(), float(aw.max())
+    big = synth.BACKBONES["facebook/dinov2-large"]
+    assert (big.hidden, big.enc_layers, big.enc_heads) == (1024, 24, 16)
+
+
 def test_structured_images_vs_oracle():
     """Natural-image-like inputs (smooth patterns + mild noise, ImageNet-normalised uint8 pixels) are the hard case for 16-bit
     operands: a patch is mostly its mean, so the rounding error of the patch-embedding weights adds up coherently.  The

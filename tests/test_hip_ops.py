@@ -126,7 +126,7 @@ def test_gemm256_exact_integer_layout():
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 512), (300, 768, 768), (1370, 2304, 768), (10960, 768, 3072), (10960, 3072, 768),
-                                   (2740, 768, 1536), (513, 256, 640)])
+                                   (2740, 768, 1536), (513, 256, 640), (700, 4096, 1024)])  # (N > 3072: bias read from memory per tile)
 def test_gemm256_matches_reference_and_small_tile_kernel(M, N, K):
     g = _rng(M + N + K + 1)
     A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))
@@ -436,6 +436,7 @@ def _attn_ref(Q, K, V, heads, dh, prescaled=True):
 @pytest.mark.parametrize("dh,heads,Lq,Lk,B", [
     (64, 2, 128, 64, 1), (64, 6, 1370, 1370, 2), (64, 2, 31, 31, 3), (64, 1, 129, 65, 1),
     (48, 8, 1369, 1369, 1), (48, 8, 300, 1500, 2), (96, 8, 257, 513, 1), (16, 8, 30, 60, 2), (16, 8, 200, 333, 1),
+    (128, 8, 257, 700, 1), (128, 2, 64, 64, 2),  # dinov2-large's decoder heads (C = 1024 / 8)
 ])
 def test_attention_matches_fp32(dh, heads, Lq, Lk, B):
     g = _rng(dh * 1000 + Lq + Lk)
