@@ -324,7 +324,8 @@ def test_patch_embed_mean_centred_vs_fp32_conv():
     assert abs(errs[("noise", 1)] - errs[("noise", 0)]) < 0.2 * errs[("noise", 0)] + 1e-5
 
 
-@pytest.mark.parametrize("I,H,W,Cc", [(3, 518, 518, 384), (2, 518, 686, 384), (1, 1036, 1036, 384), (2, 224, 238, 768), (1, 14, 28, 384)])
+@pytest.mark.parametrize("I,H,W,Cc", [(3, 518, 518, 384), (2, 518, 686, 384), (1, 1036, 1036, 384), (2, 224, 238, 768), (1, 14, 28, 384),
+                                      (2, 75, 90, 384)])  # (trailing pixels past the last whole patch are ignored, HF:141-149)
 def test_patch_embed_one_launch_matches_two_kernel_path_and_conv(I, H, W, Cc):
     """csrc/patch.hip (strip -> centred 16-bit tile in LDS -> MFMA -> token rows) against (a) the im2col + GEMM pair it replaces -- the A
     operand has the same bits (same mean, same rounding), only the fp32 summation order of the products differs -- and (b) an fp64
@@ -352,6 +353,18 @@ def test_patch_embed_one_launch_matches_two_kernel_path_and_conv(I, H, W, Cc):
     e1 = (one[:, 1:].double() - ref).abs().mean()
     e2 = (two[:, 1:].double() - ref).abs().mean()
     assert e1 < 1.05 * e2 + 1e-7 and e1 < 3e-4, (float(e1), float(e2))
+
+
+def test_patch_embed_one_launch_refuses_what_it_does_not_take():
+    """odd row pitch (8-byte loads), C not a multiple of 384, other patch sizes: CS_ERR_BAD_ARG from the op; cs_forward falls back to im2col + GEMM"""
+    g = _rng(5)
+    for (H, W, Cc, P) in ((70, 91, 384, 14), (70, 84, 256, 14)):
+        x = _t(g.standard_normal((1, 3, H, W), dtype=np.float32))
+        w = _t(g.standard_normal((Cc, 3, P, P), dtype=np.float32))
+        b = _t(g.standard_normal((Cc,), dtype=np.float32))
+        pos = _t(g.standard_normal((1 + (H // P) * (W // P), Cc), dtype=np.float32))
+        with pytest.raises(ValueError):
+            hh.patch_embed_fused(x, w, b, pos, P)
 
 
 def test_patch_embed_one_launch_bf16_operands():
