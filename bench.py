@@ -276,7 +276,7 @@ class Workload:
         """`inflight` batches in flight (crossscore_amd/pipeline.py): replicas over the same parameters fed round-robin on their own
         streams, as the predict driver runs its batch loop; 1 = the plain forward on this stream."""
         self.pipe = ForwardPipeline(self.net, depth=self.inflight, lanes=self._lanes_arg if self._lanes_arg > 0 else None)
-        self.lanes = self.net.lanes
+        self.lanes = self.pipe.nets[0].lanes  # what the replicas run (the caller's module keeps its own setting)
         # untimed: checks that the batches in flight really overlap on the chosen streams (hardware-queue placement, pipeline.py)
         self.calibration = self.pipe.calibrate(self.tq, self.tr)
         return self
