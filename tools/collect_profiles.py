@@ -12,7 +12,7 @@ for src, dst in (("bench.json", "bench.json"), ("bench_bf16.json", "bench_bf16.j
                  ("bench_cfg4.json", "bench_cfg4.json"), ("bench_cfg5.json", "bench_cfg5.json")):
     json.dump(line(os.path.join(O, src)), open(os.path.join(P, f"{tag}_{dst}"), "w"), indent=1)
 for src, dst in (("default_kernel_stats.csv", "kernel_stats.csv"), ("alone_kernel_stats.csv", "kernel_stats_alone.csv"),
-                 ("alone_cfg4_kernel_stats.csv", "kernel_stats_alone_cfg4.csv"), ("attn_pmc.json", "attn_pmc.json"),
+                 ("alone_cfg4_kernel_stats.csv", "kernel_stats_alone_cfg4.csv"), ("attn_pmc.json", "attn_pmc.json"), ("kernel_pmc.json", "kernel_pmc.json"),
                  ("timeline.json", "timeline.json"), ("gemm_vs_blas.log", "gemm_vs_blas.txt"), ("mfma_peak.log", "mfma_peak.txt"),
                  ("gemm256_phases.log", "gemm256_phases.txt")):
     shutil.copy(os.path.join(O, src), os.path.join(P, f"{tag}_{dst}"))

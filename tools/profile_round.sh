@@ -26,8 +26,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_cf
 echo "traffic passes done"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_attn1 -- python3 $R/tools/attn_pmc.py > $O/pmc_attn1.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_attn2 -- python3 $R/tools/attn_pmc.py > $O/pmc_attn2.log 2>&1 || exit 1
-echo "attention counters done"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_k1 -- python3 $R/tools/panel_pmc.py > $O/pmc_k1.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_k2 -- python3 $R/tools/panel_pmc.py > $O/pmc_k2.log 2>&1 || exit 1
+echo "attention, panel and GEMM counters done"
 cd $R && python3 tools/summarise_attn_pmc.py $O/attn_pmc.json $O/pmc_attn1 $O/pmc_attn2 > /dev/null || exit 1
+cd $R && python3 tools/summarise_kernel_pmc.py $O/kernel_pmc.json $O/pmc_k1 $O/pmc_k2 > /dev/null || exit 1
 cd $R && python3 tools/summarise_prof.py $O/stats_alone $O/pmc_fetch $O/pmc_write $O/alone && python3 tools/summarise_prof.py $O/stats_default $O/pmc_fetch $O/pmc_write $O/default \
   && python3 tools/summarise_prof.py $O/stats_alone_cfg4 $O/pmc_fetch_cfg4 $O/pmc_write_cfg4 $O/alone_cfg4 || exit 1
 cd $R && python3 tools/timeline.py $O/stats_default $O/timeline.json > $O/timeline.txt 2>&1 || exit 1
