@@ -15,7 +15,11 @@ for src, dst in (("default_kernel_stats.csv", "kernel_stats.csv"), ("alone_kerne
                  ("alone_cfg4_kernel_stats.csv", "kernel_stats_alone_cfg4.csv"), ("attn_pmc.json", "attn_pmc.json"), ("kernel_pmc.json", "kernel_pmc.json"),
                  ("timeline.json", "timeline.json"), ("gemm_vs_blas.log", "gemm_vs_blas.txt"), ("mfma_peak.log", "mfma_peak.txt"),
                  ("gemm256_phases.log", "gemm256_phases.txt")):
-    shutil.copy(os.path.join(O, src), os.path.join(P, f"{tag}_{dst}"))
+    keep = {"mfma_peak.txt": "CUs busy", "gemm256_phases.txt": "M half", "gemm_vs_blas.txt": "M="}.get(dst)
+    if keep:  # text logs: only the result lines (compiler warnings and loader notices stay behind)
+        open(os.path.join(P, f"{tag}_{dst}"), "w").write("".join(l for l in open(os.path.join(O, src)) if keep in l))
+    else:
+        shutil.copy(os.path.join(O, src), os.path.join(P, f"{tag}_{dst}"))
 for src, dst, cmd in (("alone_hbm_traffic.json", "hbm_traffic.json", "bench.py --no-cpu-baseline --no-eager --no-cfg4 --inflight 1 --lanes 1 --chunk 48 --steps 3 --warmup 1"),
                       ("alone_cfg4_hbm_traffic.json", "hbm_traffic_cfg4.json", "bench.py --workload cfg4 --no-cpu-baseline --no-eager --no-cfg4 --inflight 1 --lanes 1 --chunk 96 --steps 2 --warmup 1")):
     t = json.load(open(os.path.join(O, src)))
