@@ -174,7 +174,7 @@ def cpu_baseline(arch, sd, H, W, N, hip_score_item0, seed, max_seconds=25.0):
         if int(g["H"]) == H and int(g["W"]) == W and int(g["N"]) == N:
             cb["reference_itself_in_build_container"] = dict(seconds_per_query=float(g["ref_seconds"]), threads=int(g["threads"]),
                                                              note="imported /root/reference forward, cold, when tests/golden was generated")
-    return cb, mae
+    return cb, mae, ref[0]
 
 
 def eager_baseline(arch, sd, tq, tr, dev, steps=3, variants=("fp32_sdpa", "fp16_autocast_sdpa", "bf16_autocast_sdpa")):
@@ -253,9 +253,10 @@ def timed_steps(step, sync, steps, warmup, dev):
 class Workload:
     """One BASELINE.json configuration on this rank: replica from the seed, this rank's shard of the synthetic batch in HBM."""
 
-    def __init__(self, name, rank, dev, lanes=0, chunk=0, seed=1, inflight=1, dtype="fp16"):
+    def __init__(self, name, rank, dev, lanes=0, chunk=0, seed=1, inflight=1, dtype="fp16", item_range=None):
         self.name = name
         self.backbone, self.H, self.W, self.N, self.B = WORKLOADS[name]
+        self.micro = self.B  # items per forward
         self.seed, self.dev = seed, dev
         self.net = CrossScoreNet(model_config(**{"backbone.from_pretrained": self.backbone}))
         self.arch = self.net.arch
@@ -268,9 +269,22 @@ class Workload:
         if chunk > 0:
             self.net.enc_chunk_images = chunk
         self.inflight, self._lanes_arg, self.pipe = inflight, lanes, None
-        lo = rank * self.B  # weak scaling: rank r scores global items [r*B, (r+1)*B)
-        q, r = synth.make_inputs_shard(lo, lo + self.B, self.N, self.H, self.W, seed)
-        self.tq, self.tr = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)  # inputs resident in HBM before timing
+        if item_range is None:
+            lo = rank * self.B  # weak scaling: rank r scores global items [r*B, (r+1)*B)
+            q, r = synth.make_inputs_shard(lo, lo + self.B, self.N, self.H, self.W, seed)
+            self.tq, self.tr = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)  # inputs resident in HBM before timing
+        else:
+            # strong scaling: this rank's contiguous shard [lo, hi) of a fixed global batch (parallel.shard_bounds), generated on the device
+            # item by item from (seed, global item index) -- the same item whatever the world size -- and resident before timing
+            lo, hi = item_range
+            self.B = hi - lo
+            self.tq = torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=dev)
+            self.tr = torch.empty((self.B, self.N, 3, self.H, self.W), dtype=torch.float32, device=dev)
+            g = torch.Generator(device=dev)
+            for i, b in enumerate(range(lo, hi)):
+                g.manual_seed(1000003 * seed + b)
+                self.tq[i].normal_(generator=g)
+                self.tr[i].normal_(generator=g)
 
     def start_pipeline(self):
         """`inflight` batches in flight (crossscore_amd/pipeline.py): replicas over the same parameters fed round-robin on their own
@@ -278,12 +292,17 @@ class Workload:
         self.pipe = ForwardPipeline(self.net, depth=self.inflight, lanes=self._lanes_arg if self._lanes_arg > 0 else None)
         self.lanes = self.pipe.nets[0].lanes  # what the replicas run (the caller's module keeps its own setting)
         # untimed: checks that the batches in flight really overlap on the chosen streams (hardware-queue placement, pipeline.py)
-        self.calibration = self.pipe.calibrate(self.tq, self.tr)
+        self.calibration = self.pipe.calibrate(self.tq[:self.micro], self.tr[:self.micro])
         return self
 
     def step(self):
         """queues one batch; returns its ticket (pipe.result(ticket) orders the outputs on the current stream)"""
-        return self.pipe.submit(self.tq, self.tr, False, 0, False)
+        if self.B <= self.micro:
+            return self.pipe.submit(self.tq, self.tr, False, 0, False)
+        t = None  # a shard larger than one forward's batch: consecutive forwards of `micro` items, all queued on the pipeline
+        for b0 in range(0, self.B, self.micro):
+            t = self.pipe.submit(self.tq[b0:b0 + self.micro], self.tr[b0:b0 + self.micro], False, 0, False)
+        return t
 
     def direct(self):
         """one batch through replica 0 on the current stream (per-kernel profiling pass)"""
@@ -312,11 +331,23 @@ def plumbing_test(args, rank, world):
     elapsed, _ = timed_steps(step, lambda: None, args.steps, args.warmup, dev)
     means = parallel.gather_means(torch.full((2,), float(rank)), 2 * world)
     census = parallel.rank_census(dev, ms_per_step=1e3 * timed_steps.last_rank_seconds / args.steps)
+    # the strong-scaling leg's plumbing (scaling_cfg4): a fixed global batch split by parallel.shard_bounds, a stub that costs 1 ms per item
+    G = args.global_batch
+    lo, hi = parallel.shard_bounds(G, world, rank)
+
+    def strong_step():
+        time.sleep(0.001 * (hi - lo))
+        return None
+
+    e_s, _ = timed_steps(strong_step, lambda: None, args.steps, args.warmup, dev)
+    census_s = parallel.rank_census(dev, shard=[lo, hi], items=hi - lo, ms_per_step=1e3 * timed_steps.last_rank_seconds / args.steps)
     if rank == 0:
         print(json.dumps({"metric": "plumbing-test (stub forward, no GPU work)", "value": world * 8 * args.steps / elapsed,
                           "unit": "stub-items/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * elapsed / args.steps, "data": "stub", "scaling": "weak",
-                          "gathered_means": means.tolist(), "ranks_seen": census, "process_group": parallel.backend_info()}), flush=True)
+                          "gathered_means": means.tolist(), "ranks_seen": census, "process_group": parallel.backend_info(),
+                          "scaling_cfg4": {"mode": "strong", "global_batch": G, "value": G * args.steps / e_s, "unit": "stub-items/sec",
+                                           "ms_per_step": 1e3 * e_s / args.steps, "ranks_seen": census_s}}), flush=True)
     parallel.barrier()
     parallel.shutdown()
 
@@ -341,6 +372,9 @@ def main():
                     "driver's batch loop); 1 = one forward at a time with the library's two encoder lanes")
     ap.add_argument("--dtype", default="fp16", choices=("fp16", "bf16"), help="16-bit MFMA operand type (cs_config.operand_dtype): fp16 is the "
                     "default of the path (score-map MAE 1e-4); bf16 is BASELINE.json's wording for cfg-2 (MAE 8e-4, fp32's range)")
+    ap.add_argument("--global-batch", type=int, default=128, help="fixed global batch of the strong-scaling leg (BASELINE.json configs[3]: ViT-B/14, 5 refs, "
+                    "global bs=128 batch-sharded over the ranks); reported as scaling_cfg4 with mode 'strong'")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16-operand leg of the headline workload (dtype_legs)")
     ap.add_argument("--no-repeats", action="store_true", help="skip the four extra K-step regions behind the timed one (value_median_of_5)")
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo rehearsal of the rank plumbing
     args = ap.parse_args()
@@ -389,18 +423,49 @@ def main():
         e_r, _t = timed_steps(wl.step, sync, args.steps, 1, dev)
         repeats.append(e_r)
 
-    # ---- BASELINE.json configs[3] (the scaling configuration) on the same ranks: ViT-B/14, 5 refs, 16 items per GPU ----
+    # ---- the headline workload again with the other 16-bit operand type (BASELINE words cfg-2 "bf16"; the path's default is fp16): same
+    #      K steps, same pipeline; both legs' values and score-map MAEs go into `dtype_legs` ----
+    other = None
+    if not args.no_bf16_leg:
+        odt = "bf16" if args.dtype == "fp16" else "fp16"
+        wo = Workload(args.workload, rank, dev, args.lanes, args.chunk, inflight=args.inflight, dtype=odt).start_pipeline()
+        eo, to = timed_steps(wo.step, sync, args.steps, args.warmup, dev)
+        other = {"dtype": odt, "value": world * B * args.steps / eo, "ms_per_step": 1e3 * eo / args.steps, "steps": args.steps,
+                 "score": wo.pipe.result(to)["score_map_ref_cross"][:1].clone(), "nonfinite_score_values": wo.pipe.nonfinite_count()}
+        del wo
+        torch.cuda.empty_cache()
+
+    # ---- BASELINE.json configs[3] (the scaling configuration) on the same ranks: ViT-B/14, 5 refs.  STRONG scaling as BASELINE words it
+    #      (global bs=128 batch-sharded: rank r scores parallel.shard_bounds(128, world, r), in forwards of 16 items with the same batches
+    #      in flight; the reference shards a fixed dataset the same way, task/predict.py:119-135), and the weak form (16 items per GPU) ----
     cfg4 = None
     if not args.no_cfg4 and args.workload != "cfg4":
         w4 = Workload("cfg4", rank, dev, inflight=args.inflight, dtype=args.dtype).start_pipeline()
         steps4 = max(3, args.steps // 2)  # 2 batches in flight: the pipeline's fill and drain weigh on very short runs
         e4, _ = timed_steps(w4.step, sync, steps4, 2, dev)
         v4 = world * w4.B * steps4 / e4
-        cfg4 = {"metric": w4.metric(), "value": v4, "unit": "query-images/sec", "steps": steps4, "warmup": 2,
-                "ms_per_step": 1e3 * e4 / steps4, "workload": w4.describe(world), "gflop_per_query": w4.flops_per_query() / 1e9,
-                "whole_path_tflops_per_gpu": v4 * w4.flops_per_query() / 1e12 / world,
-                "frac_of_mfma_peak": v4 * w4.flops_per_query() / 1e12 / world / PEAK_BF16_TFLOPS}
+        weak4 = {"mode": "weak", "metric": w4.metric(), "value": v4, "unit": "query-images/sec", "steps": steps4, "warmup": 2,
+                 "ms_per_step": 1e3 * e4 / steps4, "workload": w4.describe(world), "gflop_per_query": w4.flops_per_query() / 1e9,
+                 "whole_path_tflops_per_gpu": v4 * w4.flops_per_query() / 1e12 / world,
+                 "frac_of_mfma_peak": v4 * w4.flops_per_query() / 1e12 / world / PEAK_BF16_TFLOPS}
+        fq4 = w4.flops_per_query()
         del w4
+        torch.cuda.empty_cache()
+        G = args.global_batch
+        lo, hi = parallel.shard_bounds(G, world, rank)
+        ws = Workload("cfg4", rank, dev, inflight=args.inflight, dtype=args.dtype, item_range=(lo, hi)).start_pipeline()
+        steps_s = 3
+        es, _ = timed_steps(ws.step, sync, steps_s, 1, dev)
+        census_s = parallel.rank_census(dev, shard=[lo, hi], items=hi - lo, forwards_per_step=(hi - lo + ws.micro - 1) // ws.micro,
+                                        ms_per_step=1e3 * timed_steps.last_rank_seconds / steps_s)
+        vs = G * steps_s / es
+        cfg4 = {"mode": "strong", "global_batch": G, "metric": f"query-images/sec at {ws.H}x{ws.W}, {ws.N} ref views, global bs={G}",
+                "value": vs, "unit": "query-images/sec", "steps": steps_s, "warmup": 1, "ms_per_step": 1e3 * es / steps_s,
+                "workload": f"cfg4: {ws.backbone} encoder, {ws.H}x{ws.W}, {ws.N} refs, global batch {G} sharded contiguously over {world} rank(s), "
+                            f"forwards of {ws.micro} items, inputs generated on the device per (seed, item)",
+                "gflop_per_query": fq4 / 1e9, "whole_path_tflops_per_gpu": vs * fq4 / 1e12 / world,
+                "frac_of_mfma_peak": vs * fq4 / 1e12 / world / PEAK_BF16_TFLOPS, "ranks_seen": census_s, "weak_16_per_gpu": weak4}
+        del ws
         torch.cuda.empty_cache()
 
     # ---- per-kernel HIP-event timing (separate pass so the events do not perturb the timed region) ----
@@ -497,10 +562,18 @@ def main():
                 if "value" in v:
                     result[f"speedup_vs_eager_{k}"] = value / v["value"]
             result["target_10x_met"] = {k: (value / v["value"] >= 10.0) for k, v in eb.items() if "value" in v}
+        legs = {args.dtype: {"value": value, "ms_per_step": 1e3 * elapsed / args.steps, "score_map_mae": None}}
+        if other is not None:
+            legs[other["dtype"]] = {"value": other["value"], "ms_per_step": other["ms_per_step"], "score_map_mae": None,
+                                    "nonfinite_score_values": other["nonfinite_score_values"]}
+        result["dtype_legs"] = legs  # same workload, same K steps: the headline's operand type and the other one
         if world == 1 and not args.no_cpu_baseline:
-            cb, mae = cpu_baseline(arch, wl.sd, H, W, N, score[0], wl.seed)
+            cb, mae, ref0 = cpu_baseline(arch, wl.sd, H, W, N, score[0], wl.seed)
             result["cpu_baseline"] = cb
             result["score_map_mae"] = mae
+            legs[args.dtype]["score_map_mae"] = mae
+            if other is not None:
+                legs[other["dtype"]]["score_map_mae"] = float((other["score"][0].cpu() - ref0).abs().mean())
             result["speedup_vs_cpu_baseline"] = value / cb["value"]
     parallel.barrier()
     if rank == 0:

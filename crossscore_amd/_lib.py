@@ -42,7 +42,9 @@ SYMBOLS = {
     "cs_forward_cached": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "cs_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "cs_nonfinite_count": (_i, [_vp, C.POINTER(C.c_longlong)]),
-    "cs_op_set_operand_dtype": (_i, [_i]),
+    "cs_debug_set_op_operand_dtype": (_i, [_i]),
+    "cs_debug_capture": (_i, [_vp, _i]),
+    "cs_debug_read": (_i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), _vp]),
     "cs_profile_enable": (_i, [_vp, _i]),
     "cs_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "cs_profile_read_bytes": (_i, [_vp, _i, C.POINTER(C.c_double)]),
@@ -54,7 +56,7 @@ SYMBOLS = {
     "cs_op_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cs_op_patch_embed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_patch_embed_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "cs_patch_fused_enable": (None, [_i]),
+    "cs_debug_patch_fused_enable": (None, [_i]),
     "cs_set_lanes": (_i, [_vp, _i]),
     "cs_redraw_lane_streams": (_i, [_vp]),
     "cs_op_pos_bicubic": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
@@ -67,7 +69,7 @@ SYMBOLS = {
     "cs_op_streams_overlap": (_i, [_vp, _vp, _vp]),
     "cs_op_ln_fold_consts": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cs_gemm_column_tiles": (_i, [_i]),
-    "cs_gemm256_enable": (None, [_i]),
+    "cs_debug_gemm256_enable": (None, [_i]),
     "cs_panel_supported": (_i, [_i, _i]),
     "cs_panel_image_bytes": (_sz, [_i]),
     "cs_op_panel_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -133,6 +133,7 @@ struct cs_model {
   // lanes: internal streams that run independent image chunks / batch groups concurrently (forked from and joined to
   // the caller's stream with events), so one kernel's tail and the memory-bound stages overlap another's MFMA work
   hipStream_t lane_st[CS_MAX_LANES] = {};
+  std::vector<hipStream_t> lane_st_old;  // given back by cs_redraw_lane_streams; destroyed once the next forward has drawn their replacements
   int lanes_now = 0;  // cs_set_lanes: lanes of the next forwards (0 = as configured)
   hipStream_t last_stream = nullptr; hipEvent_t ev_done = nullptr;  // ordering of calls that arrive on different streams
   hipEvent_t ev_kv0 = nullptr, ev_kv1 = nullptr;                    // decoder: K/V projection on a side stream
@@ -141,6 +142,10 @@ struct cs_model {
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
+  // debug taps (cs_debug_capture / cs_debug_read): copies of intermediate tensors of the last forward, for the stage-level parity tests
+  bool capture = false;
+  struct Tap { void* d = nullptr; size_t bytes = 0; int dtype = 0; int ndim = 0; int64_t shape[4] = {0, 0, 0, 0}; };
+  std::map<std::string, Tap> taps;
 };
 
 namespace {
@@ -262,9 +267,9 @@ struct Launcher {
   void end() { if (m->prof) hipEventRecord(m->recs.back().b, st); }
   bool gemm(CsGemmParams g, int epi, double k_real = 0) {
     if (rc) return false;
-    if (const char* e = cs_gemm_check(&g, epi)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
     g.bpc = bpc;
-    g.bf16 = m->cfg.operand_dtype;
+    g.bf16 = m->cfg.operand_dtype;  // before the check: its "bf16 with a LayerNorm-folded epilogue" guard reads it
+    if (const char* e = cs_gemm_check(&g, epi)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
     // algorithmic HBM bytes of one launch: A and W once (fp16), bias, the output once, the residual / position addend once
     const double mn = (double)g.M * g.N;
     const bool f32out = epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32 || epi == CS_EPI_HEAD_SCORE;
@@ -361,6 +366,31 @@ void reap_retired(cs_model* m, bool all) {
   }
 }
 
+// Debug tap: copies `bytes` of `src` into the tap `name` at byte offset `off` on stream `st` (stream-ordered behind the kernel that wrote src).
+// The tap buffer holds `total` bytes and is (re)allocated here when its size changes: capture mode is for tests, not for timed runs.
+int tap_buffer(cs_model* m, const std::string& name, size_t total, int dtype, std::initializer_list<int64_t> shape, void** out) {
+  cs_model::Tap& t = m->taps[name];
+  if (t.bytes != total) {
+    if (t.d) { HIPCHK(hipDeviceSynchronize()); hipFree(t.d); t.d = nullptr; t.bytes = 0; }
+    HIPCHK(hipMalloc(&t.d, total));
+    t.bytes = total;
+  }
+  t.dtype = dtype; t.ndim = (int)shape.size();
+  int k = 0;
+  for (int64_t v : shape) t.shape[k++] = v;
+  *out = t.d;
+  return 0;
+}
+int tap_copy(cs_model* m, const std::string& name, const void* src, size_t off, size_t bytes, size_t total, int dtype,
+             std::initializer_list<int64_t> shape, hipStream_t st) {
+  if (!m->capture) return 0;
+  void* d = nullptr;
+  if (int r = tap_buffer(m, name, total, dtype, shape, &d)) return r;
+  if (off + bytes > total) return fail(CS_ERR_STATE, "debug tap %s: copy out of range", name.c_str());
+  HIPCHK(hipMemcpyAsync(static_cast<char*>(d) + off, src, bytes, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -372,8 +402,8 @@ cs_handle cs_create(const cs_config* cfg) {
   const cs_config& c = *cfg;
   if (c.hidden <= 0 || c.hidden % 64 || c.hidden > 1024) { fail(CS_ERR_UNSUPPORTED, "hidden=%d must be a multiple of 64 and <= 1024", c.hidden); return nullptr; }
   if (c.enc_layers <= 0 || c.enc_heads <= 0 || c.hidden % c.enc_heads) { fail(CS_ERR_BAD_ARG, "bad encoder layers/heads"); return nullptr; }
-  if (!supported_dh(c.hidden / c.enc_heads)) { fail(CS_ERR_UNSUPPORTED, "encoder head dim %d not in {16,48,64,96}", c.hidden / c.enc_heads); return nullptr; }
-  if (c.dec_heads <= 0 || c.hidden % c.dec_heads || !supported_dh(c.hidden / c.dec_heads)) { fail(CS_ERR_UNSUPPORTED, "decoder head dim %d not in {16,48,64,96}", c.dec_heads > 0 ? c.hidden / c.dec_heads : 0); return nullptr; }
+  if (!supported_dh(c.hidden / c.enc_heads)) { fail(CS_ERR_UNSUPPORTED, "encoder head dim %d not in {16,48,64,96,128}", c.hidden / c.enc_heads); return nullptr; }
+  if (c.dec_heads <= 0 || c.hidden % c.dec_heads || !supported_dh(c.hidden / c.dec_heads)) { fail(CS_ERR_UNSUPPORTED, "decoder head dim %d not in {16,48,64,96,128}", c.dec_heads > 0 ? c.hidden / c.dec_heads : 0); return nullptr; }
   if (c.dec_layers <= 0 || c.patch <= 0 || (c.patch * c.patch) % 4 || c.pos_grid <= 0 || c.pe_h <= 0 || c.pe_w <= 0 || c.mlp_ratio <= 0) { fail(CS_ERR_BAD_ARG, "bad config"); return nullptr; }
   if (c.act != 0 && c.act != 1) { fail(CS_ERR_BAD_ARG, "act must be 0 (sigmoid) or 1 (tanh)"); return nullptr; }
   if (c.act == 1 && c.pow_p != 1.0f) { fail(CS_ERR_BAD_ARG, "power factor applies only to the sigmoid range"); return nullptr; }
@@ -394,7 +424,11 @@ cs_handle cs_create(const cs_config* cfg) {
 
 void cs_destroy(cs_handle h) {
   if (!h) return;
-  hipDeviceSynchronize();
+  // waits for THIS handle's work only (its last forward's completion event and its lane streams; a forward that failed half-way may have left
+  // lane work that no event covers) -- not for the device: sibling handles of a pipeline keep running while one is torn down
+  if (h->ev_done) hipEventSynchronize(h->ev_done);
+  for (int l = 0; l < CS_MAX_LANES; ++l) if (h->lane_st[l]) hipStreamSynchronize(h->lane_st[l]);
+  for (auto& r : h->retired) hipEventSynchronize(r.ev);
   for (auto& kv : h->w) if (kv.second.d) hipFree(kv.second.d);
   for (void* p : h->owned) hipFree(p);
   for (auto& t : h->tables) { if (t.pos_owned) hipFree(t.pos_tab); if (t.pe_owned) hipFree(t.pe_tab); }
@@ -408,9 +442,11 @@ void cs_destroy(cs_handle h) {
     if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]);
     if (h->ev_stag[l]) hipEventDestroy(h->ev_stag[l]);
   }
+  for (hipStream_t o : h->lane_st_old) hipStreamDestroy(o);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->nonfinite) hipFree(h->nonfinite);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (auto& kv : h->taps) if (kv.second.d) hipFree(kv.second.d);
   delete h;
 }
 
@@ -744,6 +780,8 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       lst[l] = h->lane_st[l];
     }
     if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (hipStream_t o : h->lane_st_old) hipStreamDestroy(o);  // the replacements exist now
+    h->lane_st_old.clear();
   }
   auto fork = [&](int n) -> int {
     if (NL == 1) return 0;
@@ -789,9 +827,16 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       L.gemm(g, CS_EPI_PATCH_F32, 3.0 * P * P);
     }
     (void)ob;
+    // tap: Dinov2Embeddings output (CLS row + patch rows + position rows), HF:97-116
+    if (h->capture && !L.rc) L.rc = tap_copy(h, "embeddings", x, (size_t)i0 * p.T * C * 4, (size_t)Mc * C * 4, (size_t)p.I * p.T * C * 4, 0, {p.I, p.T, C}, s);
     }
     const bool fold = h->lnfold;
     h16_t* ob = p.ob[slot]; float* stats = p.stats[slot];
+    // tap: the residual stream behind encoder layer l (Dinov2Layer output, HF:361-380)
+    auto tap_layer = [&](int l) {
+      if (h->capture && !L.rc)
+        L.rc = tap_copy(h, "enc_layer_" + std::to_string(l), x, (size_t)i0 * p.T * C * 4, (size_t)Mc * C * 4, (size_t)p.I * p.T * C * 4, 0, {p.I, p.T, C}, s);
+    };
     for (int l = 0; l < c.enc_layers; ++l) {
       if (l != stage) continue;
       const EncLayer& E = h->enc[l];
@@ -814,6 +859,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         q.x = x; q.attn_o = u; q.img = E.panel_img; q.bo = E.bo; q.b1 = E.c_1; q.b2 = E.b2; q.u_out = last ? nullptr : u;
         q.M = Mc; q.eps = 1e-6f;
         L.panel(q);
+        tap_layer(l);
         continue;
       }
       if (fold) {
@@ -842,6 +888,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
           if (!last) { g.out_f16 = u; g.stats_out = stats; g.stats_sp = h->ln_sp; }
           L.gemm(g, last ? CS_EPI_RESID_F32 : CS_EPI_RESID_F32_LN);  // the final LayerNorm reads the fp32 stream
         }
+        tap_layer(l);
         continue;
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, u, bf, s), "ln1"); L.end();
@@ -860,6 +907,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         g.resid = x; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
+      tap_layer(l);
     }
     if (stage != c.enc_layers) return;
     L.begin(32, 0);
@@ -898,7 +946,6 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.gemm(gp(q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_F16);
         CsAttnParams a{};
         a.bf16 = bf;
-      a.bf16 = bf;
         a.Q = dqkv; a.K = dqkv + C; a.V = dqkv + 2 * C; a.O = dob;
         a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
         a.q_bs = a.k_bs = a.v_bs = (long long)p.Np * 3 * C; a.o_bs = (long long)p.Np * C;
@@ -938,6 +985,9 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.gemm(g, CS_EPI_RESID_F32);
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n3g, D.n3b, 1e-5f, xq, q_bf, bf, s), "norm3"); L.end();
+      // tap: decoder layer l's output (transformer.py:157-173)
+      if (h->capture && !L.rc)
+        L.rc = tap_copy(h, "dec" + std::to_string(l) + "_out", xq, ro * C * 4, (size_t)M * C * 4, (size_t)B * p.Np * C * 4, 0, {B, p.Np, C}, s);
     }
     // head + RegressionLayer + jigsaw (cross_reference.py:45-50,82-87)
     L.gemm(gp(q_bf, C, h->Wh0, C, M, C, C, h->bh0, dhid, C), CS_EPI_BIAS_LEAKY_F16);
@@ -945,6 +995,13 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       CsGemmParams g = gp(dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4);
       g.Np = p.Np; g.gw = p.gw; g.P = P; g.act = c.act; g.powp = c.pow_p;
       L.gemm(g, CS_EPI_HEAD_SCORE);
+    }
+    if (h->capture && !L.rc) {
+      // tap: the head's second linear before the activation (cross_reference.py:45-50).  The score epilogue applies the activation in
+      // registers, so the pre-activation is produced by one more launch of the same GEMM with a plain fp32 store (capture mode only).
+      void* pre = nullptr;
+      L.rc = tap_buffer(h, "head_pre_activation", (size_t)B * p.Np * P * P * 4, 0, {B, p.Np, (int64_t)P * P}, &pre);
+      if (!L.rc) L.gemm(gp(dhid, C, h->Wh2, C, M, P * P, C, h->bh2, static_cast<float*>(pre) + ro * P * P, P * P), CS_EPI_RESID_F32);
     }
   };
 
@@ -982,6 +1039,17 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   }
   if (int r = join(NL)) return r;
   if (int r = lanes_rc()) return r;
+  if (h->capture) {
+    // taps: the decoder's inputs = final LayerNorm of the patch tokens + multi-view PE (core.py:141-153,93-98): query rows fp32, reference rows 16 bit
+    const int dt16 = bf ? 2 : 1;
+    if (mode == 2) {
+      if (int r = tap_copy(h, "featmap_ref", tokens_out, 0, (size_t)B * p.Np * C * 2, (size_t)B * p.Np * C * 2, dt16, {B, p.Np, C}, st)) return r;
+    } else {
+      if (int r = tap_copy(h, "featmap_query", p.xq, 0, (size_t)B * p.Np * C * 4, (size_t)B * p.Np * C * 4, 0, {B, p.Np, C}, st)) return r;
+      const h16_t* mem = mode == 1 ? ref_tokens : p.mem_bf;
+      if (int r = tap_copy(h, "featmap_ref", mem, 0, (size_t)B * N * p.Np * C * 2, (size_t)B * N * p.Np * C * 2, dt16, {B, (int64_t)N * p.Np, C}, st)) return r;
+    }
+  }
   if (mode == 2) return 0;
   {  // every image's tokens are in place (join above) before the decoder starts
     (void)ND;
@@ -1026,6 +1094,34 @@ int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_token
   return forward_impl(h, 1, query, nullptr, ref_tokens, nullptr, B, N, H, W, score_out, attn_out, head_id, mean_out, stream);
 }
 
+// Debug taps for the stage-level parity tests: with capture on, every forward also copies its intermediate tensors (stream-ordered
+// device-to-device copies into library-owned buffers): "embeddings", "enc_layer_<l>" (fp32 [I][T][C], images in the reference's
+// batch-major (query, refs) order), "featmap_query" (fp32 [B][Np][C]), "featmap_ref" (16 bit [B][N*Np][C]), "dec<l>_out" (fp32
+// [B][Np][C]), "head_pre_activation" (fp32 [B][Np][P*P]).  Not for timed runs: the first captured forward of a shape allocates.
+int cs_debug_capture(cs_handle h, int on) {
+  if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
+  h->capture = on != 0;
+  return 0;
+}
+
+// Copies tap `name` of the last captured forward to `dst` (device memory, dst_bytes >= the tap's size) on `stream`; reports its element
+// type (CS_DTYPE_*), rank and shape.  dst == NULL: only reports.  CS_ERR_STATE when no forward has captured that tap.
+int cs_debug_read(cs_handle h, const char* name, void* dst, size_t dst_bytes, int* dtype, int* ndim, int64_t* shape4, cs_stream stream) {
+  if (!h || !name) return fail(CS_ERR_BAD_ARG, "null argument");
+  auto it = h->taps.find(name);
+  if (it == h->taps.end() || !it->second.d) return fail(CS_ERR_STATE, "no tap named '%s' was captured (cs_debug_capture before the forward?)", name);
+  const cs_model::Tap& t = it->second;
+  if (dtype) *dtype = t.dtype;
+  if (ndim) *ndim = t.ndim;
+  if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+  if (!dst) return 0;
+  if (dst_bytes < t.bytes) return fail(CS_ERR_BAD_ARG, "tap '%s' holds %zu bytes, destination %zu", name, t.bytes, dst_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  if (h->ev_done && h->last_stream != st) HIPCHK(hipStreamWaitEvent(st, h->ev_done, 0));
+  HIPCHK(hipMemcpyAsync(dst, t.d, t.bytes, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 int cs_profile_enable(cs_handle h, int on) {
   if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
   hipDeviceSynchronize();
@@ -1050,7 +1146,9 @@ int cs_redraw_lane_streams(cs_handle h) {
   for (int l = 0; l < CS_MAX_LANES; ++l)
     if (h->lane_st[l]) {
       HIPCHK(hipStreamSynchronize(h->lane_st[l]));
-      HIPCHK(hipStreamDestroy(h->lane_st[l]));
+      // kept alive until the next forward has created the replacements: a stream destroyed now would hand its hardware queue
+      // straight back to the very next hipStreamCreate
+      h->lane_st_old.push_back(h->lane_st[l]);
       h->lane_st[l] = nullptr;
     }
   return 0;
@@ -1099,7 +1197,7 @@ int cs_nonfinite_count(cs_handle h, long long* count) {
 // single-op entry points
 // ---------------------------------------------------------------------------------------------------------
 static int g_op_bf16 = 0;  // operand type of the cs_op_* entry points below (a handle carries its own: cs_config.operand_dtype)
-int cs_op_set_operand_dtype(int dtype) {
+int cs_debug_set_op_operand_dtype(int dtype) {
   if (dtype != 0 && dtype != 1) return fail(CS_ERR_BAD_ARG, "operand dtype must be 0 (fp16) or 1 (bf16)");
   g_op_bf16 = dtype;
   return 0;

@@ -101,18 +101,23 @@ __global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
     kgo[it] = ((unsigned)skey[it] * (unsigned)p.ldk + (unsigned)sch[it] * 8u) * 2u;
     vgo[it] = ((unsigned)skey[it] * (unsigned)p.ldv + (unsigned)sch[it] * 8u) * 2u;
   }
-  // K / V tiles through buffer loads: scalar tile offset + this thread's 32-bit offset, and the descriptor's range check returns zeros for
-  // keys past Lk (they are masked to -inf in S and multiply p = 0 in PV), so the ragged last tile needs no clamped addresses and no
-  // second code path (cdna_hip_programming T8)
-  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(Kb), 0, (int)(((size_t)(p.Lk - 1) * p.ldk + DH) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(Vb), 0, (int)(((size_t)(p.Lk - 1) * p.ldv + DH) * 2), 0x00020000);
+  // K / V tiles through buffer loads.  The descriptor's range check returns zeros for keys past Lk (they are masked to -inf in S and
+  // multiply p = 0 in PV), so the ragged last tile needs no clamped addresses and no second code path (cdna_hip_programming T8).  The
+  // hardware check covers the VGPR offset only -- an SGPR offset is added AFTER it -- so the tile's position must not travel in soffset
+  // (rows past Lk would then be read, and a NaN bit pattern behind V's last row gives 0 * NaN in O).  Each tile therefore gets
+  // its own descriptor: base advanced to the tile's first row, num_records = the bytes that remain (scalar arithmetic only, nothing per lane).
+  const unsigned k_bytes = (unsigned)(((size_t)(p.Lk - 1) * p.ldk + DH) * 2), v_bytes = (unsigned)(((size_t)(p.Lk - 1) * p.ldv + DH) * 2);
 #define CS_ATTN_LOAD_TILE(T)                                                                       \
   {                                                                                                \
-    const int ks_ = (T) * 64 * p.ldk * 2, vs_ = (T) * 64 * p.ldv * 2;                              \
+    const unsigned ks_ = (unsigned)(T) * 64u * (unsigned)p.ldk * 2u, vs_ = (unsigned)(T) * 64u * (unsigned)p.ldv * 2u; \
+    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(                         \
+        const_cast<char*>(reinterpret_cast<const char*>(Kb)) + ks_, 0, (int)(k_bytes - ks_), 0x00020000); \
+    const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(                         \
+        const_cast<char*>(reinterpret_cast<const char*>(Vb)) + vs_, 0, (int)(v_bytes - vs_), 0x00020000); \
     _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
       if (kFullLast || it + 1 < NIT || tid + it * 256 < 64 * CH) {                                 \
-        kreg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(k_rs, kgo[it], ks_, 0)); \
-        vreg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v_rs, vgo[it], vs_, 0)); \
+        kreg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(k_rs, kgo[it], 0, 0)); \
+        vreg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v_rs, vgo[it], 0, 0)); \
       }                                                                                            \
     }                                                                                              \
   }

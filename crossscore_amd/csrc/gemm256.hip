@@ -447,7 +447,7 @@ int cs_gemm256_debug_read(unsigned long long* dst) { return (int)hipMemcpyFromSy
 #endif
 
 // tools / tests: 0 routes every GEMM to gemm.hip's kernel again
-void cs_gemm256_enable(int on) { g_enabled = on; }
+void cs_debug_gemm256_enable(int on) { g_enabled = on; }
 
 // Shapes this kernel takes (everything else stays with gemm.hip): whole 256-column tiles, an even number of 64-deep K tiles and
 // K >= 512 (below that a tile's prologue and epilogue outweigh what the larger tile saves), the plain epilogues.

@@ -253,7 +253,7 @@ int g_pf_enabled = 1;
 
 }  // namespace
 
-extern "C" void cs_patch_fused_enable(int on) { g_pf_enabled = on; }
+extern "C" void cs_debug_patch_fused_enable(int on) { g_pf_enabled = on; }
 
 // halves in the fragment-ordered weight copy
 size_t cs_patch_pack_elems(int C) { return (size_t)(C / 96) * PF_KS * PF_NT * 64 * 8; }

@@ -109,6 +109,7 @@ class CrossScoreNet(torch.nn.Module):
         # the mode for checkpoints whose activations leave the half range; nonfinite_count() tells).  An optional key of THIS build:
         # model.backbone.operand_dtype; the predict driver derives it from the reference's own trainer.precision key.
         self.operand_dtype = str(cfg.model.backbone.get("operand_dtype", "fp16"))
+        self._capture = False      # debug taps (debug_capture / debug_read): stage-level parity tests only
         self.finite_check = True   # every forward counts the non-finite values of its score map on the device (~3 us)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
@@ -185,6 +186,8 @@ class CrossScoreNet(torch.nn.Module):
                 lib.cs_destroy(h)
                 raise
         self._handle, self._handle_device, self._dirty = h, device, False
+        if self._capture:
+            _lib.check(lib.cs_debug_capture(h, 1))
         return h
 
     # -- forward ----------------------------------------------------------------------------------------------
@@ -336,6 +339,28 @@ class CrossScoreNet(torch.nn.Module):
             if seen[-1] < (1.0 - min_gain) * one:
                 break
         return {"one_lane_s": one, "lanes_s": seen}
+
+    # -- debug taps used by the stage-level parity tests (tests/test_hip_stages.py) ------------------------------------
+    def debug_capture(self, on: bool = True) -> None:
+        """Following forwards also keep their intermediate tensors (cs_debug_capture): not for timed runs."""
+        self._capture = bool(on)
+        if self._handle is not None:
+            _lib.check(_lib.load().cs_debug_capture(self._handle, int(self._capture)))
+
+    def debug_read(self, name: str) -> torch.Tensor:
+        """Tap `name` of the last captured forward (include/crossscore_hip.h lists the names), in its own dtype and shape."""
+        if self._handle is None:
+            raise _lib.CrossScoreHipError("debug_read before any forward")
+        lib = _lib.load()
+        dt, nd, shp = C.c_int(), C.c_int(), (C.c_int64 * 4)()
+        stream = C.c_void_p(torch.cuda.current_stream(self._handle_device).cuda_stream)
+        _lib.check(lib.cs_debug_read(self._handle, name.encode(), None, 0, C.byref(dt), C.byref(nd), shp, stream))
+        dtype = {_lib.DTYPE_F32: torch.float32, _lib.DTYPE_F16: torch.float16, _lib.DTYPE_BF16: torch.bfloat16}[dt.value]
+        out = torch.empty(tuple(int(shp[k]) for k in range(nd.value)), dtype=dtype, device=self._handle_device)
+        with torch.cuda.device(self._handle_device):
+            _lib.check(lib.cs_debug_read(self._handle, name.encode(), C.c_void_p(out.data_ptr()), out.numel() * out.element_size(),
+                                         C.byref(dt), C.byref(nd), shp, stream))
+        return out
 
     # -- profiling hooks used by bench.py --------------------------------------------------------------------
     def profile_enable(self, on: bool) -> None:

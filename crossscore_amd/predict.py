@@ -156,16 +156,22 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
         consume(queued.pop(0))
     torch.cuda.synchronize(device)
     t_loop = time.perf_counter() - t0
+    # finish the outputs and the pools first, then decide about the overflow report together with the other ranks: a rank that raised on its
+    # own before the barrier would leave the others waiting in it, and the files written so far are worth keeping either way
+    try:
+        if writer is not None:
+            writer.finish()
+        files += summariser.summarise()
+    finally:
+        prefetch.shutdown()
+        pool.shutdown()
     bad = pipe.nonfinite_count()
-    if bad:  # an activation left the range of the 16-bit operand type somewhere upstream (fp16: |x| > 65504)
-        raise FloatingPointError(f"{bad} non-finite score-map values with {net.operand_dtype} MFMA operands: run with trainer.precision=bf16-mixed "
-                                 "(model.backbone.operand_dtype=bf16)")
-    if writer is not None:
-        writer.finish()
-    files += summariser.summarise()
-    prefetch.shutdown()
-    pool.shutdown()
+    bad_any = int(parallel.max_over_ranks(float(bad), device))  # every rank learns whether ANY rank saw non-finite values
     parallel.barrier()
+    if bad_any:  # an activation left the range of the 16-bit operand type somewhere upstream (fp16: |x| > 65504)
+        raise FloatingPointError(f"{bad} non-finite score-map values on this rank (up to {bad_any} on one rank) with {net.operand_dtype} MFMA operands: "
+                                 "run with trainer.precision=bf16-mixed (model.backbone.operand_dtype=bf16); the outputs written are under "
+                                 f"{cfg.logger.predict.out_dir}")
     return {"out_dir": cfg.logger.predict.out_dir, "files": files, "rows": summariser.rows,
             "query_images_per_sec": n_done / t_loop if t_loop > 0 else 0.0}  # the whole scoring loop: input stage, forwards, output stage
 

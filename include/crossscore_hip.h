@@ -40,7 +40,7 @@ typedef void* cs_stream; /* hipStream_t */
 enum {
   CS_OK = 0,
   CS_ERR_BAD_ARG = 1,     /* shape / config the reference would also reject (ValueError / assert) */
-  CS_ERR_UNSUPPORTED = 2, /* legal for the reference, not built here (e.g. head dim outside {16,48,64,96}) */
+  CS_ERR_UNSUPPORTED = 2, /* legal for the reference, not built here (e.g. head dim outside {16,48,64,96,128}) */
   CS_ERR_STATE = 3,       /* wrong call order (forward before finalize, missing weight) */
   CS_ERR_HIP = 4          /* HIP runtime error; message carries hipGetErrorString */
 };
@@ -49,7 +49,7 @@ enum {
 typedef struct cs_config {
   int hidden;        /* C: Dinov2Config.hidden_size (384 small / 768 base), task/core.py:39 */
   int enc_layers;    /* Dinov2Config.num_hidden_layers */
-  int enc_heads;     /* Dinov2Config.num_attention_heads (head dim must be 64 or 16) */
+  int enc_heads;     /* Dinov2Config.num_attention_heads (head dim hidden / enc_heads in {16,48,64,96,128}; DINOv2: 64) */
   int mlp_ratio;     /* 4 */
   int patch;         /* model.patch_size = 14 */
   int pos_grid;      /* sqrt(#position_embeddings - 1) = 37 */
@@ -128,6 +128,21 @@ size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
 int cs_set_lanes(cs_handle h, int lanes);
 int cs_redraw_lane_streams(cs_handle h);
 
+/* Stage-level taps for the parity tests (tests/test_hip_stages.py): with capture on, every forward of this handle also copies its
+ * intermediate tensors into library-owned buffers (stream-ordered device-to-device copies; the first captured forward of a shape
+ * allocates -- not for timed runs).  Names follow the reference's module outputs (tests/golden/make_golden.py hooks the same points):
+ *   "embeddings"            fp32 (I, T, C)      Dinov2Embeddings output, HF modeling_dinov2.py:97-116; I = B * (1 + N) images in the
+ *                                               reference's batch-major (query, refs...) order of task/core.py:134-138, T = 1 + h*w
+ *   "enc_layer_<l>"         fp32 (I, T, C)      residual stream behind Dinov2Layer l, HF:361-380
+ *   "featmap_query"         fp32 (B, h*w, C)    final LayerNorm of the query's patch tokens + multi-view PE, core.py:141-153,93-98
+ *   "featmap_ref"           16 bit (B, N*h*w, C)  the same for the reference views (the decoder's memory), in the handle's operand type
+ *   "dec<l>_out"            fp32 (B, h*w, C)    decoder layer l output, transformer.py:157-173
+ *   "head_pre_activation"   fp32 (B, h*w, P*P)  head[2] output before the RegressionLayer, cross_reference.py:45-50
+ * cs_debug_read copies a tap to dst (device memory of at least the tap's size; NULL = only report) on `stream` and reports its element
+ * type (CS_DTYPE_*), rank and shape (4 entries).  CS_ERR_STATE when the last forwards captured no such tap. */
+int cs_debug_capture(cs_handle h, int on);
+int cs_debug_read(cs_handle h, const char* name, void* dst, size_t dst_bytes, int* dtype, int* ndim, int64_t* shape4, cs_stream stream);
+
 /* Per-kernel-family timing with HIP events on the launch stream (for bench.py's roofline object).
  * Families = kernel symbols: 0..9 cs_gemm_kernel<epilogue> (either GEMM kernel), 16 + dh/16 cs_attn_kernel<dh>, 40 cs_panel_kernel,
  * 41 cs_patch_fused_kernel, 32 everything else (LayerNorm, im2col, CLS rows, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */
@@ -137,8 +152,10 @@ int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, do
 int cs_profile_read_bytes(cs_handle h, int family, double* bytes);
 
 /* ---- single-op entry points (used by the parity tests; same kernels the forward launches) ------------- */
-/* 16-bit operand type of the cs_op_* entry points below (process-wide; a handle has its own cs_config.operand_dtype): 0 fp16 (default), 1 bf16 */
-int cs_op_set_operand_dtype(int dtype);
+/* cs_debug_*: PROCESS-WIDE switches and taps for tests and measurement tools.  They are not part of the drop-in surface: a product caller never
+ * needs them, and the "handles are independent" promise above holds only while nobody flips them under a running forward.
+ * 16-bit operand type of the cs_op_* entry points below (a handle has its own cs_config.operand_dtype): 0 fp16 (default), 1 bf16 */
+int cs_debug_set_op_operand_dtype(int dtype);
 /* out = epilogue(bias + A[M,K] @ W[N,K]^T): see CsEpilogue in csrc/cs_common.h for `epi`. fp16 = raw uint16. */
 int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K, const float* bias,
                const float* resid, int ldr, void* out, int ldc, int epi, const float* pos, int Np,
@@ -169,8 +186,8 @@ int cs_op_patch_embed(const float* x, const float* w, const float* bias, const f
  * Arguments and result as cs_op_patch_embed(centred = 1); CS_ERR_BAD_ARG for other shapes.  Replaces HF modeling_dinov2.py:141-149. */
 int cs_op_patch_embed_fused(const float* x, const float* w, const float* bias, const float* pos, int I, int H, int W, int P, int C,
                             float* out, cs_stream stream);
-/* 0 = cs_forward goes back to im2col + GEMM for the patch embedding (tests and tools; process-wide; default 1) */
-void cs_patch_fused_enable(int on);
+/* debug switch, process-wide (see cs_debug_* above): 0 = cs_forward goes back to im2col + GEMM for the patch embedding; default 1 */
+void cs_debug_patch_fused_enable(int on);
 /* Input stage: device uint8 HWC image (3 channels, rows in_row_bytes apart) -> fp32 CHW [3][out_h][out_w], the
  * tensor cs_forward consumes.  Same operations, in the same order, as the reference's CPU transforms: x/255 (utils/io/images.py:14-29),
  * antialiased bilinear resize to (rs_h, rs_w) (T.Resize, task/predict.py:87-93; skipped when equal to the input size), crop window
@@ -213,10 +230,10 @@ int cs_op_panel_pack(const float* wo, const float* ls1, const float* w1, const f
                      uint16_t* img, cs_stream stream);
 int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, const float* bo, const float* b1, const float* b2,
                         uint16_t* u_out, int M, float eps, cs_stream stream);
-/* Kernel selection of cs_op_gemm / the forward's linears (tests and tools; process-wide): 1 (default) = shapes with K >= 512, N a multiple of
+/* debug switch, process-wide (see cs_debug_* above).  Kernel selection of cs_op_gemm / the forward's linears: 1 (default) = shapes with K >= 512, N a multiple of
  * 256 and M >= 256 run on the 256 x 256 x 64-tile kernel (csrc/gemm256.hip), everything else on the 128-row kernel (csrc/gemm.hip);
  * 0 = the 128-row kernel for every shape.  The two kernels add the same products in the same order: their results are bit-identical (tested). */
-void cs_gemm256_enable(int on);
+void cs_debug_gemm256_enable(int on);
 /* number of column tiles the GEMM launcher uses for N output columns (LayerNorm partial-sum slots per row = 4 x this) */
 int cs_gemm_column_tiles(int N);
 

@@ -52,6 +52,22 @@ def test_cfg3_vitb_10refs_batch8(golden_dir):
     _properties(net, q, r, score)
 
 
+def test_cfg3_shape_vitb_bf16_operands_vs_reference_golden(golden_dir):
+    """BASELINE words cfg-2 "bf16"; the same operand mode on the ViT-B path (256 x 256 tile GEMMs with fp32-residual / GELU epilogues, dh = 64
+    encoder and dh = 96 decoder attention over 13 690 keys, all with bf16 MFMA forms): item 0 of cfg-3 (B = 1) against the reference's own
+    golden g2, inside north_star's 1e-3 (VERDICT r3 weak #2)."""
+    g = np.load(os.path.join(golden_dir, "g2_vitb_518_n10.npz"))
+    seed = int(g["seed"])
+    net, arch, sd = _net(VITB, seed)
+    net.operand_dtype = "bf16"
+    q, r = synth.make_inputs_shard(0, 1, 10, 518, 518, seed)
+    score = _run(net, q, r)
+    assert net.nonfinite_count() == 0
+    mae_rows, mae_grid, dmean = _check_compact(g, score)
+    print(f"cfg-3 shape, bf16 operands vs g2: MAE rows {mae_rows:.2e} grid {mae_grid:.2e} mean diff {dmean:.2e}")
+    assert mae_rows < MAE_TOL and mae_grid < MAE_TOL and dmean < 1e-3, (mae_rows, mae_grid, dmean)
+
+
 def test_cfg4_vitb_5refs_vs_oracle_and_16_per_gpu():
     """BASELINE configs[3]: ViT-B/14, 518x518, 5 refs, global bs=128 = 16 items per GPU.  B=2 against the fp32 oracle on the host,
     then one rank's 16 items: the first two must be bit-identical to the B=2 forward (shard-equivalence: concatenated shard outputs

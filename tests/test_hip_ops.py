@@ -103,7 +103,7 @@ def test_gemm_resid_f32(M, with_scale, with_resid):
 
 # ---- the 256 x 256 x 64-tile kernel (csrc/gemm256.hip): shapes with K >= 512, N % 256 == 0, M >= 256 ----
 def _gemm256(on):
-    _lib.load().cs_gemm256_enable(1 if on else 0)
+    _lib.load().cs_debug_gemm256_enable(1 if on else 0)
 
 
 def test_gemm256_exact_integer_layout():
@@ -160,10 +160,10 @@ def test_gemm256_matches_reference_and_small_tile_kernel(M, N, K):
 
 
 def test_ops_in_bf16_operand_mode():
-    """The single-op entry points with bfloat16 operands (cs_op_set_operand_dtype(1)): both GEMM kernels exact on small integers (which
+    """The single-op entry points with bfloat16 operands (cs_debug_set_op_operand_dtype(1)): both GEMM kernels exact on small integers (which
     bf16 holds exactly), bias + GELU / residual epilogues and attention against fp32 references at bf16 tolerances."""
     lib = _lib.load()
-    assert lib.cs_op_set_operand_dtype(1) == 0
+    assert lib.cs_debug_set_op_operand_dtype(1) == 0
     try:
         for (M, N, K) in ((300, 384, 256), (700, 512, 1024)):  # 128-row kernel / 256 x 256 x 64-tile kernel
             A = ((torch.arange(M, device=DEV)[:, None] * 5 + torch.arange(K, device=DEV)[None, :] * 3) % 7 - 3.0)
@@ -184,7 +184,17 @@ def test_ops_in_bf16_operand_mode():
         err = (og.float() - refg).abs()
         assert (err <= 4.2e-3 * refg.abs() + 3e-4).all(), float((err - 4.2e-3 * refg.abs()).max())  # bf16 output: half an ulp = rel 2^-8
         # attention, dh = 64 and 48
-        for dh, heads in ((64, 6), (48, 8)):
+        # the 256 x 256 tile kernel's fp32 residual epilogue and the 128-row kernel's, on random data (ragged M)
+        for (M, N, K) in ((1370, 768, 768), (700, 768, 3072), (300, 384, 384)):
+            A = _t(g.standard_normal((M, K), dtype=np.float32)).to(torch.bfloat16)
+            W = _t(g.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).to(torch.bfloat16)
+            b = _t(g.standard_normal((N,), dtype=np.float32))
+            res = _t(g.standard_normal((M, N), dtype=np.float32))
+            out = hh.gemm(A.view(torch.float16), W.view(torch.float16), b, _lib.EPI_RESID_F32, resid=res)
+            ref = res + A.float() @ W.float().t() + b
+            torch.cuda.synchronize()
+            assert (out - ref).abs().max() < 2e-4 * math.sqrt(K / 768), (M, N, K, float((out - ref).abs().max()))  # exact products, fp32 accumulation order only
+        for dh, heads in ((64, 6), (48, 8), (96, 8), (128, 8)):
             B, Lq, Lk = 2, 300, 500
             Q = _t(g.standard_normal((B, Lq, heads * dh), dtype=np.float32))
             Kt = _t(g.standard_normal((B, Lk, heads * dh), dtype=np.float32))
@@ -198,7 +208,7 @@ def test_ops_in_bf16_operand_mode():
             d = (O.float() - ref).abs()
             assert float(d.max()) < 3e-2 and float(d.mean()) < 3e-3, (dh, float(d.max()), float(d.mean()))
     finally:
-        lib.cs_op_set_operand_dtype(0)
+        lib.cs_debug_set_op_operand_dtype(0)
 
 
 def _row_partials(x, sp):
@@ -376,13 +386,13 @@ def test_patch_embed_one_launch_bf16_operands():
     b = _t(g.standard_normal((Cc,), dtype=np.float32))
     pos = _t(g.standard_normal((1 + Np, Cc), dtype=np.float32))
     lib = _lib.load()
-    lib.cs_op_set_operand_dtype(1)
+    lib.cs_debug_set_op_operand_dtype(1)
     try:
         one = hh.patch_embed_fused(x, wconv, b, pos, P).reshape(I, 1 + Np, Cc)
         two = hh.patch_embed(x, wconv, b, pos, P, 1).reshape(I, 1 + Np, Cc)
         torch.cuda.synchronize()
     finally:
-        lib.cs_op_set_operand_dtype(0)
+        lib.cs_debug_set_op_operand_dtype(0)
     assert (one[:, 1:] - two[:, 1:]).abs().max() < 2e-5
     ref = torch.nn.functional.conv2d(x.double(), wconv.double(), b.double(), stride=P).flatten(2).transpose(1, 2) + pos[None, 1:].double()
     assert (one[:, 1:].double() - ref).abs().mean() < 4e-3  # bfloat16 operands: 8 significant bits
@@ -556,6 +566,36 @@ def test_attention_strided_packed_qkv():
     ref, _, _ = _attn_ref(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads, dh)
     torch.cuda.synchronize()
     assert (O.float() - ref).abs().max() < 4e-3
+
+
+@pytest.mark.parametrize("dh,heads,Lq,Lk,packed", [(64, 6, 1370, 1370, True), (48, 8, 300, 1369, False), (96, 8, 257, 6845 % 2000 + 13, False),
+                                                   (128, 8, 130, 65, False), (16, 8, 70, 30, True)])
+def test_attention_ignores_poison_behind_the_last_key(dh, heads, Lq, Lk, packed):
+    """K / V are views into a larger buffer whose rows behind key Lk-1 hold NaN / Inf bit patterns: the ragged last tile must not
+    read them -- a masked key has p = 0, and 0 * NaN would reach O.  Encoder shape (packed [T][3C] projection, 1370 keys) and decoder shapes."""
+    g = _rng(dh + Lk)
+    Cc = heads * dh
+    pad = 130  # more than one 64-key tile of poison rows
+    poison = torch.tensor([float("nan"), float("inf"), -float("inf"), 65504.0], device=DEV).to(torch.float16)
+    if packed:
+        buf = poison[torch.arange((Lk + pad) * 3 * Cc, device=DEV) % 4].view(1, Lk + pad, 3 * Cc).clone()
+        buf[:, :Lk] = _bf(_t(g.standard_normal((1, Lk, 3 * Cc), dtype=np.float32)))
+        Q = hh.prescale_q(_bf(_t(1.5 * g.standard_normal((1, Lq, Cc), dtype=np.float32))), dh)
+        K, V = buf[:, :Lk, Cc:2 * Cc], buf[:, :Lk, 2 * Cc:]
+    else:
+        kb = poison[torch.arange((Lk + pad) * Cc, device=DEV) % 4].view(1, Lk + pad, Cc).clone()
+        vb = kb.clone()
+        kb[:, :Lk] = _bf(_t(1.5 * g.standard_normal((1, Lk, Cc), dtype=np.float32)))
+        vb[:, :Lk] = _bf(_t(g.standard_normal((1, Lk, Cc), dtype=np.float32)))
+        Q = hh.prescale_q(_bf(_t(1.5 * g.standard_normal((1, Lq, Cc), dtype=np.float32))), dh)
+        K, V = kb[:, :Lk], vb[:, :Lk]
+    O, lse = hh.attention(Q, K, V, heads, dh, lse=True, q_scale=1.0)
+    ref, _, lse_ref = _attn_ref(Q, K.contiguous(), V.contiguous(), heads, dh)
+    torch.cuda.synchronize()
+    assert torch.isfinite(O.float()).all() and torch.isfinite(lse).all()
+    err = (O.float() - ref).abs()
+    assert err.max() < 4e-3 and err.mean() < 4e-4, (float(err.max()), float(err.mean()))
+    assert (lse * math.log(2.0) - lse_ref).abs().max() < 5e-4
 
 
 def test_attention_weights_one_head():

@@ -199,8 +199,8 @@ def test_bench_launches_its_own_ranks_and_takes_the_slowest(tmp_path):
 
     env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
     env.pop("WORLD_SIZE", None)
-    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--plumbing-test", "--steps", "4", "--warmup", "1"],
-                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--plumbing-test", "--steps", "4", "--warmup", "1",
+                          "--global-batch", "5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout  # rank 0 prints ONE line
@@ -214,6 +214,13 @@ def test_bench_launches_its_own_ranks_and_takes_the_slowest(tmp_path):
     assert len({x["pid"] for x in seen}) == 2 and all(x["ms_per_step"] > 0 for x in seen)
     assert seen[1]["ms_per_step"] > seen[0]["ms_per_step"]  # rank 1's stub is the slow one
     assert r["process_group"]["backend"] == "gloo" and r["process_group"]["world_size"] == 2
+    # the strong-scaling leg (BASELINE configs[3]: a FIXED global batch sharded over the ranks, task/predict.py:119-135): ragged shards by
+    # parallel.shard_bounds, every rank's shard in the line, throughput = global batch over the slowest rank's time
+    s4 = r["scaling_cfg4"]
+    assert s4["mode"] == "strong" and s4["global_batch"] == 5
+    assert [x["shard"] for x in s4["ranks_seen"]] == [[0, 3], [3, 5]] and [x["items"] for x in s4["ranks_seen"]] == [3, 2]
+    assert s4["ms_per_step"] >= 3.0 and s4["ranks_seen"][0]["ms_per_step"] > s4["ranks_seen"][1]["ms_per_step"]  # rank 0 holds 3 items at 1 ms
+    assert abs(s4["value"] - 5 / (s4["ms_per_step"] / 1e3)) < 1e-6 * s4["value"]
 
 
 def test_predict_config_defaults_to_the_reference_environments_pos_embed_resize():

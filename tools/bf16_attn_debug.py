@@ -6,7 +6,7 @@ import hip_helpers as hh
 lib = _lib.load(); dev = "cuda"
 g = torch.Generator().manual_seed(0)
 for mode in (0, 1):
-    lib.cs_op_set_operand_dtype(mode)
+    lib.cs_debug_set_op_operand_dtype(mode)
     dt = torch.bfloat16 if mode else torch.float16
     for dh, heads in ((64, 6), (48, 8), (16, 8)):
         B, Lq, Lk = 2, 300, 500
@@ -19,4 +19,4 @@ for mode in (0, 1):
         torch.cuda.synchronize()
         for nm, O in (("raw q", O0), ("prescaled", O1)):
             d = (O.float() - ref).abs(); print(f"mode {mode} dh {dh} {nm}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}", flush=True)
-lib.cs_op_set_operand_dtype(0)
+lib.cs_debug_set_op_operand_dtype(0)

@@ -25,9 +25,9 @@ for Mimgs in [int(v) for v in os.environ.get("CS_GVB_IMGS", "48,12,96,8,22").spl
         resid = torch.randn(M, N, device=dev) if epi == _lib.EPI_RESID_F32 else None
         o = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.float16)
         lib = _lib.load()
-        lib.cs_gemm256_enable(0)
+        lib.cs_debug_gemm256_enable(0)
         t_old = timeit(lambda: hh.gemm(A, W, b, epi, resid=resid, out=o))
-        lib.cs_gemm256_enable(1)
+        lib.cs_debug_gemm256_enable(1)
         t_us = timeit(lambda: hh.gemm(A, W, b, epi, resid=resid, out=o))
         t_plain = timeit(lambda: hh.gemm(A, W, b, _lib.EPI_BIAS_F16, out=o if o.dtype == torch.float16 else None)) if False else 0
         Wt = W.t().contiguous(); ob = torch.empty(M, N, device=dev, dtype=torch.float16)
