@@ -9,7 +9,7 @@ pre-activation GEMM) and compared with the same-named golden array.
 
 Tolerances are relative to the stage's RMS magnitude (values are O(1)-O(10) after LayerNorm / in the residual stream): all MFMA operands are
 fp16 (11 significant bits, half an ulp = 4.9e-4 relative), accumulation / LayerNorm / residual stream fp32.  Measured values are printed;
-the bounds are ~3x what MI355X measured (r4), stated per stage below.
+the bounds are ~3x what MI355X measured (r4), stated per stage below; the bf16 test scales them by 8 (3 mantissa bits), which is again ~3x its measured values.
 """
 import os
 
@@ -28,13 +28,13 @@ TINY = "synthetic/dinov2-tiny"
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # stage -> (mean |d| / rms(ref), max |d| / rms(ref)) bounds, fp16 operand mode
-STAGE_TOL = {
-    "embeddings": (1.5e-3, 1.5e-2),          # one fp16-operand GEMM over 588 taps (mean-centred), fp32 position rows
-    "enc_layer": (2.5e-3, 2.5e-2),           # + QKV / attention / out-proj / MLP per layer, fp32 residual stream
-    "featmap_query": (2.5e-3, 2.5e-2),       # final LayerNorm (fp32) + PE
-    "featmap_ref": (2.5e-3, 2.5e-2),         # the same, stored as fp16 (the decoder's memory operand)
-    "dec_out": (4e-3, 4e-2),                 # self-attn + cross-attn over all reference tokens + FFN, three LayerNorms
-    "head_pre_activation": (6e-3, 6e-2),     # two more fp16-operand linears
+STAGE_TOL = {                                # measured on MI355X (r4), fp16 operands: mean / max
+    "embeddings": (7e-4, 3.5e-3),            # 2.3e-4 / 1.1e-3   one fp16-operand GEMM over 588 taps (mean-centred), fp32 position rows
+    "enc_layer": (1.2e-3, 7e-3),             # 3.7e-4 / 2.1e-3   + QKV / attention / out-proj / MLP per layer, fp32 residual stream
+    "featmap_query": (1.1e-3, 8e-3),         # 3.3e-4 / 2.5e-3   final LayerNorm (fp32) + PE
+    "featmap_ref": (1.2e-3, 9e-3),           # 3.8e-4 / 2.9e-3   the same, stored as fp16 (the decoder's memory operand)
+    "dec_out": (2e-3, 1.2e-2),               # 6.2e-4 / 3.9e-3   self-attn + cross-attn over all reference tokens + FFN, three LayerNorms
+    "head_pre_activation": (2.2e-3, 1.2e-2), # 7.1e-4 / 3.8e-3   two more fp16-operand linears
 }
 
 
