@@ -49,10 +49,16 @@ constexpr int PANEL_ROWS = 128;
 // LDS map.  Out-projection phase: 3 ring slots of 24 KiB, the residual-row tiles and attention-output fragments that travel with them.
 // MLP phase: 2 ring slots of 48 KiB (one barrier per tick) over the ring and the start of the then-idle tile region, activation slots.
 constexpr int LDS_RING = 0;
-constexpr int LDS_X = 3 * CHUNK;                     // 72 K: 3 slots x 4 pairs x 4 KiB residual-row tiles
-constexpr int LDS_OF = LDS_X + 3 * 4 * 4 * FRAG;     // 120 K: 3 slots x 4 pairs x 2 attention-output fragments
+constexpr int LDS_X = 3 * CHUNK;                     // 72 K: 3 slots x 4 pairs x one 6-KiB record [4 KiB residual-row tile | 2 attention-output fragments]
+constexpr int XREC = 6 * FRAG;                       //       (one record, one address register on the B side: r4)
+constexpr int LDS_OF = LDS_X + 3 * 4 * 4 * FRAG;     // 120 K (the MLP phase's hand-off areas start here; the out-projection records end at 144 K)
 constexpr int LDS_XF = 2 * TICK;                     // 96 K: norm2(x) hand-off, 4 pairs x 12 fragments at a time (48 KiB; ends at 144 K)
-constexpr int LDS_HB = LDS_OF;                       // 120 K: 2 slots x 4 pairs x 2 activation fragments (MLP phase)
+// 120 K, MLP phase: the pairs' hand-off areas of 6 KiB each (one base register, everything else immediates):
+//   [activation fragment of fc2 k-step 0, slot 0 | slot 1 (1 KiB each: written by the A wave) | the slice's other 8 pre-activations per lane as
+//    fp32, slot 0 | slot 1 (2 KiB each: the B wave activates them)]
+constexpr int LDS_HB = LDS_OF;
+constexpr int HB_PAIR = 6 * FRAG;
+constexpr int HB_RAW = 2 * FRAG;
 constexpr int LDS_B1 = LDS_OF + 3 * 4 * 2 * FRAG;    // 144 K: fc1 bias, fp32
 constexpr int LDS_BV = LDS_B1 + PF * 4;              // bo | b2, fp32
 constexpr int LDS_BYTES = LDS_BV + 2 * PC * 4;       // 153 KiB
@@ -86,6 +92,39 @@ __device__ __forceinline__ float gelu_erf1(float x) {
   q = fmaf(q, t, -6.5599355124e-02f);
   q = fmaf(q, t, 3.9850871469e-01f);
   return x * fmaf(c, q, 0.5f);
+}
+
+// the same arithmetic in two halves (5 + 6 instructions) so that a value can be spread over two MFMA gaps; c, t, q travel between them
+struct GeluMid { float c, t, q; };
+__device__ __forceinline__ GeluMid gelu_erf_a(float x) {
+  GeluMid m;
+  m.c = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f);
+  m.t = m.c * m.c;
+  m.q = fmaf(-9.6129670387e-10f, m.t, 8.3297297734e-08f);
+  m.q = fmaf(m.q, m.t, -3.1398569575e-06f);
+  m.q = fmaf(m.q, m.t, 6.8266010957e-05f);
+  return m;
+}
+__device__ __forceinline__ float gelu_erf_b(float x, GeluMid m) {
+  float q = fmaf(m.q, m.t, -9.6075936689e-04f);
+  q = fmaf(q, m.t, 9.3374518106e-03f);
+  q = fmaf(q, m.t, -6.5599355124e-02f);
+  q = fmaf(q, m.t, 3.9850871469e-01f);
+  return x * fmaf(m.c, q, 0.5f);
+}
+
+// the lane id from scratch (opaque to the compiler): lane-derived addresses of a late phase are formed from it where they are used, so that
+// nothing lane-derived has to stay in a register (or be spilled) across the MFMA loops, whose B-wave side runs at the 256-register limit
+__device__ __forceinline__ unsigned fresh_lane() {
+  unsigned l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+// x + (the same lane's value in the other half of the wave), without an index register (v_permlane32_swap exchanges the upper half of its
+// first operand with the lower half of its second: afterwards one register holds the lower halves' values twice, the other the upper ones')
+__device__ __forceinline__ float add_other_half(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -122,9 +161,14 @@ __device__ unsigned long long g_panel_dbg[64 * 8 * 16];
 #define CS_STAMP(k) do { if (blockIdx.x < 64 && lane == 0) { \
     __builtin_amdgcn_sched_barrier(0); g_panel_dbg[(blockIdx.x * 8 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define CS_STAMP_RT(k) do { if (blockIdx.x < 64 && lane == 0) g_panel_dbg[(blockIdx.x * 8 + wv) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// arrival / release times at the MLP phase's unit boundaries v = 40 .. 55 (ticks 20 .. 27) of blocks 0 .. 3: who is late at the barriers?
+__device__ unsigned long long g_panel_bar[4 * 8 * 16 * 2];
+#define CS_BAR_STAMP(v, k) do { if (blockIdx.x < 4 && (v) >= 40 && (v) < 56 && (threadIdx.x & 63) == 0) { \
+    __builtin_amdgcn_sched_barrier(0); g_panel_bar[((blockIdx.x * 8 + wv) * 16 + ((v) - 40)) * 2 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define CS_STAMP(k) do { } while (0)
 #define CS_STAMP_RT(k) do { } while (0)
+#define CS_BAR_STAMP(v, k) do { } while (0)
 #endif
 
 // ABL: timing-only ablations (tools/panel_ablate.py builds them with -DCS_PANEL_ABLATE; results are wrong by design):
@@ -160,28 +204,29 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     dma_piece<0>(s6, dst); dma_piece<FRAG>(s6, dst); dma_piece<2 * FRAG>(s6, dst); dma_piece<3 * FRAG>(s6, dst);
     dma_piece<0>(s6 + 4 * FRAG, dst + 4 * FRAG); dma_piece<FRAG>(s6 + 4 * FRAG, dst + 4 * FRAG);
     // residual-row tile c in the accumulator layout (piece q = registers 4q .. 4q+3 of every lane) and the B fragments of k-steps 2c, 2c+1
-    const unsigned dx = lds0 + LDS_X + (slot * 4 + pair) * 4 * FRAG;
+    const unsigned dx = lds0 + LDS_X + (slot * 4 + pair) * XREC;
     const char* sx = reinterpret_cast<const char*>(p.x) + (size_t)(xoff + c * 128);
     dma_piece<0>(sx, dx); dma_piece<0>(sx + 16, dx + FRAG); dma_piece<0>(sx + 32, dx + 2 * FRAG); dma_piece<0>(sx + 48, dx + 3 * FRAG);
-    const unsigned dof = lds0 + LDS_OF + (slot * 4 + pair) * 2 * FRAG;
+    const unsigned dof = dx + 4 * FRAG;
     const char* so = reinterpret_cast<const char*>(p.attn_o) + (size_t)(ooff + c * 64);
     dma_piece<0>(so, dof); dma_piece<0>(so + 32, dof + FRAG);
   };
-  int pend_t = 0;          // tick whose pieces issue_piece() copies
-  bool pend_late = false;  // pieces 6..11 of it are still to be issued (in the first gaps of the next tick)
-  // piece K (0..11) of this pair's twelve 1-KiB pieces of tick pend_t
+  // MLP weight stream (r4): the image is cut into HALF-tick units v = 2 t + hf of 24 KiB, [12 fragments of the A waves | 12 of the B waves]
+  // (fc1 slice t, k-steps 12 hf .. 12 hf + 11 | fc2 slice t - 2, k-step hf, tiles 0 .. 11); unit v lives at ring offset (v & 3) * 24 KiB, i.e.
+  // tick t still occupies the 48-KiB half (t & 1) of the ring.  Every A wave copies six 1-KiB pieces of a unit (pair * 6 + K).
+  int pend_u = 0;          // unit whose pieces issue_piece() copies
+  bool pend = false;       // ... if any
   auto issue_piece = [&](auto K_) {
     constexpr int K = decltype(K_)::value;
-    const unsigned dst = lds0 + LDS_RING + (pend_t & 1) * TICK + (pair * 12 + (K & ~3)) * FRAG;
-    const char* s = reinterpret_cast<const char*>(p.img) + (IMG_MLP + (size_t)pend_t * TICK + (pair * 12 + (K & ~3)) * FRAG) + lane16;
+    const unsigned dst = lds0 + LDS_RING + (pend_u & 3) * CHUNK + (pair * 6 + (K & ~3)) * FRAG;
+    const char* s = reinterpret_cast<const char*>(p.img) + (IMG_MLP + (size_t)pend_u * CHUNK + (pair * 6 + (K & ~3)) * FRAG) + lane16;
     dma_piece<(K & 3) * FRAG>(s, dst);
   };
-  auto tick_issue_all = [&](int t) {  // a wave's whole share of tick t at once (outside the tick loops)
-    pend_t = t;
+  auto tick_issue_all = [&](int t) {  // a wave's whole share of tick t at once (outside the tick loops): unit 2t first, then 2t + 1
     sfor<12>([&](auto K_) {
-      constexpr int K = decltype(K_)::value;
-      const unsigned dst = lds0 + LDS_RING + (t & 1) * TICK + (pair * 12 + (K & ~3)) * FRAG;
-      const char* s = reinterpret_cast<const char*>(p.img) + (IMG_MLP + (size_t)t * TICK + (pair * 12 + (K & ~3)) * FRAG) + lane16;
+      constexpr int K = decltype(K_)::value % 6, HF = decltype(K_)::value / 6;
+      const unsigned dst = lds0 + LDS_RING + (t & 1) * TICK + HF * CHUNK + (pair * 6 + (K & ~3)) * FRAG;
+      const char* s = reinterpret_cast<const char*>(p.img) + (IMG_MLP + (size_t)t * TICK + HF * CHUNK + (pair * 6 + (K & ~3)) * FRAG) + lane16;
       dma_piece<(K & 3) * FRAG>(s, dst);
     });
   };
@@ -189,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   // transition into unit u_next: this wave's LDS reads of the current unit are complete (its slot may be refilled right after the barrier)
   // and its own LDS-DMA pieces of unit u_next have landed; barrier (the same holds for every wave); then the next fetch is started (or, with
   // `defer`, left to issue_piece() between the caller's MFMAs).  Returns this lane's LDS address of fragment 0 of unit u_next.
-  auto transition = [&](auto ISA_, bool defer = false) -> unsigned {
+  auto transition = [&](auto ISA_) -> unsigned {
     constexpr bool ISA = decltype(ISA_)::value;
     CS_SB();
     unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
@@ -213,11 +258,9 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       if constexpr (ISA && OUTPROJ) out_unit_issue(u_next + 2);
     } else if (u_next + 1 >= NOUT) {
       const int t = u_next + 1 - NOUT;  // the tick to fetch now (the image ends with PAD_TICKS: no tail case)
-      if (t < 2) {
-        if constexpr (ISA) tick_issue_all(t);
-      } else if constexpr (!ISA && !(ABL & 2)) {
-        if (defer) { pend_t = t; pend_late = true; }
-        else tick_issue_all(t);
+      // MLP ticks 0 and 1 (units 0..3) are fetched here, whole, by the A waves; every later unit at the MLP phase's own unit boundaries
+      if constexpr (ISA) {
+        if (t < 2) tick_issue_all(t);
       }
     }
     const unsigned base = lds0 + LDS_RING + lane16 + (u_next < NOUT ? (u_next % 3) * CHUNK : ((u_next - NOUT) & 1) * TICK);
@@ -244,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if constexpr (OUTPROJ) { out_unit_issue(0); out_unit_issue(1); }
     else tick_issue_all(0);
-    unsigned cur = transition(TA{});                       // unit 0
+    unsigned cur = transition(TA{});              // unit 0
     CS_STAMP(1);
     for (int c = 0; c < NOUT; ++c) cur = transition(TA{});  // the B waves multiply units 0 .. NOUT-1; `cur` ends at MLP tick 0
     CS_STAMP(2);
@@ -265,7 +308,6 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     //      (t-1) & 1 before the tick's transition (gap 18): the partner multiplies them from tick t+1 on ----
     f32x16_t acE, acO;  // even / odd slices
     const unsigned bias_addr = lds0 + LDS_B1 + 64 * h;
-    const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
     float gv[8];
     f32x4_t bb[4];
     auto read_bias = [&](int t) {  // this lane's 16 hidden units of slice t: 32 t + 16 h + r
@@ -276,14 +318,58 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     // transition to the next unit sits before fragment 18, when all 24 fragments of this unit are in registers or behind it in the LDS queue.
     // hb_write = false for tick 0: its "previous slice" does not exist, and hb slot 1 lies inside the norm2 hand-off region (LDS_XF), which
     // the sibling pairs' A waves may still be reading behind H3 -- nothing may be written there before the first tick's transition
-    auto tick = [&](auto FC1_, f32x16_t& acc, const f32x16_t& act, int hb_slot, int t_next, bool hb_write) {
+    // GELU split (r4): the VALU work of a slice is shared by the two waves of the pair -- a single wave issues a vector instruction every 4-8
+    // cycles, and with all 16 values per lane on the A wave its instruction stream (24 MFMAs + ~190 VALU) set the tick (2 600 cycles against
+    // 1 536 of MFMA) while the B wave idled at the barrier.  The A wave now activates registers 0..7 of the previous slice (= the B fragment of
+    // fc2 k-step 0, one half value per MFMA gap) and hands registers 8..15 over as they are (fp32, 2 KiB per pair) at the start of the tick;
+    // the B wave activates those in the gaps of its first 12 MFMAs (which use k-step 0) into the fragment of k-step 1.  Same arithmetic on the
+    // same values: bit-identical to the one-wave form.
+    // Unit boundaries of the MLP phase (r4).  Round 3 had ONE barrier per tick with an LDS drain in front of it (the slot of the tick just
+    // read was refilled right behind the barrier): all eight waves stopped issuing MFMAs, emptied their prefetch queues, met, and refilled
+    // them -- the matrix pipe idled a quarter of every tick.  Now a unit is HALF a tick and is released LATE: the barrier in front of the first
+    // read of unit v + 1 (gap 6 / gap 18) only says "unit v + 1 has landed and everybody is done with unit v - 1" -- which the counted LDS waits
+    // of the gaps in between already guarantee -- so nobody drains anything, the reads in flight across the barrier target units v and v + 1,
+    // and the loader refills the slot of unit v - 1 with unit v + 3 (one 1-KiB piece per gap, 6 per A wave) two boundaries ahead of its use.
+    const unsigned hb_base = lds0 + LDS_HB + pair * HB_PAIR + lane16;
+    const unsigned ring = lds0 + LDS_RING + lane16;   // + (t & 1) * TICK: this lane's address of tick t's fragment 0
+    GeluMid gm;
+    auto boundary = [&](auto FC1_, int v) {  // in front of the first read of unit v + 1
+      CS_SB();
+      if constexpr (!decltype(FC1_)::value) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // (last tick: no counted waits retire its hand-off writes)
+      CS_BAR_STAMP(v, 0);
+      CS_VMCNT(6);  // this wave's pieces of unit v + 1 have landed (those of unit v + 2, issued one boundary ago, may be in flight)
+      if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      CS_BAR_STAMP(v, 1);
+      pend_u = v + 3;
+      pend = v >= 1 && v + 3 < 2 * NTICK && !(ABL & 2);
+      CS_SB();
+    };
+    auto tick = [&](auto FC1_, f32x16_t& acc, const f32x16_t& act, int hb_slot, int t, int t_next, bool hb_write) {
       constexpr bool FC1 = decltype(FC1_)::value;
       sfor<24>([&](auto M_) {
         constexpr int M = decltype(M_)::value;
+        if constexpr (M == 6) boundary(FC1_, 2 * t);
         if constexpr (M == 18) {
-          cur = transition(TA{});
+          boundary(FC1_, 2 * t + 1);
+          cur = ring + ((t + 1) & 1) * TICK;
           if constexpr (FC1) read_bias(t_next);  // (never leave an inline-asm read without a consumer: hipcc would reuse its destination
                                                  //  registers at once, and the LDS data would land on top of the new owner)
+        }
+        if constexpr ((M >= 6 && M < 12) || M >= 18) {
+          if (pend) issue_piece(IC<(M >= 18 ? M - 18 : M - 6)>{});
+        }
+        // The raw half of the previous slice leaves in gap 3, NOT in gap 0: `act` was completed by the last MFMA of the previous tick, and an
+        // inline-asm consumer gets none of the wait states hipcc inserts between an MFMA and a reader of its result (16 passes = 64 cycles
+        // for 32x32x16).  In gap 0 the ds_write read the accumulator before MFMAs 22 / 23 had landed (r4: every even slice lost k-steps 22 and
+        // 23 in registers 8..15, non-deterministically).  Three MFMAs of this tick (>= 32 cycles of matrix pipe each, issued in order behind
+        // that MFMA) lie in between now; the MFMA-free last tick waits explicitly.
+        if constexpr (M == 3) {
+          if (hb_write) {
+            if constexpr (!FC1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            lds_write16<HB_RAW>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[8], act[9], act[10], act[11]}));
+            lds_write16<HB_RAW + FRAG>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[12], act[13], act[14], act[15]}));
+          }
         }
         if constexpr (FC1) {
           CS_LGKM(5);
@@ -293,16 +379,27 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
             for (int q = 0; q < 4; ++q)
 #pragma unroll
               for (int i = 0; i < 4; ++i) b16[4 * q + i] = bb[q][i];
-            acc = mfma_32x32x16<BF>(w[0], xf[0], b16);
-          } else {
+            if constexpr (ABL & 4) acc = b16;
+            else acc = mfma_32x32x16<BF>(w[0], xf[0], b16);
+          } else if constexpr (!(ABL & 4)) {
             acc = mfma_32x32x16<BF>(w[M % 6], xf[M], acc);
           }
-          if constexpr (M < 18) lds_read1<(M + 6) * FRAG>(cur, w[M % 6]);
-          else lds_read1<(M - 18) * FRAG>(cur, w[M % 6]);
+          constexpr int F = (M + 6) % 24;  // the fragment read now: of this tick up to gap 17, of the next one (cur has moved) from gap 18 on
+          if constexpr (!(ABL & 32)) lds_read1<((F / 12) * 24 + F % 12) * FRAG>(cur, w[M % 6]);
         }
-        if constexpr (M < 16) gv[M & 7] = (ABL & 1) ? act[M] : gelu_erf1(act[M]);
-        if constexpr (M == 7) { if (hb_write) lds_write16<0>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8<BF>(gv)); }
-        if constexpr (M == 15) { if (hb_write) lds_write16<FRAG>(hb_addr + hb_slot * (4 * 2 * FRAG), pack8<BF>(gv)); }
+        // GELU of registers 0..7 of the previous slice: 16 half values over gaps 0..11 (two in gaps 6..9); the fragment leaves in gap 11, so that
+        // the counted wait of gap 17 has retired the write before the barrier of gap 18 tells the partner to read it
+        if constexpr (M < 12) {
+          constexpr int H0 = M < 6 ? M : (M < 10 ? 6 + 2 * (M - 6) : 14 + (M - 10));
+          constexpr int NH = (M >= 6 && M < 10) ? 2 : 1;
+          sfor<NH>([&](auto I_) {
+            constexpr int HI = H0 + decltype(I_)::value;
+            constexpr int V = HI >> 1;
+            if constexpr ((HI & 1) == 0) { if constexpr (!(ABL & 1)) gm = gelu_erf_a(act[V]); }
+            else gv[V] = (ABL & 1) ? act[V] : gelu_erf_b(act[V], gm);
+          });
+        }
+        if constexpr (M == 11) { if (hb_write) lds_write16<0>(hb_base + hb_slot * FRAG, pack8<BF>(gv)); }
         CS_SB();
       });
     };
@@ -311,15 +408,15 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acO[i] = 0.f;  // tick 0 "activates" this (slice -1: never read by the partner)
     for (int t = 0; t < NSL; t += 2) {
-      tick(std::true_type{}, acE, acO, 1, t + 1, t > 0);
-      tick(std::true_type{}, acO, acE, 0, min(t + 2, NSL - 1), true);
+      tick(std::true_type{}, acE, acO, 1, t, t + 1, t > 0);
+      tick(std::true_type{}, acO, acE, 0, t + 1, min(t + 2, NSL - 1), true);
     }
     CS_STAMP(4);
-    // tick NSL: only the GELU of the last slice (odd)
+    // tick NSL: only the GELU of the last slice (odd), and the boundaries the B waves' tick NSL needs
     CS_LGKM(0);
-    tick(std::false_type{}, acE, acO, 1, 0, true);
-    // (this was the transition into the last tick, NTICK - 1: the B waves' last slice)
-    CS_VMCNT(0);  // every LDS-DMA has landed before the workgroup can end
+    tick(std::false_type{}, acE, acO, 1, NSL, 0, true);
+    CS_VMCNT(0);  // every LDS-DMA has landed before the workgroup can end ...
+    if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();  // ... and the B waves' last boundary (tick NSL + 1, gap 6: unit 2 NTICK - 1)
     CS_STAMP(5);
     // ---- epilogue, A side: the partner stages its rows in LDS (three rounds: residual halves, normalised rows), this wave writes them to
     //      memory as whole 128-byte lines: a store instruction covers 4 rows x 256 contiguous bytes (16 lanes x 16 B per row) ----
@@ -369,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   // =======================================================================================================================
   CS_STAMP_RT(8); CS_STAMP(0);
   f32x16_t acc2[NT];
-  const unsigned bv_addr = lds0 + LDS_BV + 64 * h;
+  const unsigned bv_addr = lds0 + LDS_BV + 64 * (fresh_lane() >> 5);
   unsigned cur = transition(TB{});  // unit 0 (and: the bias vectors are in LDS)
   CS_STAMP(1);
   auto add_bias = [&](auto T_, auto INIT_, int which) {  // acc2[T] (+)= bias[32 T + 16 h + r]
@@ -387,11 +484,10 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     // ---- attention output projection.  Unit c = k-steps 2c, 2c+1 x 12 output tiles (fragment 12 ksl + T).  Its B fragments (this lane's
     //      16 B of its attention-output row per k-step) and residual-row tile c arrive in LDS with the unit (copied by the partner). ----
     sfor<NT>([&](auto T_) { add_bias(T_, std::true_type{}, 0); });
-    const unsigned xs_addr = lds0 + LDS_X + pair * 4 * FRAG + lane16;
-    const unsigned of_addr = lds0 + LDS_OF + pair * 2 * FRAG + lane16;
+    const unsigned xs_addr = lds0 + LDS_X + pair * XREC + lane16;  // this pair's record of slot 0 (+ slot * 4 * XREC)
     h16x8_t of[2];
-    lds_read1<0>(of_addr, of[0]);
-    lds_read1<FRAG>(of_addr, of[1]);
+    lds_read1<4 * FRAG>(xs_addr, of[0]);
+    lds_read1<5 * FRAG>(xs_addr, of[1]);
     sfor<6>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(cur, w[decltype(F_)::value]); });
     int slot_x = 0;  // ring slot of the current unit (its residual tile / attention-output fragments share the index)
     sfor<OUT_CHUNKS>([&](auto C_) {
@@ -410,13 +506,13 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           for (int i = 0; i < 4; ++i) acc2[C][4 * Q + i] += xs[i];
           CS_SB();
         }
-        if constexpr (M >= 12 && M <= 15) lds_read_f4<(M - 12) * FRAG>(xs_addr + slot_x * (4 * 4 * FRAG), xs);
+        if constexpr (M >= 12 && M <= 15) lds_read_f4<(M - 12) * FRAG>(xs_addr + slot_x * (4 * XREC), xs);
         if constexpr (M == 18) {
           cur = transition(TB{});
           slot_x = slot_x + 1 >= 3 ? 0 : slot_x + 1;
-          if constexpr (C + 1 < OUT_CHUNKS) lds_read1<0>(of_addr + slot_x * (4 * 2 * FRAG), of[0]);  // k-step 0's fragment is free from M = 12 on
+          if constexpr (C + 1 < OUT_CHUNKS) lds_read1<4 * FRAG>(xs_addr + slot_x * (4 * XREC), of[0]);  // k-step 0's fragment is free from M = 12 on
         }
-        if constexpr (M == 0 && C > 0) lds_read1<FRAG>(of_addr + slot_x * (4 * 2 * FRAG), of[1]);  // (needed from M = 12 on)
+        if constexpr (M == 0 && C > 0) lds_read1<5 * FRAG>(xs_addr + slot_x * (4 * XREC), of[1]);  // (needed from M = 12 on)
         CS_LGKM(5);
         constexpr int T = M % 12;
         acc2[T] = mfma_32x32x16<BF>(w[M % 6], of[M / 12], acc2[T]);
@@ -448,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     for (int T = 0; T < NT; ++T)
 #pragma unroll
       for (int r = 0; r < 16; r += 4) s += (acc2[T][r] + acc2[T][r + 1]) + (acc2[T][r + 2] + acc2[T][r + 3]);
-    s += __shfl_xor(s, 32, 64);
+    s = add_other_half(s);
     mean = s * (1.0f / PC);
     float q = 0.f;
 #pragma unroll
@@ -458,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
         const float d = acc2[T][r] - mean;
         q = fmaf(d, d, q);
       }
-    q += __shfl_xor(q, 32, 64);
+    q = add_other_half(q);
     rstd = 1.0f / sqrtf(q * (1.0f / PC) + p.eps);
   };
   {
@@ -490,35 +586,65 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   //      whose activations are in hb slot (t - LAGT) & 1.  A k-step uses ONE activation fragment for all 12 tiles, so the other fragment
   //      register is free to be refilled meanwhile: behind the tick's transition (gap 18) comes fragment 0 of the NEXT slice (the partner
   //      wrote it before that barrier), in gap 0 fragment 1 of the current slice. ----
-  for (int g = 0; g < LAGT - 1; ++g) cur = transition(TB{});
-  const unsigned hb_addr = lds0 + LDS_HB + pair * 2 * FRAG + lane16;
-  h16x8_t hb[2];
+  // the A waves' first LAGT ticks: two unit boundaries each (nothing to multiply yet)
+  for (int g = 0; g < 2 * LAGT; ++g) { if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier(); }
+  const unsigned hb_base = lds0 + LDS_HB + pair * HB_PAIR + lane16;
+  int cur_step = TICK;  // this lane's address of tick T's fragment 0 is lds0 + LDS_RING + lane16 + (T & 1) * TICK: `cur` alternates (no base register kept)
+  h16x8_t hb0;       // B fragment of k-step 0 of the current slice (activated by the partner)
+  u32x4_t hb1;       // B fragment of k-step 1: activated here, in the gaps of the k-step-0 MFMAs, from the partner's raw fp32 values
+  f32x4_t rw[2];     // those raw values (registers 8..15 of the partner's fc1 accumulator of the slice)
+  GeluMid gm;
+  // fc2 tick T = slice + LAGT (same parity): unit boundaries in front of gaps 6 and 18 as on the A side, but a B wave has nothing to wait for
+  // except the barrier itself (it issues no LDS-DMA, and its own reads of the released unit were retired by the counted waits long before)
   auto fc2_tick = [&](int slice, bool more) {
     sfor<24>([&](auto M_) {
       constexpr int M = decltype(M_)::value;
-      if constexpr (M == 0) lds_read1<FRAG>(hb_addr + (slice & 1) * (4 * 2 * FRAG), hb[1]);
+      if constexpr (M == 6) { CS_SB(); CS_BAR_STAMP(2 * (slice + LAGT), 0); if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); CS_BAR_STAMP(2 * (slice + LAGT), 1); CS_SB(); }
       if constexpr (M == 18) {
         if (more) {
-          cur = transition(TB{}, true);
-          lds_read1<0>(hb_addr + ((slice + 1) & 1) * (4 * 2 * FRAG), hb[0]);
+          CS_SB();
+          CS_BAR_STAMP(2 * (slice + LAGT) + 1, 0);
+          if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          CS_BAR_STAMP(2 * (slice + LAGT) + 1, 1);
+          cur += cur_step;
+          cur_step = -cur_step;
+          lds_read1<0>(hb_base + ((slice + 1) & 1) * FRAG, hb0);  // free from gap 12 on; the partner wrote it before this barrier
+          lds_read_f4<HB_RAW>(hb_base + ((slice + 1) & 1) * (2 * FRAG), rw[0]);
+          lds_read_f4<HB_RAW + FRAG>(hb_base + ((slice + 1) & 1) * (2 * FRAG), rw[1]);
+          CS_SB();
         }
       }
-      if constexpr (M >= 18) {
-        if (more && pend_late) issue_piece(IC<M - 18>{});
-      } else if constexpr (M < 6) {
-        if (pend_late) issue_piece(IC<6 + M>{});
-      }
-      if constexpr (M == 5) pend_late = false;
       CS_LGKM(5);
-      acc2[M % 12] = mfma_32x32x16<BF>(w[M % 6], hb[M / 12], acc2[M % 12]);
-      if constexpr (M < 18) lds_read1<(24 + M + 6) * FRAG>(cur, w[M % 6]);
-      else lds_read1<(24 + M - 18) * FRAG>(cur, w[M % 6]);  // (after the last tick: re-reads of this unit, unused)
+      if constexpr (ABL & 8) { if constexpr (M == 12) asm volatile("" ::"v"(hb1)); }
+      else if constexpr (M < 12) acc2[M % 12] = mfma_32x32x16<BF>(w[M % 6], hb0, acc2[M % 12]);
+      else acc2[M % 12] = mfma_32x32x16<BF>(w[M % 6], __builtin_bit_cast(h16x8_t, hb1), acc2[M % 12]);
+      constexpr int F = (M + 6) % 24;  // (after the last tick: re-reads of this tick's first fragments, unused)
+      if constexpr (!(ABL & 32)) lds_read1<((F / 12) * 24 + 12 + F % 12) * FRAG>(cur, w[M % 6]);
+      // the slice's second fragment: 8 values = 16 half values over gaps 0..11 (two in gaps 6..9), packed pairwise
+      if constexpr (M < 12) {
+        constexpr int H0 = M < 6 ? M : (M < 10 ? 6 + 2 * (M - 6) : 14 + (M - 10));  // first half-value index of this gap
+        constexpr int NH = (M >= 6 && M < 10) ? 2 : 1;
+        sfor<NH>([&](auto I_) {
+          constexpr int HI = H0 + decltype(I_)::value;
+          constexpr int V = HI >> 1;
+          const float x = rw[V >> 2][V & 3];
+          if constexpr ((HI & 1) == 0) { if constexpr (!(ABL & 1)) gm = gelu_erf_a(x); }
+          else {
+            const float y = (ABL & 1) ? x : gelu_erf_b(x, gm);
+            if constexpr ((V & 1) == 0) hb1[V >> 1] = __float_as_uint(y);  // parked in its own target word until the pair is complete
+            else hb1[V >> 1] = pack_o16x2<BF>(__uint_as_float(hb1[V >> 1]), y);
+          }
+        });
+      }
       CS_SB();
     });
   };
-  cur = transition(TB{});  // MLP tick LAGT: slice 0
-  lds_read1<0>(hb_addr, hb[0]);
-  sfor<6>([&](auto F_) { lds_read1<(24 + decltype(F_)::value) * FRAG>(cur, w[decltype(F_)::value]); });
+  cur = lds0 + LDS_RING + lane16;  // tick LAGT (even): slice 0
+  lds_read1<0>(hb_base, hb0);
+  lds_read_f4<HB_RAW>(hb_base, rw[0]);
+  lds_read_f4<HB_RAW + FRAG>(hb_base, rw[1]);
+  sfor<6>([&](auto F_) { lds_read1<(12 + decltype(F_)::value) * FRAG>(cur, w[decltype(F_)::value]); });
   for (int sl = 0; sl < NSL - 1; ++sl) fc2_tick(sl, true);
   fc2_tick(NSL - 1, false);
   CS_LGKM(0);
@@ -528,7 +654,8 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   // ---- epilogue, B side: rows go to memory through LDS and the partner (a lane holds 64 B of a row per tile: stored directly, every store
   //      instruction would touch 32 rows) ----
   {
-    const unsigned st_addr = lds0 + pair * ST_PAIR + j * ST_ROW + 64 * h;
+    const unsigned le = fresh_lane();
+    const unsigned st_addr = (unsigned)(size_t)CS_LDS_PTR(smem) + pair * ST_PAIR + (le & 31) * ST_ROW + 64 * (le >> 5);
     auto stage_x = [&](auto HALF_) {
       constexpr int HALF = decltype(HALF_)::value;
       sfor<6>([&](auto T_) {
@@ -551,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     __builtin_amdgcn_s_barrier();  // E4
     if (p.u_out) {
       const float nb = -mean * rstd;
-      const unsigned su = lds0 + pair * ST_PAIR + j * ST_ROW + 32 * h;
+      const unsigned su = (unsigned)(size_t)CS_LDS_PTR(smem) + pair * ST_PAIR + (le & 31) * ST_ROW + 32 * (le >> 5);
       sfor<NT>([&](auto T_) {
         constexpr int T = decltype(T_)::value;
         sfor<2>([&](auto Q_) {
@@ -607,7 +734,9 @@ __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restr
     const long long g2i = gi - n_out16;
     const int t = (int)(g2i / (TICK / 16));
     const int within = (int)(g2i - (long long)t * (TICK / 16));
-    const int f = within >> 6, lane = within & 63, i = lane & 31, h = lane >> 5;
+    // position in the tick: [half 0: 12 A | 12 B][half 1: 12 A | 12 B]  ->  f = role * 24 + (fragment of that role, 0..23)
+    const int fpos = within >> 6, lane = within & 63, i = lane & 31, h = lane >> 5;
+    const int f = ((fpos % 24) / 12) * 24 + (fpos / 24) * 12 + fpos % 12;
     if (t < NTICK) {
       if (f < 24) {
         if (t < NSL) {
@@ -656,6 +785,7 @@ extern "C" {
 
 #ifdef CS_PANEL_ABLATE
 int cs_panel_debug_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_panel_dbg), sizeof(g_panel_dbg)); }
+int cs_panel_bar_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_panel_bar), sizeof(g_panel_bar)); }
 #endif
 
 int cs_panel_supported(int C, int mlp_ratio) { return C == PC && mlp_ratio * C == PF; }
@@ -687,7 +817,7 @@ hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st) {
 #define CS_ABL_CASE(N) if (abl == N) { \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cs_panel_kernel<true, N>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
       hipLaunchKernelGGL((cs_panel_kernel<true, N>), dim3(grid), dim3(512), LDS_BYTES, st, *p); return hipGetLastError(); }
-    CS_ABL_CASE(1) CS_ABL_CASE(2) CS_ABL_CASE(3) CS_ABL_CASE(16) CS_ABL_CASE(18) CS_ABL_CASE(64)
+    CS_ABL_CASE(1) CS_ABL_CASE(2) CS_ABL_CASE(3) CS_ABL_CASE(4) CS_ABL_CASE(8) CS_ABL_CASE(12) CS_ABL_CASE(16) CS_ABL_CASE(18) CS_ABL_CASE(32) CS_ABL_CASE(34) CS_ABL_CASE(50) CS_ABL_CASE(64)
 #undef CS_ABL_CASE
   }
 #endif

@@ -47,6 +47,24 @@ if os.environ.get("CS_ABL_PKG"):  # child: crossscore_amd comes from the scratch
             clk = (d[:, sl, 5] - d[:, sl, 0]) / np.maximum(d[:, sl, 9] - d[:, sl, 8], 1) * 100.0
             print(f"M={Mrows} role {role}: phase cycles median", dict(zip(["prologue", "outproj", "handoff", "mlp", "tail"], np.median(ph, axis=0).astype(int).tolist())),
                   f"total {int(np.median(ph.sum(1)))} cycles; clock ~{np.median(clk):.0f} MHz", flush=True)
+    # who is late at the MLP phase's unit boundaries (units 40 .. 55 of blocks 0 .. 3): arrival relative to the first arriver, and the release
+    if hasattr(lib, "cs_panel_bar_read"):
+        os.environ["CS_PANEL_ABL"] = "0"
+        xs, os_, ws = _make(M, 1, dev)
+        for _ in range(3):
+            hh.encoder_panel(xs, os_, img, w["bo"], w["b1"], w["b2"])
+        torch.cuda.synchronize()
+        bb = np.zeros(4 * 8 * 16 * 2, dtype=np.uint64)
+        assert lib.cs_panel_bar_read(bb.ctypes.data_as(ctypes.c_void_p)) == 0
+        b = bb.reshape(4, 8, 16, 2).astype(np.int64)
+        for blk in range(2):
+            print(f"block {blk}: per boundary v = 40..55: arrival of waves A0..A3 B0..B3 relative to the first (cycles) | release - last arrival | interval since the previous release")
+            prev = None
+            for v in range(16):
+                arr = b[blk, :, v, 0]; rel = b[blk, :, v, 1]
+                first = arr.min()
+                print(f"  v={40 + v} (gap {6 if v % 2 == 0 else 18}):", " ".join(f"{int(a - first):5d}" for a in arr), "|", int(rel.min() - arr.max()), "|", (int(rel.min() - prev) if prev is not None else "-"))
+                prev = rel.min()
     # where the transitions' time goes (ABL = 64: s_memtime around the LDS drain, the vmcnt wait and the barrier of every transition)
     os.environ["CS_PANEL_ABL"] = "64"
     xs, os_, ws = _make(M, 1, dev)
