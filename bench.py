@@ -419,9 +419,15 @@ def main():
     # four more K-step regions follow and the median of the five is reported beside `value` (which stays the FIRST region's, per the
     # bench contract: exactly K timed steps after W warm-up steps)
     repeats = [elapsed]
-    for _ in range(0 if args.no_repeats else 4):
+    overlap = None
+    for k in range(0 if args.no_repeats else 4):
+        if k == 3:  # the last repeat also carries two timing events per forward: how long were two batches really in flight?
+            wl.pipe.record_timeline(True)
         e_r, _t = timed_steps(wl.step, sync, args.steps, 1, dev)
         repeats.append(e_r)
+        if k == 3:
+            overlap = wl.pipe.in_flight_fractions()
+            wl.pipe.record_timeline(False)
 
     # ---- the headline workload again with the other 16-bit operand type (BASELINE words cfg-2 "bf16"; the path's default is fp16): same
     #      K steps, same pipeline; both legs' values and score-map MAEs go into `dtype_legs` ----
@@ -500,6 +506,7 @@ def main():
             "ranks_seen": census, "process_group": parallel.backend_info(),
             "dtype": args.dtype, "data": "synthetic",  # 16-bit MFMA operands (IEEE half by default: the bf16 MFMA rate, 3 more mantissa bits), fp32 accumulate / softmax / LayerNorm / output
             "nonfinite_score_values": wl.pipe.nonfinite_count(),
+            "batches_in_flight_measured": overlap,  # of the fifth K-step region (warm-up step included), HIP events per forward
             "config": {"workload": wl.describe(world),
                        "gflop_per_query": flops_q / 1e9, "parallelism": f"batch-shard x{world} (replicas, no data-path collective); per GPU {wl.inflight} batch(es) in flight x "
                                       f"{wl.lanes if wl.lanes else 2} encoder lane(s)",

@@ -22,7 +22,7 @@ class CsConfig(C.Structure):
         ("patch", C.c_int), ("pos_grid", C.c_int), ("pe_h", C.c_int), ("pe_w", C.c_int),
         ("dec_layers", C.c_int), ("dec_heads", C.c_int), ("do_self_attn", C.c_int), ("do_short_cut", C.c_int),
         ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int), ("ln_fold", C.c_int), ("lanes", C.c_int), ("pos_interp_legacy", C.c_int), ("enc_fused", C.c_int),
-        ("operand_dtype", C.c_int), ("skip_finite_check", C.c_int),
+        ("operand_dtype", C.c_int), ("pe_interp_mode", C.c_int), ("skip_finite_check", C.c_int),
     ]
 
 
@@ -62,6 +62,7 @@ SYMBOLS = {
     "cs_op_pos_bicubic": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pos_bicubic_ex": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pe_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cs_op_pe_interp": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_score_to_gray16": (_i, [_vp, C.c_longlong, _i, _vp, _vp]),
     "cs_op_score_to_rgb": (_i, [_vp, C.c_longlong, C.c_float, C.c_float, _vp, _vp, _vp]),
     "cs_op_preprocess_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _vp]),

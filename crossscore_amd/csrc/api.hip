@@ -41,6 +41,7 @@ hipError_t cs_ln_fold_consts_launch(const h16_t* wp, int ldp, const float* w, co
 int cs_gemm_column_tiles(int N);
 hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float grow, float* out, hipStream_t st);
 hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st);
+hipError_t cs_pe_interp_launch(const float* pe, int ph, int pw, int C, int gh, int gw, int mode, float* out, hipStream_t st);
 hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
                                int bf, hipStream_t st);
 hipError_t cs_score_check_launch(const float* score, size_t n, unsigned* counter, hipStream_t st);
@@ -347,7 +348,7 @@ int ensure_tables(cs_model* m, int gh, int gw, bool square, hipStream_t st) {
   } else {
     HIPCHK(hipMalloc(&t.pe_tab, (size_t)Np * C * sizeof(float)));
     t.pe_owned = true;
-    HIPCHK(cs_pe_bilinear_launch(m->pe, c.pe_h, c.pe_w, C, gh, gw, t.pe_tab, st));
+    HIPCHK(cs_pe_interp_launch(m->pe, c.pe_h, c.pe_w, C, gh, gw, c.pe_interp_mode, t.pe_tab, st));
   }
   m->tables.push_back(t);
   m->pos_tab = t.pos_tab; m->pe_tab = t.pe_tab;
@@ -407,6 +408,7 @@ cs_handle cs_create(const cs_config* cfg) {
   if (c.dec_layers <= 0 || c.patch <= 0 || (c.patch * c.patch) % 4 || c.pos_grid <= 0 || c.pe_h <= 0 || c.pe_w <= 0 || c.mlp_ratio <= 0) { fail(CS_ERR_BAD_ARG, "bad config"); return nullptr; }
   if (c.act != 0 && c.act != 1) { fail(CS_ERR_BAD_ARG, "act must be 0 (sigmoid) or 1 (tanh)"); return nullptr; }
   if (c.act == 1 && c.pow_p != 1.0f) { fail(CS_ERR_BAD_ARG, "power factor applies only to the sigmoid range"); return nullptr; }
+  if (c.pe_interp_mode != 0 && c.pe_interp_mode != 1) { fail(CS_ERR_BAD_ARG, "pe_interp_mode must be 0 (bilinear) or 1 (bicubic)"); return nullptr; }
   if (c.operand_dtype != 0 && c.operand_dtype != 1) { fail(CS_ERR_BAD_ARG, "operand_dtype must be 0 (fp16) or 1 (bf16)"); return nullptr; }
   if (c.operand_dtype == 1 && c.ln_fold == 1) { fail(CS_ERR_UNSUPPORTED, "the LayerNorm-folded epilogues (ln_fold = 1) are built for fp16 operands only"); return nullptr; }
   cs_model* m = new cs_model();
@@ -1347,6 +1349,13 @@ int cs_op_pos_bicubic_ex(const float* pos, int G, int C, int gh, int gw, int leg
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream) {
   if (!pe || !out || ph <= 0 || pw <= 0 || C <= 0 || gh <= 0 || gw <= 0) return fail(CS_ERR_BAD_ARG, "pe_bilinear: bad arguments");
   HIPCHK(cs_pe_bilinear_launch(pe, ph, pw, C, gh, gw, out, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_pe_interp(const float* pe, int ph, int pw, int C, int gh, int gw, int mode, float* out, cs_stream stream) {
+  if (!pe || !out || ph <= 0 || pw <= 0 || C <= 0 || gh <= 0 || gw <= 0) return fail(CS_ERR_BAD_ARG, "cs_op_pe_interp: bad arguments");
+  if (mode != 0 && mode != 1) return fail(CS_ERR_BAD_ARG, "cs_op_pe_interp: mode must be 0 (bilinear) or 1 (bicubic)");
+  HIPCHK(cs_pe_interp_launch(pe, ph, pw, C, gh, gw, mode, out, (hipStream_t)stream));
   return 0;
 }
 

@@ -324,6 +324,39 @@ __global__ void pe_bilinear_kernel(const float* __restrict__ pe, int ph, int pw,
   out[i] = top * (1.f - ly) + bot * ly;
 }
 
+// The same resize with mode='bicubic' (model.pos_enc.multi_view.interpolate_mode; positional_encoding.py:61-69 passes the mode through with
+// align_corners=True): src = dst*(in-1)/(out-1), four taps per axis with border-clamped indices, A = -0.75 (aten upsample_bicubic2d).
+__global__ void pe_bicubic_ac_kernel(const float* __restrict__ pe, int ph, int pw, int C, int gh, int gw, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)gh * gw * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int t = (int)(i / C);
+  const int oy = t / gw, ox = t - oy * gw;
+  const float A = -0.75f;
+  const float scy = gh > 1 ? (float)(ph - 1) / (float)(gh - 1) : 0.f;
+  const float scx = gw > 1 ? (float)(pw - 1) / (float)(gw - 1) : 0.f;
+  const float sy = oy * scy, sx = ox * scx;
+  const float fy = floorf(sy), fx = floorf(sx);
+  const float ty = sy - fy, tx = sx - fx;
+  const int iy = (int)fy, ix = (int)fx;
+  const float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+  const float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int yy = min(max(iy - 1 + a, 0), ph - 1);
+    float rowacc = 0.f;
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) {
+      const int xx = min(max(ix - 1 + bq, 0), pw - 1);
+      rowacc += pe[((size_t)yy * pw + xx) * C + c] * wx[bq];
+    }
+    acc += rowacc * wy[a];
+  }
+  out[i] = acc;
+}
+
 // fp32 -> fp16 weight packing (K-contiguous rows; optional zero padding of K to ldo; optional per-output-row scale:
 // LayerScale lambda folded into the projection, HF modeling_dinov2.py:277-278, so the GEMM epilogue has no scale operand)
 __global__ void pack_f16_kernel(const float* __restrict__ w, int rows, int K, h16_t* __restrict__ out, int ldo,
@@ -514,6 +547,15 @@ hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw,
 hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st) {
   const long long total = (long long)gh * gw * C;
   hipLaunchKernelGGL(pe_bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pe, ph, pw, C, gh, gw, out);
+  return hipGetLastError();
+}
+
+// mode: 0 bilinear, 1 bicubic (both align_corners=True)
+hipError_t cs_pe_interp_launch(const float* pe, int ph, int pw, int C, int gh, int gw, int mode, float* out, hipStream_t st) {
+  if (mode == 0) return cs_pe_bilinear_launch(pe, ph, pw, C, gh, gw, out, st);
+  if (mode != 1) return hipErrorInvalidValue;
+  const long long total = (long long)gh * gw * C;
+  hipLaunchKernelGGL(pe_bicubic_ac_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pe, ph, pw, C, gh, gw, out);
   return hipGetLastError();
 }
 

@@ -78,8 +78,13 @@ class CrossScoreNet(torch.nn.Module):
         m = cfg.model
         if not m.do_reference_cross:
             raise NotImplementedError("model.do_reference_cross=False produces no score map in the reference (task/core.py:89); not built")
-        if m.pos_enc.multi_view.interpolate_mode != "bilinear":
-            raise NotImplementedError("only model.pos_enc.multi_view.interpolate_mode=bilinear (the reference default) is built")
+        # model/positional_encoding.py:61-69 hands the mode to F.interpolate together with align_corners=True, which torch accepts for a 4-D tensor
+        # only with the interpolating modes bilinear and bicubic: every other value raises there too ("align_corners option can only be set with
+        # the interpolating modes ...").  The reference raises at the first forward that has to resize; here the error comes at construction.
+        self._pe_mode = {"bilinear": 0, "bicubic": 1}.get(str(m.pos_enc.multi_view.interpolate_mode))
+        if self._pe_mode is None:
+            raise ValueError(f"model.pos_enc.multi_view.interpolate_mode={m.pos_enc.multi_view.interpolate_mode!r}: align_corners option can only be "
+                             "set with the interpolating modes: linear | bilinear | bicubic | trilinear (4-D input: bilinear | bicubic)")
         self.arch = arch_from_cfg(cfg)
         metric = m.predict.metric
         self._act, self._pow = regression_activation(metric.type, metric.min, metric.max, metric.power_factor)
@@ -168,7 +173,7 @@ class CrossScoreNet(torch.nn.Module):
                            do_self_attn=int(bool(m.decoder_do_self_attn)), do_short_cut=int(bool(m.decoder_do_short_cut)),
                            act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold),
                            lanes=int(self.lanes), pos_interp_legacy=int(self._pos_legacy), enc_fused=int(self.enc_fused),
-                           operand_dtype=self._operand_code(), skip_finite_check=int(not self.finite_check))
+                           operand_dtype=self._operand_code(), pe_interp_mode=int(self._pe_mode), skip_finite_check=int(not self.finite_check))
         with torch.cuda.device(device):
             h = lib.cs_create(C.byref(cc))
             if not h:

@@ -73,6 +73,7 @@ class ForwardPipeline:
 
             net.register_load_state_dict_post_hook(_replicas_dirty)
         self._n = 0
+        self._marks = None  # record_timeline(): [(replica, start event, end event)] of every submit
 
     def _overlapping_streams(self, n: int) -> List[Any]:
         """n streams on which kernels really run side by side.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
@@ -155,21 +156,57 @@ class ForwardPipeline:
         self.streams = best[1]
         return {"serial_s": serial, "in_flight_s": seen}
 
+    def record_timeline(self, on: bool = True) -> None:
+        """From now on every submit is bracketed by two timing events on its replica's stream (in-run evidence of how many batches are in
+        flight: in_flight_fractions()).  Two event records per forward; off by default."""
+        self._marks = [] if on else None
+
+    def in_flight_fractions(self) -> Dict[str, Any]:
+        """Fractions of the recorded window (first start .. last end) during which 0 / 1 / >= 2 forwards were executing, from the HIP events of
+        record_timeline() (device time, on the streams the forwards ran on).  Waits for the recorded work."""
+        if not self._marks:
+            return {}
+        torch.cuda.synchronize(self.device)
+        t0 = self._marks[0][1]
+        iv = sorted((t0.elapsed_time(a), t0.elapsed_time(b)) for _, a, b in self._marks)  # ms since the first start
+        pts = sorted([(a, 1) for a, _ in iv] + [(b, -1) for _, b in iv])
+        lo, hi = min(a for a, _ in iv), max(b for _, b in iv)
+        acc, depth, last = [0.0, 0.0, 0.0], 0, lo
+        for t, d in pts:
+            acc[min(depth, 2)] += t - last
+            last, depth = t, depth + d
+        span = max(hi - lo, 1e-9)
+        n = len(self._marks)
+        self._marks = []
+        return {"forwards": n, "window_ms": span, "fraction_two_in_flight": acc[2] / span, "fraction_one_in_flight": acc[1] / span,
+                "fraction_idle": acc[0] / span,
+                "measured": "HIP events at the start and the end of every forward of the window, recorded on the stream the forward ran on"}
+
     def _run(self, method: str, args, kwargs) -> Ticket:
         i = self._n % self.depth
         self._n += 1
         net = self.nets[i]
         if self.depth == 1:
+            if self._marks is not None:
+                a = torch.cuda.Event(enable_timing=True)
+                a.record(torch.cuda.current_stream(self.device))
             out = getattr(net, method)(*args, **kwargs)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self._marks is not None)
             ev.record(torch.cuda.current_stream(self.device))
+            if self._marks is not None:
+                self._marks.append((0, a, ev))
             return Ticket(out, ev, None)
         s = self.streams[i]
         s.wait_stream(torch.cuda.current_stream(self.device))  # inputs were produced on the caller's stream
         with torch.cuda.stream(s):
+            if self._marks is not None:
+                a = torch.cuda.Event(enable_timing=True)
+                a.record(s)
             out = getattr(net, method)(*args, **kwargs)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self._marks is not None)
             ev.record(s)
+            if self._marks is not None:
+                self._marks.append((i, a, ev))
         for a in list(args) + list(kwargs.values()):
             if isinstance(a, torch.Tensor) and a.is_cuda:
                 a.record_stream(s)  # the caching allocator must not recycle an input before the replica has read it

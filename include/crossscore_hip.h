@@ -74,6 +74,9 @@ typedef struct cs_config {
                        * bits, finite to 65504; score-map MAE 1e-4 vs the fp32 reference), 1 = bfloat16 (8 bits, fp32's range; MAE 8e-4): the
                        * choice for a checkpoint whose activations leave the half range (trainer.precision = bf16-mixed in the predict driver).
                        * Accumulation, softmax statistics, LayerNorm, the residual stream and the outputs are fp32 either way. */
+  int pe_interp_mode; /* model.pos_enc.multi_view.interpolate_mode, applied when the patch grid differs from (pe_h, pe_w) (model/positional_encoding.py:61-69,
+                       * always with align_corners=True): 0 = bilinear (the reference default), 1 = bicubic.  torch rejects every other mode of a 4-D
+                       * tensor with align_corners=True, so these two are all the reference can run. */
   int skip_finite_check; /* 0 = default: every forward ends with a pass over the score map that counts non-finite values into a device
                        * counter (cs_nonfinite_count; ~3 us); 1 = skip it */
 } cs_config;
@@ -207,6 +210,8 @@ int cs_op_pos_bicubic(const float* pos, int G, int C, int gh, int gw, float* out
  * transformers 4.33.3 form scale_factor=((gh + 0.1) / G, (gw + 0.1) / G) (cs_config.pos_interp_legacy; golden tests/golden/g6_pos_legacy.npz) */
 int cs_op_pos_bicubic_ex(const float* pos, int G, int C, int gh, int gw, int legacy, float* out, cs_stream stream);
 int cs_op_pe_bilinear(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, cs_stream stream);
+/* the same resize with the mode as an argument: 0 bilinear (cs_op_pe_bilinear), 1 bicubic; align_corners=True in both (cs_config.pe_interp_mode) */
+int cs_op_pe_interp(const float* pe, int ph, int pw, int C, int gh, int gw, int mode, float* out, cs_stream stream);
 /* fp32 [rows][K] -> fp16 [rows][ldo] (zero padded); row_scale (rows) / col_scale (K) may be NULL: LayerScale folded into the
  * rows of a projection, LayerNorm gamma into its columns */
 /* 1 in *overlap when kernels queued on the two streams run side by side, 0 when the runtime serialises them (streams that share a

@@ -27,6 +27,35 @@ import torch
 Tensor = torch.Tensor
 
 
+def bicubic_resize_grid_align_corners(grid: Tensor, oh: int, ow: int) -> Tensor:
+    """F.interpolate(mode='bicubic', align_corners=True) of a (gh,gw,C) grid: what model/positional_encoding.py:61-69 executes with
+    interpolate_mode=bicubic.  src = dst*(in-1)/(out-1) per axis (aten area_pixel_compute_source_index, align_corners branch), four taps
+    with border-clamped indices, A = -0.75, x first then y (aten upsample_bicubic2d).  Pinned against torch in tests/test_oracle_golden.py."""
+    gh, gw, C = grid.shape
+
+    def axis(n_in: int, n_out: int):
+        scale = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
+        dst = torch.arange(n_out, dtype=torch.float32)
+        src = dst * torch.tensor(scale, dtype=torch.float32)
+        i0 = torch.floor(src)
+        t = src - i0
+        i0 = i0.to(torch.int64)
+        w = _cubic_coeffs(t)
+        idx = [torch.clamp(i0 + d, 0, n_in - 1).to(grid.device) for d in (-1, 0, 1, 2)]
+        return idx, [c.to(grid.device) for c in w]
+
+    iy, wy = axis(gh, oh)
+    ix, wx = axis(gw, ow)
+    out = torch.zeros(oh, ow, C, dtype=grid.dtype, device=grid.device)
+    for a in range(4):
+        rows = grid[iy[a]]
+        acc = torch.zeros(oh, ow, C, dtype=grid.dtype, device=grid.device)
+        for b in range(4):
+            acc = acc + rows[:, ix[b]] * wx[b][None, :, None]
+        out = out + acc * wy[a][:, None, None]
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # primitive restatements
 # --------------------------------------------------------------------------------------------------
@@ -199,11 +228,15 @@ def dinov2_encoder(imgs: Tensor, Wt: Dict[str, Tensor], enc_heads: int, P: int, 
     return layer_norm(x, Wt["backbone.layernorm.weight"], Wt["backbone.layernorm.bias"], 1e-6)
 
 
-def multiview_pe(Wt: Dict[str, Tensor], h: int, w: int) -> Tensor:
-    """(h*w, C) grid added to every view (model/positional_encoding.py:42-75)."""
+def multiview_pe(Wt: Dict[str, Tensor], h: int, w: int, mode: str = "bilinear") -> Tensor:
+    """(h*w, C) grid added to every view (model/positional_encoding.py:42-75); mode = cfg.model.pos_enc.multi_view.interpolate_mode."""
     PE = Wt["pos_enc_fn.PE"][0]  # (pe_h,pe_w,C)
     if PE.shape[0] == h and PE.shape[1] == w:
         return PE.reshape(h * w, -1)
+    if mode == "bicubic":
+        return bicubic_resize_grid_align_corners(PE, h, w).reshape(h * w, -1)
+    if mode != "bilinear":
+        raise ValueError("align_corners option can only be set with the interpolating modes: linear | bilinear | bicubic | trilinear")
     return bilinear_resize_grid_align_corners(PE, h, w).reshape(h * w, -1)
 
 
@@ -319,7 +352,7 @@ def forward(Wt: Dict[str, Tensor], cfg: dict, query_img: Tensor, ref_cross_imgs:
     if taps is not None:
         taps["last_hidden_state"] = hs.clone()
     fm = hs[:, 1:].reshape(B, 1 + N, h * w, -1)
-    pe = multiview_pe(Wt, h, w)
+    pe = multiview_pe(Wt, h, w, c.get("pe_interpolate_mode", "bilinear"))
     fq = fm[:, 0] + pe[None]  # core.py:87
     fr = (fm[:, 1:] + pe[None, None]).reshape(B, N * h * w, -1)  # core.py:93-98
     if taps is not None:

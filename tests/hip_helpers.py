@@ -99,6 +99,15 @@ def pe_bilinear(pe, gh, gw):
     return out
 
 
+def pe_interp(pe, gh, gw, mode):
+    """mode 0 bilinear, 1 bicubic (align_corners=True): model.pos_enc.multi_view.interpolate_mode"""
+    lib = _lib.load()
+    ph, pw, Cc = pe.shape
+    out = torch.zeros((gh * gw, Cc), dtype=torch.float32, device=pe.device)
+    _lib.check(lib.cs_op_pe_interp(_p(pe), ph, pw, Cc, gh, gw, int(mode), _p(out), _stream()))
+    return out
+
+
 def pack_f16(w, ldo=None, row_scale=None, col_scale=None):
     lib = _lib.load()
     rows, K = w.shape

