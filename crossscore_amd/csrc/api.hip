@@ -109,6 +109,8 @@ struct cs_model {
   std::map<std::string, Tensor> w;
   bool finalized = false;
   int Kp = 0;  // padded patch K
+  int qkv_n = 0;  // columns of the encoder's packed QKV projection: 3C, or 3C padded to whole 256-column tiles (zero rows) when that lets the
+                  // large-tile GEMM take it (ViT-S: 1152 -> 1280; measured 47.5 -> 36.9 us per 24-image chunk, r4); attention reads with this stride
   bool panel = false;   // encoder layers run as QKV GEMM + attention + ONE token-panel kernel (panel.hip; hidden == 384 only)
   float *ones = nullptr, *zeros = nullptr;  // [C]: layer 0's norm1 without gamma/beta (they are folded into its QKV projection)
   bool lnfold = false;  // encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass)
@@ -235,7 +237,7 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
   for (int l = 0; l < nsets; ++l) {
     p.x[l] = a.take<float>(Mc * C);
     p.u[l] = a.take<h16_t>(Mc * C);
-    p.r1[l] = a.take<h16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * 3 * C, (size_t)p.Ic * p.Np * m->Kp)));
+    p.r1[l] = a.take<h16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * (size_t)m->qkv_n, (size_t)p.Ic * p.Np * m->Kp)));
     p.ob[l] = a.take<h16_t>(m->lnfold ? Mc * C : 0);
     p.pmean[l] = a.take<float>((size_t)p.Ic * p.Np * 4);
     p.stats[l] = a.take<float>(m->lnfold ? Mc * (size_t)m->ln_sp * 2 : 0);
@@ -415,6 +417,8 @@ cs_handle cs_create(const cs_config* cfg) {
   m->cfg = c;
   m->names = expected_names(c);
   m->Kp = ((3 * c.patch * c.patch + 63) / 64) * 64;
+  // the 256 x 256 x 64-tile GEMM (gemm256.hip) needs whole 256-column tiles and K >= 384 in multiples of 128
+  m->qkv_n = (c.hidden >= 384 && c.hidden % 128 == 0) ? ((3 * c.hidden + 255) / 256) * 256 : 3 * c.hidden;
   m->ln_sp = 4 * cs_gemm_column_tiles(c.hidden);
   // opt-in: measured slower than separate LayerNorm kernels on cfg-2 (kernel-time sum 10.2 vs 9.5 ms: the folded consumers run
   // at the 256-register limit and their tile-switch loads drain the LDS-DMA queue)
@@ -566,7 +570,9 @@ int cs_finalize(cs_handle h) {
     HIPCHK(cs_vec_mul_launch(ob->d, l1->d, bo_s, (int)C, st));
     HIPCHK(cs_vec_mul_launch(f2b->d, l2->d, b2_s, (int)C, st));
     L.bo = bo_s; L.b2 = b2_s; L.ls1 = nullptr; L.ls2 = nullptr;
-    ALLOC_BF(wqkv, (size_t)3 * C * C) ALLOC_F(bqkv, (size_t)3 * C)
+    const size_t NQ = (size_t)h->qkv_n;  // >= 3C: the padding rows of the weights and the padding entries of the bias / fold vectors are zero
+    ALLOC_BF(wqkv, NQ * C) ALLOC_F(bqkv, NQ)
+    if (NQ > 3 * C) { HIPCHK(hipMemset(wqkv + 3 * C * C, 0, (NQ - 3 * C) * C * sizeof(h16_t))); HIPCHK(hipMemset(bqkv + 3 * C, 0, (NQ - 3 * C) * sizeof(float))); }
     const bool fold = h->lnfold || h->panel;
     const float* g1 = fold ? n1w->d : nullptr;  // LayerNorm gamma folded into the columns of the consuming projection
     const float* g2 = fold ? n2w->d : nullptr;
@@ -588,7 +594,8 @@ int cs_finalize(cs_handle h) {
       L.panel_img = img;
     }
     if (fold) {
-      ALLOC_F(sq, (size_t)3 * C) ALLOC_F(cq, (size_t)3 * C) ALLOC_F(s1v, (size_t)F) ALLOC_F(c1v, (size_t)F)
+      ALLOC_F(sq, NQ) ALLOC_F(cq, NQ) ALLOC_F(s1v, (size_t)F) ALLOC_F(c1v, (size_t)F)
+      if (NQ > 3 * C) { HIPCHK(hipMemset(sq + 3 * C, 0, (NQ - 3 * C) * sizeof(float))); HIPCHK(hipMemset(cq + 3 * C, 0, (NQ - 3 * C) * sizeof(float))); }
       const float* wsrc[3] = {qw->d, kw->d, vw->d};
       const float* bsrc[3] = {qb->d, kb->d, vb->d};
       for (int part = 0; part < 3; ++part)
@@ -845,16 +852,17 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       const bool last = l == c.enc_layers - 1;
       CsAttnParams a{};
       a.bf16 = bf;
+      const int NQ = h->qkv_n;  // row stride of the packed QKV rows (3C, or padded to whole 256-column GEMM tiles)
       a.Q = r1; a.K = r1 + C; a.V = r1 + 2 * C;
-      a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
-      a.q_bs = a.k_bs = a.v_bs = (long long)p.T * 3 * C; a.o_bs = (long long)p.T * C;
+      a.ldq = a.ldk = a.ldv = NQ; a.ldo = C;
+      a.q_bs = a.k_bs = a.v_bs = (long long)p.T * NQ; a.o_bs = (long long)p.T * C;
       a.Lq = a.Lk = p.T; a.heads = c.enc_heads; a.scale_log2e = 1.0f;  // folded into the Q rows of Wqkv (cs_finalize)
       a.lse = nullptr;
       if (h->panel) {
         // u = fp16 normalised rows (norm1 without gamma/beta: folded into Wqkv / c_qkv), written by the previous layer's panel
         // kernel; layer 0 gets it from the LayerNorm kernel
         if (l == 0) { L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, h->ones, h->zeros, 1e-6f, nullptr, u, bf, s), "ln1"); L.end(); }
-        L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C), CS_EPI_BIAS_F16);
+        L.gemm(gp(u, C, E.Wqkv, C, Mc, NQ, C, E.c_qkv, r1, NQ), CS_EPI_BIAS_F16);
         a.O = u;
         L.attn(a, enc_dh, ic);
         CsPanelParams q{};
@@ -868,7 +876,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         // u holds fp16(x) and `stats` the per-row partial sums, both written by the epilogue that produced x: LayerNorm is
         // applied inside the consuming projection's epilogue (CS_EPI_LN_*), there is no separate LN pass over x
         {
-          CsGemmParams g = gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.c_qkv, r1, 3 * C);
+          CsGemmParams g = gp(u, C, E.Wqkv, C, Mc, NQ, C, E.c_qkv, r1, NQ);
           g.col_s = E.s_qkv; g.ln_part = stats; g.ln_sp = h->ln_sp; g.ln_eps = 1e-6f;
           L.gemm(g, CS_EPI_LN_F16);
         }
@@ -894,7 +902,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         continue;
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, u, bf, s), "ln1"); L.end();
-      L.gemm(gp(u, C, E.Wqkv, C, Mc, 3 * C, C, E.bqkv, r1, 3 * C), CS_EPI_BIAS_F16);
+      L.gemm(gp(u, C, E.Wqkv, C, Mc, NQ, C, E.bqkv, r1, NQ), CS_EPI_BIAS_F16);
       a.O = u;
       L.attn(a, enc_dh, ic);
       {

@@ -27,6 +27,7 @@
 // through a wave-private LDS patch (inline-asm ds ops: the compiler must not order them against the LDS-DMA in flight) and stores
 // whole 128-byte lines; the bias vector lives in LDS and is the accumulators' initial value.
 #include "cs_common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -450,11 +451,14 @@ int cs_gemm256_debug_read(unsigned long long* dst) { return (int)hipMemcpyFromSy
 void cs_debug_gemm256_enable(int on) { g_enabled = on; }
 
 // Shapes this kernel takes (everything else stays with gemm.hip): whole 256-column tiles, an even number of 64-deep K tiles and
-// K >= 512 (below that a tile's prologue and epilogue outweigh what the larger tile saves), the plain epilogues.
+// K >= 384, the plain epilogues.
 int cs_gemm256_supported(const CsGemmParams* p, int epi) {
   if (!g_enabled) return 0;
   if (epi > CS_EPI_RESID_F32) return 0;
-  if (p->N % G_BN || p->N > G_NLIM || p->K % (2 * G_BK) || p->K < 512 || p->M < G_BM) return 0;
+  // K >= 384 (r4; 512 before): at K = 384 the large tile already wins clearly -- ViT-S QKV (32 880 x 1280 x 384) 36.9 us against 52.9 on the
+  // 128-row kernel (47.5 at the unpadded 1152 columns), tools/qkv_k384_try.py.  The K loop itself takes any even number >= 4 of K tiles.
+  static const int kmin = getenv("CS_G256_KMIN") ? atoi(getenv("CS_G256_KMIN")) : 384;
+  if (p->N % G_BN || p->N > G_NLIM || p->K % (2 * G_BK) || p->K < kmin || p->K < 4 * G_BK || p->M < G_BM) return 0;
   if (p->lda % 8 || p->ldw % 8 || p->ldc % 8) return 0;
   if ((long long)p->M * p->lda * 2 >= (1ll << 32) || (long long)p->N * p->ldw * 2 >= (1ll << 32)) return 0;
   if (epi == CS_EPI_RESID_F32 && p->resid && (p->ldr % 4 || (long long)p->M * p->ldr * 4 >= (1ll << 32))) return 0;
