@@ -99,7 +99,7 @@ def roofline_of(dom):
     return r
 
 
-TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r04_hbm_traffic.json"
 
 
 def pmc_traffic(kernel_name):
@@ -268,7 +268,10 @@ class Workload:
             self.net.lanes = lanes
         if chunk > 0:
             self.net.enc_chunk_images = chunk
-        self.inflight, self._lanes_arg, self.pipe = inflight, lanes, None
+        # batches in flight: 0 = by backbone width -- 3 for ViT-S (measured 1312 vs 1293 q/s with 2 on cfg-2), 2 for the wider ones, whose kernels
+        # fill the chip on their own (cfg-4 458 vs 452 with 3, cfg-3 253 vs 248; r4)
+        self.inflight = inflight if inflight > 0 else (3 if self.arch.hidden <= 384 else 2)
+        self._lanes_arg, self.pipe = lanes, None
         if item_range is None:
             lo = rank * self.B  # weak scaling: rank r scores global items [r*B, (r+1)*B)
             q, r = synth.make_inputs_shard(lo, lo + self.B, self.N, self.H, self.W, seed)
@@ -368,8 +371,8 @@ def main():
                     "kernel run alone, which is how the per-kernel table below is measured")
     ap.add_argument("--chunk", type=int, default=0, help="encoder chunk in images (0 = library default); the per-kernel table uses "
                     "one chunk for the whole batch")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (crossscore_amd.pipeline.ForwardPipeline, the predict "
-                    "driver's batch loop); 1 = one forward at a time with the library's two encoder lanes")
+    ap.add_argument("--inflight", type=int, default=0, help="batches in flight per GPU (crossscore_amd.pipeline.ForwardPipeline, the predict "
+                    "driver's batch loop); 0 = 3 for ViT-S, 2 for wider backbones; 1 = one forward at a time with the library's two encoder lanes")
     ap.add_argument("--dtype", default="fp16", choices=("fp16", "bf16"), help="16-bit MFMA operand type (cs_config.operand_dtype): fp16 is the "
                     "default of the path (score-map MAE 1e-4); bf16 is BASELINE.json's wording for cfg-2 (MAE 8e-4, fp32's range)")
     ap.add_argument("--global-batch", type=int, default=128, help="fixed global batch of the strong-scaling leg (BASELINE.json configs[3]: ViT-B/14, 5 refs, "
@@ -394,8 +397,8 @@ def main():
     torch.cuda.set_device(dev)
     sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
 
-    if args.inflight < 1:
-        raise SystemExit("--inflight must be >= 1")
+    if args.inflight < 0:
+        raise SystemExit("--inflight must be >= 0")
     wl = Workload(args.workload, rank, dev, args.lanes, args.chunk, inflight=args.inflight, dtype=args.dtype)
     net, arch, B, N, H, W = wl.net, wl.arch, wl.B, wl.N, wl.H, wl.W
     # ---- the same workload with ONE batch at a time (no pipeline; the library's two encoder lanes inside the forward): reported beside

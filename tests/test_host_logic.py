@@ -287,10 +287,10 @@ def test_bench_refuses_more_gpus_than_visible():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r03_bench.json is a verbatim bench.py line: the keys the driver and the judge read must be there."""
+    """profiles/r04_bench.json is a verbatim bench.py line: the keys the driver and the judge read must be there."""
     import json
 
-    path = os.path.join(REPO, "profiles", "r03_bench.json")
+    path = os.path.join(REPO, "profiles", "r04_bench.json")
     r = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
@@ -315,3 +315,13 @@ def test_committed_bench_line_follows_the_contract():
     assert len(r["ranks_seen"]) == r["n_gpus"] and {"rank", "local_rank", "device"} <= set(r["ranks_seen"][0])
     assert "backend" in r["process_group"] and r["nonfinite_score_values"] == 0
     assert len(r["value_repeats"]) == 5 and min(r["value_repeats"]) <= r["value_median_of_5"] <= max(r["value_repeats"])
+    # round 4: both 16-bit operand types driver-measured in the same line (BASELINE words cfg-2 "bf16"), the strong-scaling form of
+    # BASELINE configs[3] with every rank's shard, and how long batches were really in flight (HIP events per forward)
+    legs = r["dtype_legs"]
+    assert set(legs) == {"fp16", "bf16"} and legs[r["dtype"]]["value"] == r["value"]
+    assert legs["fp16"]["score_map_mae"] < 2e-4 and legs["bf16"]["score_map_mae"] < 1e-3 and legs["bf16"]["value"] > 0
+    s4 = r["scaling_cfg4"]
+    assert s4["mode"] == "strong" and s4["global_batch"] == 128 and sum(x["items"] for x in s4["ranks_seen"]) == 128
+    assert s4["weak_16_per_gpu"]["mode"] == "weak" and s4["weak_16_per_gpu"]["value"] > 0
+    f = r["batches_in_flight_measured"]
+    assert abs(f["fraction_two_in_flight"] + f["fraction_one_in_flight"] + f["fraction_idle"] - 1.0) < 1e-6 and f["fraction_two_in_flight"] > 0.5
