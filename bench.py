@@ -64,12 +64,13 @@ def algorithmic_flops_per_query(C, L, H, W, N, P=14, dec_layers=2):
 
 def kernel_table(net):
     rows = []
-    for fam in list(range(10)) + [16 + d // 16 for d in (16, 48, 64, 96, 128)] + [40, 41, 32]:
+    for fam in list(range(10)) + [16 + d // 16 for d in (16, 48, 64, 96, 128)] + [40, 41, 42, 32]:
         ms, n, fl = net.profile_read(fam)
         if n == 0:
             continue
         name = (f"cs_gemm_kernel<{GEMM_EPI[fam]}>" if fam < 10 else f"cs_attn_kernel<{(fam - 16) * 16}>" if fam < 32
-                else "cs_panel_kernel" if fam == 40 else "cs_patch_fused_kernel" if fam == 41 else "layernorm/cls/other")
+                else "cs_panel_kernel" if fam == 40 else "cs_patch_fused_kernel" if fam == 41 else "cs_rowln_kernel" if fam == 42
+                else "layernorm/cls/other")
         by = net.profile_read_bytes(fam)
         rows.append(dict(kernel=name, launches=n, total_ms=ms, avg_us=1e3 * ms / n, tflops=(fl / ms / 1e9) if fl else None, flops=fl,
                          gbytes_per_s=(by / ms / 1e6) if by else None, flop_per_byte=(fl / by) if by else None, bytes=by))
@@ -399,6 +400,9 @@ def main():
 
     if args.inflight < 0:
         raise SystemExit("--inflight must be >= 0")
+    if os.environ.get("CS_NO_ROWLN"):  # A/B runs: the decoder's sub-block closings as GEMM + LayerNorm launches again (process-wide debug switch)
+        from crossscore_amd import _lib
+        _lib.load().cs_debug_rowln_enable(0)
     wl = Workload(args.workload, rank, dev, args.lanes, args.chunk, inflight=args.inflight, dtype=args.dtype)
     net, arch, B, N, H, W = wl.net, wl.arch, wl.B, wl.N, wl.H, wl.W
     # ---- the same workload with ONE batch at a time (no pipeline; the library's two encoder lanes inside the forward): reported beside

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrossscore_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip", "patch.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip", "patch.hip", "rowln.hip"]
 
 
 # panel.hip: its GELU arithmetic shares one wave's issue stream with the MFMAs; SLP-packed v_pk_fma_f32 (dependent-issue nops)

@@ -57,6 +57,9 @@ size_t cs_panel_image_bytes(int with_outproj);
 hipError_t cs_panel_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
                                 h16_t* img, int bf16, hipStream_t st);
 const char* cs_panel_check(const CsPanelParams* p);
+int cs_rowln_supported(int C);
+const char* cs_rowln_check(const CsRowLnParams* p, int C);
+hipError_t cs_rowln_launch(const CsRowLnParams* p, int C, int bf16, hipStream_t st);
 hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st);
 hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int oh,
                                 int ow, const float* mean, const float* stdv, float* out, float* scratch, hipStream_t stream);
@@ -65,6 +68,7 @@ hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_
 namespace {
 
 thread_local std::string g_err;
+int g_rowln_off = 0;  // cs_debug_rowln_enable(0): the decoder goes back to GEMM + LayerNorm launches (A/B runs and tests; process-wide)
 int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -307,6 +311,22 @@ struct Launcher {
     hipError_t e = cs_panel_launch(&q, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "panel launch: %s", hipGetErrorString(e)); return false; }
+    return true;
+  }
+  // out = LN(resid + A W^T + bias): the decoder's out-projection / linear2 + residual + LayerNorm in one launch (rowln.hip; C = 384)
+  bool rowln(const h16_t* A, const h16_t* W, const float* bias, const float* resid, const float* gamma, const float* beta, float eps,
+             float* out_f32, h16_t* out_f16, int M) {
+    if (rc) return false;
+    const int C = m->cfg.hidden;
+    CsRowLnParams q{};
+    q.A = A; q.lda = C; q.W = W; q.ldw = C; q.bias = bias; q.resid = resid; q.ldr = C; q.gamma = gamma; q.beta = beta; q.eps = eps;
+    q.out_f32 = out_f32; q.out_f16 = out_f16; q.M = M;
+    if (const char* e = cs_rowln_check(&q, C)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
+    // algorithmic bytes: A and W once, the residual rows in, both forms of the normalised rows out
+    begin(42, 2.0 * M * C * (double)C, 2.0 * M * C + 2.0 * C * C + (resid ? 4.0 : 0.0) * M * C + 6.0 * M * C);
+    hipError_t e = cs_rowln_launch(&q, C, m->cfg.operand_dtype, st);
+    end();
+    if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "linear + LayerNorm launch: %s", hipGetErrorString(e)); return false; }
     return true;
   }
   bool misc(hipError_t e, const char* what) {
@@ -938,6 +958,8 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     float* lse = p.lse + (size_t)b0 * c.dec_heads * p.Np;
     // K/V projection of the memory (both layers at once).  Nothing before the first cross-attention depends on it, so with lanes
     // it runs on lane stream 1 next to layer 0's self-attention branch (the decoder phase has one small kernel in flight otherwise).
+    // each sub-block closes with LN(x + Linear(.)): one launch where the row-complete kernel is built (C = 384), else GEMM + LayerNorm
+    const bool fused_ln = cs_rowln_supported(C) != 0 && !g_rowln_off;
     const bool kv_side = NL >= 2 && c.do_self_attn && !h->prof;
     if (kv_side) {
       if (!h->ev_kv0) { if (hipEventCreateWithFlags(&h->ev_kv0, hipEventDisableTiming) != hipSuccess) L.rc = CS_ERR_HIP; }
@@ -961,10 +983,14 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         a.q_bs = a.k_bs = a.v_bs = (long long)p.Np * 3 * C; a.o_bs = (long long)p.Np * C;
         a.Lq = a.Lk = p.Np; a.heads = c.dec_heads; a.scale_log2e = 1.0f;  // folded into the Q projection (cs_finalize)
         L.attn(a, dec_dh, nb);
-        CsGemmParams g = gp(dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, y, C);
-        g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
-        L.gemm(g, CS_EPI_RESID_F32);
-        L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n1g, D.n1b, 1e-5f, xq, q_bf, bf, s), "norm1"); L.end();
+        if (fused_ln) {
+          L.rowln(dob, D.sa_Wo, D.sa_bo, c.do_short_cut ? xq : nullptr, D.n1g, D.n1b, 1e-5f, xq, q_bf, M);
+        } else {
+          CsGemmParams g = gp(dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, y, C);
+          g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
+          L.gemm(g, CS_EPI_RESID_F32);
+          L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n1g, D.n1b, 1e-5f, xq, q_bf, bf, s), "norm1"); L.end();
+        }
       }
       if (kv_side && l == 0 && !L.rc && hipStreamWaitEvent(s, h->ev_kv1, 0) != hipSuccess) L.rc = CS_ERR_HIP;
       L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_F16);
@@ -982,19 +1008,23 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.misc(cs_attn_weights_launch(&a, dec_dh, nb, head_id, attn_out + (size_t)b0 * p.Np * N * p.Np, s), "attn_weights");
         L.end();
       }
-      {
+      if (fused_ln) {
+        L.rowln(dob, D.ca_Wo, D.ca_bo, c.do_short_cut ? xq : nullptr, D.n2g, D.n2b, 1e-5f, xq, q_bf, M);
+      } else {
         CsGemmParams g = gp(dob, C, D.ca_Wo, C, M, C, C, D.ca_bo, y, C);
         g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
+        L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n2g, D.n2b, 1e-5f, xq, q_bf, bf, s), "norm2"); L.end();
       }
-      L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n2g, D.n2b, 1e-5f, xq, q_bf, bf, s), "norm2"); L.end();
       L.gemm(gp(q_bf, C, D.l1W, C, M, C, C, D.l1b, dhid, C), CS_EPI_BIAS_RELU_F16);
-      {
+      if (fused_ln) {
+        L.rowln(dhid, D.l2W, D.l2b, xq, D.n3g, D.n3b, 1e-5f, xq, q_bf, M);
+      } else {
         CsGemmParams g = gp(dhid, C, D.l2W, C, M, C, C, D.l2b, y, C);
         g.resid = xq; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
+        L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n3g, D.n3b, 1e-5f, xq, q_bf, bf, s), "norm3"); L.end();
       }
-      L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n3g, D.n3b, 1e-5f, xq, q_bf, bf, s), "norm3"); L.end();
       // tap: decoder layer l's output (transformer.py:157-173)
       if (h->capture && !L.rc)
         L.rc = tap_copy(h, "dec" + std::to_string(l) + "_out", xq, ro * C * 4, (size_t)M * C * 4, (size_t)B * p.Np * C * 4, 0, {B, p.Np, C}, s);
@@ -1207,6 +1237,19 @@ int cs_nonfinite_count(cs_handle h, long long* count) {
 // single-op entry points
 // ---------------------------------------------------------------------------------------------------------
 static int g_op_bf16 = 0;  // operand type of the cs_op_* entry points below (a handle carries its own: cs_config.operand_dtype)
+void cs_debug_rowln_enable(int on) { g_rowln_off = on ? 0 : 1; }
+
+// out_f32 / out_f16 (M, C) = LayerNorm(resid + A (M, C) W (C, C)^T + bias): the decoder's sub-block closing as the forward runs it (C = 384)
+int cs_op_linear_layernorm(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, const float* gamma, const float* beta,
+                           float eps, float* out_f32, uint16_t* out_f16, int M, int C, cs_stream stream) {
+  CsRowLnParams q{};
+  q.A = A; q.lda = C; q.W = W; q.ldw = C; q.bias = bias; q.resid = resid; q.ldr = C; q.gamma = gamma; q.beta = beta; q.eps = eps;
+  q.out_f32 = out_f32; q.out_f16 = out_f16; q.M = M;
+  if (const char* e = cs_rowln_check(&q, C)) return fail(CS_ERR_BAD_ARG, "%s", e);
+  HIPCHK(cs_rowln_launch(&q, C, g_op_bf16, (hipStream_t)stream));
+  return 0;
+}
+
 int cs_debug_set_op_operand_dtype(int dtype) {
   if (dtype != 0 && dtype != 1) return fail(CS_ERR_BAD_ARG, "operand dtype must be 0 (fp16) or 1 (bf16)");
   g_op_bf16 = dtype;

@@ -203,3 +203,14 @@ struct CsPanelParams {
   float eps;               // LayerNorm eps (1e-6 in DINOv2)
   int bf16;                // operand type of attn_o, img, the hidden slices and u_out: 0 IEEE half, 1 bfloat16
 };
+
+// Decoder linear + residual + LayerNorm in one launch (rowln.hip): out = LN(resid + A W^T + bias), K = N = C
+struct CsRowLnParams {
+  const h16_t* A; int lda;      // [M][lda] 16-bit activations, K = C contiguous
+  const h16_t* W; int ldw;      // [C][ldw] 16-bit weights (nn.Linear layout)
+  const float* bias;            // [C]
+  const float* resid; int ldr;  // [M][ldr] fp32 or null (no short cut)
+  const float* gamma; const float* beta; float eps;
+  float* out_f32; h16_t* out_f16;  // [M][C] each (out_f32 may alias resid: a lane reads exactly the elements it writes)
+  int M;
+};

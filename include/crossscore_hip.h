@@ -148,7 +148,7 @@ int cs_debug_read(cs_handle h, const char* name, void* dst, size_t dst_bytes, in
 
 /* Per-kernel-family timing with HIP events on the launch stream (for bench.py's roofline object).
  * Families = kernel symbols: 0..9 cs_gemm_kernel<epilogue> (either GEMM kernel), 16 + dh/16 cs_attn_kernel<dh>, 40 cs_panel_kernel,
- * 41 cs_patch_fused_kernel, 32 everything else (LayerNorm, im2col, CLS rows, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */
+ * 41 cs_patch_fused_kernel, 42 cs_rowln_kernel, 32 everything else (LayerNorm, im2col, CLS rows, tables).  `flops` = algorithmic FLOPs (2*M*N*K, 4*B*H*Lq*Lk*dh).  Two events per launch. */
 int cs_profile_enable(cs_handle h, int on);
 int cs_profile_read(cs_handle h, int family, double* total_ms, int* launches, double* flops);
 /* algorithmic HBM bytes (operands and results once each) of the recorded launches of one family */
@@ -239,6 +239,13 @@ int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, c
  * 256 and M >= 256 run on the 256 x 256 x 64-tile kernel (csrc/gemm256.hip), everything else on the 128-row kernel (csrc/gemm.hip);
  * 0 = the 128-row kernel for every shape.  The two kernels add the same products in the same order: their results are bit-identical (tested). */
 void cs_debug_gemm256_enable(int on);
+/* The decoder's sub-block closing  x = LN(x + Linear(y))  (model/customised_transformer/transformer.py:157-173) in one launch (csrc/rowln.hip;
+ * K = N = C = 384: the ViT-S decoder): out_f32 / out_f16 (M, C) = LayerNorm(resid + A W^T + bias; gamma, beta, eps); resid may be NULL
+ * (decoder_do_short_cut off) and may alias out_f32.  CS_ERR_BAD_ARG for other widths (the forward then runs GEMM + LayerNorm).
+ * cs_debug_rowln_enable(0): process-wide debug switch back to the two-launch form (see cs_debug_* above). */
+int cs_op_linear_layernorm(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, const float* gamma, const float* beta,
+                           float eps, float* out_f32, uint16_t* out_f16, int M, int C, cs_stream stream);
+void cs_debug_rowln_enable(int on);
 /* number of column tiles the GEMM launcher uses for N output columns (LayerNorm partial-sum slots per row = 4 x this) */
 int cs_gemm_column_tiles(int N);
 

@@ -99,6 +99,16 @@ def pe_bilinear(pe, gh, gw):
     return out
 
 
+def linear_layernorm(A, W, bias, resid, gamma, beta, eps, want_f32=True, want_f16=True):
+    """LN(resid + A W^T + bias) in one launch (csrc/rowln.hip): A (M,C) fp16, W (C,C) fp16 -> (out_f32, out_f16)"""
+    lib = _lib.load()
+    M, Cc = A.shape
+    of = torch.zeros((M, Cc), dtype=torch.float32, device=A.device) if want_f32 else None
+    oh = torch.zeros((M, Cc), dtype=torch.float16, device=A.device) if want_f16 else None
+    _lib.check(lib.cs_op_linear_layernorm(_p(A), _p(W), _p(bias), _p(resid), _p(gamma), _p(beta), eps, _p(of), _p(oh), M, Cc, _stream()))
+    return of, oh
+
+
 def pe_interp(pe, gh, gw, mode):
     """mode 0 bilinear, 1 bicubic (align_corners=True): model.pos_enc.multi_view.interpolate_mode"""
     lib = _lib.load()

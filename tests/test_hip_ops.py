@@ -619,6 +619,44 @@ def test_attention_rejects_unsupported_head_dim():
         hh.attention(Q, Q, Q, 1, 32)
 
 
+# ------------------------------------------------------------------------------- linear + residual + LayerNorm in one launch
+@pytest.mark.parametrize("M,with_resid", [(1369, True), (64, True), (65, False), (10952, True), (7, True)])
+def test_linear_layernorm_one_launch(M, with_resid):
+    """csrc/rowln.hip: LN(x + y W^T + b) as the post-norm decoder layer closes its sub-blocks (transformer.py:157-173; without x when
+    decoder_do_short_cut is off), against fp32 torch on the same fp16 operands, and against the two-launch form of the forward (GEMM with the
+    fp32 residual epilogue, then the LayerNorm kernel): same operands, fp32 accumulation in another order."""
+    g = _rng(M + 3)
+    Cc = 384
+    A = _bf(_t(g.standard_normal((M, Cc), dtype=np.float32)))
+    W = _bf(_t(g.standard_normal((Cc, Cc), dtype=np.float32) / math.sqrt(Cc)))
+    b = _t(g.standard_normal((Cc,), dtype=np.float32))
+    res = _t(2.0 * g.standard_normal((M, Cc), dtype=np.float32)) if with_resid else None
+    if res is not None:
+        res[:, 5] += 30.0  # an outlier channel
+    gam = _t(1.0 + 0.3 * g.standard_normal((Cc,), dtype=np.float32))
+    bet = _t(0.2 * g.standard_normal((Cc,), dtype=np.float32))
+    of, oh = hh.linear_layernorm(A, W, b, res, gam, bet, 1e-5)
+    pre = A.float() @ W.float().t() + b + (res if res is not None else 0.0)
+    ref = torch.nn.functional.layer_norm(pre.double(), (Cc,), gam.double(), bet.double(), 1e-5).float()
+    torch.cuda.synchronize()
+    assert (of - ref).abs().max() < 2e-4, float((of - ref).abs().max())  # fp32 accumulation and statistics: order-of-summation noise only
+    e16 = (oh.float() - ref).abs()
+    assert (e16 <= 6e-4 * ref.abs() + 2.5e-4).all(), float((e16 - 6e-4 * ref.abs()).max())  # + one fp16 rounding (half an ulp = 4.9e-4 relative; the outlier channel reaches |12|)
+    y = hh.gemm(A, W, b, _lib.EPI_RESID_F32, resid=res)
+    of2, oh2 = hh.layernorm(y, gam, bet, 1e-5)
+    torch.cuda.synchronize()
+    assert (of - of2).abs().max() < 2e-4
+    # in place on the residual stream, as the forward calls it
+    if res is not None:
+        r2 = res.clone()
+        lib = _lib.load()
+        _lib.check(lib.cs_op_linear_layernorm(hh._p(A), hh._p(W), hh._p(b), hh._p(r2), hh._p(gam), hh._p(bet), 1e-5, hh._p(r2), None, M, Cc, hh._stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(r2, of)
+    with pytest.raises(ValueError):
+        hh.linear_layernorm(A[:, :256].contiguous(), W[:256, :256].contiguous(), b[:256], None, gam[:256], bet[:256], 1e-5)
+
+
 # ------------------------------------------------------------------------------- LayerNorm & position tables
 @pytest.mark.parametrize("M,Cc,eps", [(1370, 384, 1e-6), (77, 768, 1e-5), (5, 128, 1e-6)])
 def test_layernorm(M, Cc, eps):

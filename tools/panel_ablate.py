@@ -82,7 +82,7 @@ tmp = tempfile.mkdtemp(prefix="panel_abl_")
 pkg = os.path.join(tmp, "crossscore_amd")
 shutil.copytree(os.path.join(R, "crossscore_amd"), pkg, ignore=shutil.ignore_patterns("*.so", "build", "__pycache__"))
 shutil.copytree(os.path.join(R, "include"), os.path.join(tmp, "include"))
-srcs = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip", "patch.hip"]
+srcs = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip", "patch.hip", "rowln.hip"]
 objs = []
 procs = []
 for s in srcs:
