@@ -400,9 +400,9 @@ def main():
 
     if args.inflight < 0:
         raise SystemExit("--inflight must be >= 0")
-    if os.environ.get("CS_NO_ROWLN"):  # A/B runs: the decoder's sub-block closings as GEMM + LayerNorm launches again (process-wide debug switch)
-        from crossscore_amd import _lib
-        _lib.load().cs_debug_rowln_enable(0)
+    if os.environ.get("CS_NO_ROWLN"):  # A/B runs (process-wide debug switch): 1 = the decoder's sub-block closings as GEMM + LayerNorm + GEMM
+        from crossscore_amd import _lib  # launches again; 2 = linear + LayerNorm in one launch, the next linear as a GEMM of its own
+        _lib.load().cs_debug_rowln_enable(2 if os.environ["CS_NO_ROWLN"] == "2" else 0)
     wl = Workload(args.workload, rank, dev, args.lanes, args.chunk, inflight=args.inflight, dtype=args.dtype)
     net, arch, B, N, H, W = wl.net, wl.arch, wl.B, wl.N, wl.H, wl.W
     # ---- the same workload with ONE batch at a time (no pipeline; the library's two encoder lanes inside the forward): reported beside

@@ -75,6 +75,7 @@ SYMBOLS = {
     "cs_panel_image_bytes": (_sz, [_i]),
     "cs_op_panel_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cs_op_linear_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]),
+    "cs_op_linear_layernorm_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "cs_debug_rowln_enable": (None, [_i]),
     "cs_op_encoder_panel": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
 }

@@ -69,6 +69,7 @@ namespace {
 
 thread_local std::string g_err;
 int g_rowln_off = 0;  // cs_debug_rowln_enable(0): the decoder goes back to GEMM + LayerNorm launches (A/B runs and tests; process-wide)
+int g_rowln_no_next = 0;  // cs_debug_rowln_enable(2): linear + LayerNorm in one launch, the following linear as a GEMM of its own (round 4's first form)
 int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -261,6 +262,9 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
 }
 
 // launch helpers that record profiling events when enabled
+// the optional second stage of Launcher::rowln: the sub-block's following linear, out (M, n) = act(LN rows x W^T + b)
+struct NextLinear { const h16_t* W = nullptr; const float* b = nullptr; h16_t* out = nullptr; int n = 0, act = 0; };
+
 struct Launcher {
   cs_model* m; hipStream_t st; int rc = 0;
   int bpc = 0;  // GEMM blocks per CU hint (CsGemmParams::bpc)
@@ -315,15 +319,17 @@ struct Launcher {
   }
   // out = LN(resid + A W^T + bias): the decoder's out-projection / linear2 + residual + LayerNorm in one launch (rowln.hip; C = 384)
   bool rowln(const h16_t* A, const h16_t* W, const float* bias, const float* resid, const float* gamma, const float* beta, float eps,
-             float* out_f32, h16_t* out_f16, int M) {
+             float* out_f32, h16_t* out_f16, int M, NextLinear next = NextLinear{}) {
     if (rc) return false;
     const int C = m->cfg.hidden;
     CsRowLnParams q{};
     q.A = A; q.lda = C; q.W = W; q.ldw = C; q.bias = bias; q.resid = resid; q.ldr = C; q.gamma = gamma; q.beta = beta; q.eps = eps;
     q.out_f32 = out_f32; q.out_f16 = out_f16; q.M = M;
+    q.W2 = next.W; q.ldw2 = C; q.bias2 = next.b; q.out2 = next.out; q.ld2 = next.n; q.n2 = next.n; q.act2 = next.act;
     if (const char* e = cs_rowln_check(&q, C)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
-    // algorithmic bytes: A and W once, the residual rows in, both forms of the normalised rows out
-    begin(42, 2.0 * M * C * (double)C, 2.0 * M * C + 2.0 * C * C + (resid ? 4.0 : 0.0) * M * C + 6.0 * M * C);
+    // algorithmic bytes: A and W once, the residual rows in, the normalised rows out (fp32, and 16-bit where asked); second stage: W2 in, rows out
+    begin(42, 2.0 * M * C * (double)(C + next.n),
+          2.0 * M * C + 2.0 * C * C + (resid ? 4.0 : 0.0) * M * C + (out_f32 ? 4.0 : 0.0) * M * C + (out_f16 ? 2.0 : 0.0) * M * C + 2.0 * next.n * C + 2.0 * M * next.n);
     hipError_t e = cs_rowln_launch(&q, C, m->cfg.operand_dtype, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "linear + LayerNorm launch: %s", hipGetErrorString(e)); return false; }
@@ -960,6 +966,15 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     // it runs on lane stream 1 next to layer 0's self-attention branch (the decoder phase has one small kernel in flight otherwise).
     // each sub-block closes with LN(x + Linear(.)): one launch where the row-complete kernel is built (C = 384), else GEMM + LayerNorm
     const bool fused_ln = cs_rowln_supported(C) != 0 && !g_rowln_off;
+    // ... and where it is, the sub-block's NEXT linear rides in the same launch when it is C wide (second stage of rowln.hip): the
+    // cross-attention's Q projection behind norm1, linear1 + ReLU behind norm2, the head's first linear + LeakyReLU behind the last
+    // norm3 -- 16 launches per decoder + head instead of 21, at the same kernel time (34.5 vs 33.3 us per pair at 10 952 rows).  The next
+    // layer's packed QKV projection (3 C wide) stays a GEMM of its own: in this kernel's 64-row shape it costs 62.5 us against 45.7.
+    // The flags say which projection is already there.
+    const bool fuse_next = fused_ln && !g_rowln_no_next;
+    using NL_t = NextLinear;
+    auto next_of = [&](const h16_t* W, const float* b, h16_t* out, int n, int act) { NL_t x; x.W = W; x.b = b; x.out = out; x.n = n; x.act = act; return x; };
+    bool have_q = false, have_hid = false, have_head0 = false;
     const bool kv_side = NL >= 2 && c.do_self_attn && !h->prof;
     if (kv_side) {
       if (!h->ev_kv0) { if (hipEventCreateWithFlags(&h->ev_kv0, hipEventDisableTiming) != hipSuccess) L.rc = CS_ERR_HIP; }
@@ -974,6 +989,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     }
     for (int l = 0; l < c.dec_layers; ++l) {
       const DecLayer& D = h->dec[l];
+      const bool last_l = l == c.dec_layers - 1;
       if (c.do_self_attn) {
         L.gemm(gp(q_bf, C, D.sa_Win, C, M, 3 * C, C, D.sa_bin, dqkv, 3 * C), CS_EPI_BIAS_F16);
         CsAttnParams a{};
@@ -984,7 +1000,12 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         a.Lq = a.Lk = p.Np; a.heads = c.dec_heads; a.scale_log2e = 1.0f;  // folded into the Q projection (cs_finalize)
         L.attn(a, dec_dh, nb);
         if (fused_ln) {
-          L.rowln(dob, D.sa_Wo, D.sa_bo, c.do_short_cut ? xq : nullptr, D.n1g, D.n1b, 1e-5f, xq, q_bf, M);
+          if (fuse_next) {
+            L.rowln(dob, D.sa_Wo, D.sa_bo, c.do_short_cut ? xq : nullptr, D.n1g, D.n1b, 1e-5f, xq, nullptr, M, next_of(D.ca_Wq, D.ca_bq, dq, (int)C, 0));
+            have_q = true;
+          } else {
+            L.rowln(dob, D.sa_Wo, D.sa_bo, c.do_short_cut ? xq : nullptr, D.n1g, D.n1b, 1e-5f, xq, q_bf, M);
+          }
         } else {
           CsGemmParams g = gp(dob, C, D.sa_Wo, C, M, C, C, D.sa_bo, y, C);
           g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
@@ -993,7 +1014,8 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         }
       }
       if (kv_side && l == 0 && !L.rc && hipStreamWaitEvent(s, h->ev_kv1, 0) != hipSuccess) L.rc = CS_ERR_HIP;
-      L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_F16);
+      if (!have_q) L.gemm(gp(q_bf, C, D.ca_Wq, C, M, C, C, D.ca_bq, dq, C), CS_EPI_BIAS_F16);
+      have_q = false;
       CsAttnParams a{};
       a.bf16 = bf;
       a.Q = dq; a.K = kv + (size_t)l * 2 * C; a.V = kv + (size_t)l * 2 * C + C; a.O = dob;
@@ -1009,16 +1031,32 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.end();
       }
       if (fused_ln) {
-        L.rowln(dob, D.ca_Wo, D.ca_bo, c.do_short_cut ? xq : nullptr, D.n2g, D.n2b, 1e-5f, xq, q_bf, M);
+        if (fuse_next) {
+          L.rowln(dob, D.ca_Wo, D.ca_bo, c.do_short_cut ? xq : nullptr, D.n2g, D.n2b, 1e-5f, xq, nullptr, M, next_of(D.l1W, D.l1b, dhid, (int)C, 1));
+          have_hid = true;
+        } else {
+          L.rowln(dob, D.ca_Wo, D.ca_bo, c.do_short_cut ? xq : nullptr, D.n2g, D.n2b, 1e-5f, xq, q_bf, M);
+        }
       } else {
         CsGemmParams g = gp(dob, C, D.ca_Wo, C, M, C, C, D.ca_bo, y, C);
         g.resid = c.do_short_cut ? xq : nullptr; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
         L.begin(32, 0); L.misc(cs_layernorm_launch(y, M, C, D.n2g, D.n2b, 1e-5f, xq, q_bf, bf, s), "norm2"); L.end();
       }
-      L.gemm(gp(q_bf, C, D.l1W, C, M, C, C, D.l1b, dhid, C), CS_EPI_BIAS_RELU_F16);
+      if (!have_hid) L.gemm(gp(q_bf, C, D.l1W, C, M, C, C, D.l1b, dhid, C), CS_EPI_BIAS_RELU_F16);
+      have_hid = false;
       if (fused_ln) {
-        L.rowln(dhid, D.l2W, D.l2b, xq, D.n3g, D.n3b, 1e-5f, xq, q_bf, M);
+        if (fuse_next && last_l) {
+          // (the head's hidden rows replace linear1's in dhid: a workgroup writes exactly the 64 rows it staged into LDS at its start)
+          L.rowln(dhid, D.l2W, D.l2b, xq, D.n3g, D.n3b, 1e-5f, xq, nullptr, M, next_of(h->Wh0, h->bh0, dhid, (int)C, 2));
+          have_head0 = true;
+        } else if (fuse_next && !c.do_self_attn) {
+          const DecLayer& Dn = h->dec[l + 1];
+          L.rowln(dhid, D.l2W, D.l2b, xq, D.n3g, D.n3b, 1e-5f, xq, nullptr, M, next_of(Dn.ca_Wq, Dn.ca_bq, dq, (int)C, 0));
+          have_q = true;
+        } else {
+          L.rowln(dhid, D.l2W, D.l2b, xq, D.n3g, D.n3b, 1e-5f, xq, q_bf, M);
+        }
       } else {
         CsGemmParams g = gp(dhid, C, D.l2W, C, M, C, C, D.l2b, y, C);
         g.resid = xq; g.ldr = C;
@@ -1030,7 +1068,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.rc = tap_copy(h, "dec" + std::to_string(l) + "_out", xq, ro * C * 4, (size_t)M * C * 4, (size_t)B * p.Np * C * 4, 0, {B, p.Np, C}, s);
     }
     // head + RegressionLayer + jigsaw (cross_reference.py:45-50,82-87)
-    L.gemm(gp(q_bf, C, h->Wh0, C, M, C, C, h->bh0, dhid, C), CS_EPI_BIAS_LEAKY_F16);
+    if (!have_head0) L.gemm(gp(q_bf, C, h->Wh0, C, M, C, C, h->bh0, dhid, C), CS_EPI_BIAS_LEAKY_F16);
     {
       CsGemmParams g = gp(dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4);
       g.Np = p.Np; g.gw = p.gw; g.P = P; g.act = c.act; g.powp = c.pow_p;
@@ -1237,7 +1275,7 @@ int cs_nonfinite_count(cs_handle h, long long* count) {
 // single-op entry points
 // ---------------------------------------------------------------------------------------------------------
 static int g_op_bf16 = 0;  // operand type of the cs_op_* entry points below (a handle carries its own: cs_config.operand_dtype)
-void cs_debug_rowln_enable(int on) { g_rowln_off = on ? 0 : 1; }
+void cs_debug_rowln_enable(int on) { g_rowln_off = on == 0 ? 1 : 0; g_rowln_no_next = on == 2 ? 1 : 0; }
 
 // out_f32 / out_f16 (M, C) = LayerNorm(resid + A (M, C) W (C, C)^T + bias): the decoder's sub-block closing as the forward runs it (C = 384)
 int cs_op_linear_layernorm(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, const float* gamma, const float* beta,
@@ -1245,6 +1283,20 @@ int cs_op_linear_layernorm(const uint16_t* A, const uint16_t* W, const float* bi
   CsRowLnParams q{};
   q.A = A; q.lda = C; q.W = W; q.ldw = C; q.bias = bias; q.resid = resid; q.ldr = C; q.gamma = gamma; q.beta = beta; q.eps = eps;
   q.out_f32 = out_f32; q.out_f16 = out_f16; q.M = M;
+  if (const char* e = cs_rowln_check(&q, C)) return fail(CS_ERR_BAD_ARG, "%s", e);
+  HIPCHK(cs_rowln_launch(&q, C, g_op_bf16, (hipStream_t)stream));
+  return 0;
+}
+
+// the same with the sub-block's next linear behind it: out2 (M, n2) = act2(LN rows (rounded to the operand type) x W2 (n2, C)^T + bias2)
+int cs_op_linear_layernorm_linear(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, const float* gamma,
+                                  const float* beta, float eps, float* out_f32, uint16_t* out_f16, const uint16_t* W2, const float* bias2,
+                                  int n2, int act2, uint16_t* out2, int M, int C, cs_stream stream) {
+  CsRowLnParams q{};
+  q.A = A; q.lda = C; q.W = W; q.ldw = C; q.bias = bias; q.resid = resid; q.ldr = C; q.gamma = gamma; q.beta = beta; q.eps = eps;
+  q.out_f32 = out_f32; q.out_f16 = out_f16; q.M = M;
+  q.W2 = W2; q.ldw2 = C; q.bias2 = bias2; q.out2 = out2; q.ld2 = n2; q.n2 = n2; q.act2 = act2;
+  if (n2 <= 0) return fail(CS_ERR_BAD_ARG, "linear + LayerNorm + linear: n2 must be positive");
   if (const char* e = cs_rowln_check(&q, C)) return fail(CS_ERR_BAD_ARG, "%s", e);
   HIPCHK(cs_rowln_launch(&q, C, g_op_bf16, (hipStream_t)stream));
   return 0;

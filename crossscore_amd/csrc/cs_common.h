@@ -213,4 +213,10 @@ struct CsRowLnParams {
   const float* gamma; const float* beta; float eps;
   float* out_f32; h16_t* out_f16;  // [M][C] each (out_f32 may alias resid: a lane reads exactly the elements it writes)
   int M;
+  // optional second stage: out2 = act2(LN rows (16-bit) x W2^T + bias2), n2 a multiple of C (the sub-block's NEXT linear: the cross-attention's
+  // Q projection, linear1 + ReLU, the next layer's packed QKV projection, the head's first linear + LeakyReLU); n2 = 0: none
+  const h16_t* W2; int ldw2;    // [n2][ldw2]
+  const float* bias2;           // [n2]
+  h16_t* out2; int ld2;         // [M][ld2]
+  int n2, act2;                 // act2: 0 none, 1 ReLU, 2 LeakyReLU(0.01)
 };

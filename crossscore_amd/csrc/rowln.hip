@@ -10,6 +10,10 @@
 // the wave and one with the other waves (LDS, 2 x C/96 x 64 floats).  Both operands come straight from L2 / L1 as 16-byte per-lane loads
 // (every 128-byte line is used by four consecutive k-steps): the kernel moves 0.3 MB of weights per workgroup and is latency-, not
 // bandwidth-bound -- 172 workgroups for the 10 952 rows of cfg-2, one round.
+// Second stage (G2 > 0): the sub-block's NEXT linear in the same launch -- out2 = act2(LN rows x W2^T + bias2) for G2 groups of C output
+// columns (the cross-attention's Q projection, transformer.py:195-205; linear1 + ReLU, :208-210; the head's first linear + LeakyReLU,
+// cross_reference.py:45-50).  The normalised rows, rounded to the operand type as a separate GEMM would read them, replace the activation rows
+// in LDS and the K loop runs again.
 #include "cs_common.h"
 
 namespace {
@@ -19,9 +23,10 @@ __device__ __forceinline__ float rl_add_other_half(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int C, bool BF>
+template <int C, bool BF, int G2>  // G2: column groups of C outputs of the second stage (0: none)
 __global__ __launch_bounds__(C / 96 * 64) void cs_rowln_kernel(CsRowLnParams p) {
   constexpr int NW = C / 96, NT = NW * 64;
+  constexpr bool NEXT = G2 > 0;
   constexpr int BK = 64, NSL = C / BK;          // K slices of the weight stream
   constexpr int APITCH = C * 2 + 16;            // bytes; odd multiples of 16: ds_read_b128 of 32 different rows is conflict free
   constexpr int WPITCH = BK * 2 + 16;
@@ -42,17 +47,17 @@ __global__ __launch_bounds__(C / 96 * 64) void cs_rowln_kernel(CsRowLnParams p) 
   // ---- staging: coalesced 16-byte loads (8 consecutive threads per 128-byte row segment), register staged (issue early, write late) ----
   // (macros, not lambdas: with the register arrays captured by reference hipcc kept them in scratch memory -- 144 scratch instructions, 37 us)
   uint4 wreg[WIT];
-#define RL_LOAD_W(SL)                                                                                          \
+#define RL_LOAD_W(REG, WP, LDW, SL)                                                                                \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                         \
     const int c_ = tid + it * NT, r_ = c_ / WCH, ch_ = c_ - r_ * WCH;                                          \
-    wreg[it] = *reinterpret_cast<const uint4*>(p.W + (size_t)r_ * p.ldw + (SL) * BK + ch_ * 8);                \
+    REG[it] = *reinterpret_cast<const uint4*>((WP) + (size_t)r_ * (LDW) + (SL) * BK + ch_ * 8);                \
   }
-#define RL_WRITE_W(BUF)                                                                                        \
+#define RL_WRITE_W(REG, BUF)                                                                                   \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                         \
     const int c_ = tid + it * NT, r_ = c_ / WCH, ch_ = c_ - r_ * WCH;                                          \
-    *reinterpret_cast<uint4*>(Ws + (BUF) * WBUF + r_ * WPITCH + ch_ * 16) = wreg[it];                          \
+    *reinterpret_cast<uint4*>(Ws + (BUF) * WBUF + r_ * WPITCH + ch_ * 16) = REG[it];                           \
   }
-  RL_LOAD_W(0)
+  RL_LOAD_W(wreg, p.W, p.ldw, 0)
   {
     uint4 areg[AIT];
 #pragma unroll
@@ -66,7 +71,16 @@ __global__ __launch_bounds__(C / 96 * 64) void cs_rowln_kernel(CsRowLnParams p) 
       *reinterpret_cast<uint4*>(As + r * APITCH + ch * 16) = areg[it];
     }
   }
-  RL_WRITE_W(0)
+#define RL_KSLICE(SLICE)                                                                                       \
+  _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                     \
+    h16x8_t a[2], w[3];                                                                                        \
+    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                                           \
+      a[rb] = *reinterpret_cast<const h16x8_t*>(a_rd + rb * 32 * APITCH + ((SLICE) * (BK / 16) + ks) * 32);    \
+    _Pragma("unroll") for (int ct = 0; ct < 3; ++ct) w[ct] = *reinterpret_cast<const h16x8_t*>(w_rd + ct * 32 * WPITCH + ks * 32); \
+    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                                           \
+      _Pragma("unroll") for (int ct = 0; ct < 3; ++ct) acc[rb][ct] = mfma_32x32x16<BF>(w[ct], a[rb], acc[rb][ct]); \
+  }
+  RL_WRITE_W(wreg, 0)
   __syncthreads();
   f32x16_t acc[2][3];
 #pragma unroll
@@ -77,21 +91,10 @@ __global__ __launch_bounds__(C / 96 * 64) void cs_rowln_kernel(CsRowLnParams p) 
       for (int e = 0; e < 16; ++e) acc[rb][ct][e] = 0.f;
   const char* a_rd = As + j * APITCH + h * 16;                         // + rb * 32 * APITCH + k-step * 32
   for (int sl = 0; sl < NSL; ++sl) {
-    if (sl + 1 < NSL) { RL_LOAD_W(sl + 1) }
+    if (sl + 1 < NSL) { RL_LOAD_W(wreg, p.W, p.ldw, sl + 1) }
     const char* w_rd = Ws + (sl & 1) * WBUF + (col0 + j) * WPITCH + h * 16;  // + ct * 32 * WPITCH + k-step * 32
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      h16x8_t a[2], w[3];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) a[rb] = *reinterpret_cast<const h16x8_t*>(a_rd + rb * 32 * APITCH + (sl * (BK / 16) + ks) * 32);
-#pragma unroll
-      for (int ct = 0; ct < 3; ++ct) w[ct] = *reinterpret_cast<const h16x8_t*>(w_rd + ct * 32 * WPITCH + ks * 32);
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct) acc[rb][ct] = mfma_32x32x16<BF>(w[ct], a[rb], acc[rb][ct]);
-    }
-    if (sl + 1 < NSL) { RL_WRITE_W((sl + 1) & 1) }
+    RL_KSLICE(sl)
+    if (sl + 1 < NSL) { RL_WRITE_W(wreg, (sl + 1) & 1) }
     __syncthreads();
   }
   // ---- epilogue.  Register e of tile ct of this lane = feature col0 + 32 ct + (e & 3) + 8 (e >> 2) + 4 h of row (row0 + 32 rb + j):
@@ -185,6 +188,83 @@ __global__ __launch_bounds__(C / 96 * 64) void cs_rowln_kernel(CsRowLnParams p) 
         }
     }
   }
+  if constexpr (NEXT) {
+    // ---- second stage: the normalised rows (rounded to the operand type, exactly what a separate GEMM would read from out_f16) replace the
+    //      activation rows in LDS -- every wave is past its last read of them (the K loop's closing barrier) -- and feed the sub-block's
+    //      next linear: n2 / C column groups of C outputs, the same K loop per group, bias + activation, 16-bit rows out ----
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      char* arow = As + (32 * rb + j) * APITCH + (col0 + 4 * h) * 2;
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float y[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = (acc[rb][ct][4 * g + i] - mean[rb]) * rstd[rb] * gam[ct][g][i] + bet[ct][g][i];
+          uint2 o;
+          o.x = pack_o16x2<BF>(y[0], y[1]);
+          o.y = pack_o16x2<BF>(y[2], y[3]);
+          *reinterpret_cast<uint2*>(arow + (32 * ct + 8 * g) * 2) = o;
+        }
+    }
+    // (the first weight slice is loaded here, not before the LayerNorm where it would travel under it: issued there, hipcc kept the staging
+    //  array in scratch memory -- 84 scratch instructions)
+    RL_LOAD_W(wreg, p.W2, p.ldw2, 0)
+    RL_WRITE_W(wreg, 0)
+    __syncthreads();
+    constexpr int nsl2 = G2 * NSL;
+#pragma unroll
+    for (int s2 = 0; s2 < nsl2; ++s2) {
+      const int grp = s2 / NSL, sl = s2 - grp * NSL;
+      if (sl == 0) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rb][ct][e] = 0.f;
+      }
+      if (s2 + 1 < nsl2) {
+        const int g2 = (s2 + 1) / NSL, sn = (s2 + 1) - g2 * NSL;
+        RL_LOAD_W(wreg, p.W2 + (size_t)g2 * C * p.ldw2, p.ldw2, sn)
+      }
+      const char* w_rd = Ws + (s2 & 1) * WBUF + (col0 + j) * WPITCH + h * 16;
+      RL_KSLICE(sl)
+      if (s2 + 1 < nsl2) { RL_WRITE_W(wreg, (s2 + 1) & 1) }
+      __syncthreads();
+      if (sl == NSL - 1) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int row = row0 + 32 * rb + j;
+          if (row < p.M) {
+            h16_t* o2 = p.out2 + (size_t)row * p.ld2 + grp * C + col0 + 4 * h;
+            const float* b2 = p.bias2 + grp * C + col0 + 4 * h;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(b2 + 32 * ct + 8 * g);
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  v[i] = acc[rb][ct][4 * g + i] + b4[i];
+                  if (p.act2 == 1) v[i] = fmaxf(v[i], 0.f);
+                  if (p.act2 == 2) v[i] = v[i] >= 0.f ? v[i] : 0.01f * v[i];
+                }
+                uint2 o;
+                o.x = pack_o16x2<BF>(v[0], v[1]);
+                o.y = pack_o16x2<BF>(v[2], v[3]);
+                *reinterpret_cast<uint2*>(o2 + 32 * ct + 8 * g) = o;
+              }
+          }
+        }
+      }
+    }
+  }
+#undef RL_KSLICE
+#undef RL_LOAD_W
+#undef RL_WRITE_W
 }
 
 }  // namespace
@@ -193,7 +273,13 @@ extern "C" int cs_rowln_supported(int C) { return C == 384; }
 
 extern "C" const char* cs_rowln_check(const CsRowLnParams* p, int C) {
   if (!cs_rowln_supported(C)) return "linear + LayerNorm: built for C = 384";
-  if (!p->A || !p->W || !p->bias || !p->gamma || !p->beta || (!p->out_f32 && !p->out_f16)) return "linear + LayerNorm: null operand";
+  if (!p->A || !p->W || !p->bias || !p->gamma || !p->beta || (!p->out_f32 && !p->out_f16 && !p->n2)) return "linear + LayerNorm: null operand";
+  if (p->n2) {
+    if ((p->n2 != C && p->n2 != 3 * C) || p->act2 < 0 || p->act2 > 2) return "linear + LayerNorm: the second stage takes C or 3 C output columns and act2 in 0..2";
+    if (!p->W2 || !p->bias2 || !p->out2) return "linear + LayerNorm: null operand (second stage)";
+    if (p->ldw2 % 8 || p->ldw2 < C || p->ld2 % 4 || p->ld2 < p->n2) return "linear + LayerNorm: row strides must keep 16-byte rows (second stage)";
+    if (((uintptr_t)p->W2 | (uintptr_t)p->bias2) & 15 || ((uintptr_t)p->out2 & 7)) return "linear + LayerNorm: operands must be 16-byte aligned (second stage)";
+  }
   if (p->M <= 0) return "linear + LayerNorm: empty shape";
   if (p->lda % 8 || p->ldw % 8 || p->lda < C || p->ldw < C || (p->resid && (p->ldr % 4 || p->ldr < C))) return "linear + LayerNorm: row strides must keep 16-byte rows";
   if (((uintptr_t)p->A | (uintptr_t)p->W | (uintptr_t)p->bias | (uintptr_t)p->gamma | (uintptr_t)p->beta | (uintptr_t)p->resid | (uintptr_t)p->out_f32 |
@@ -210,13 +296,20 @@ extern "C" hipError_t cs_rowln_launch(const CsRowLnParams* p, int C, int bf16, h
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_rowln_kernel<384, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_rowln_kernel<384, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
+    const void* fns[6] = {reinterpret_cast<const void*>(cs_rowln_kernel<384, true, 0>), reinterpret_cast<const void*>(cs_rowln_kernel<384, false, 0>),
+                          reinterpret_cast<const void*>(cs_rowln_kernel<384, true, 1>), reinterpret_cast<const void*>(cs_rowln_kernel<384, false, 1>),
+                          reinterpret_cast<const void*>(cs_rowln_kernel<384, true, 3>), reinterpret_cast<const void*>(cs_rowln_kernel<384, false, 3>)};
+    for (const void* f : fns)
+      if (hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds); e != hipSuccess) return e;
     attr_done[dev] = true;
   }
   const dim3 grid((p->M + 63) / 64), block(NW * 64);
-  if (bf16) hipLaunchKernelGGL((cs_rowln_kernel<384, true>), grid, block, lds, st, *p);
-  else hipLaunchKernelGGL((cs_rowln_kernel<384, false>), grid, block, lds, st, *p);
+#define RL_GO(G) do { if (bf16) hipLaunchKernelGGL((cs_rowln_kernel<384, true, G>), grid, block, lds, st, *p);  \
+                      else hipLaunchKernelGGL((cs_rowln_kernel<384, false, G>), grid, block, lds, st, *p); } while (0)
+  if (p->n2 == 0) RL_GO(0);
+  else if (p->n2 == CC) RL_GO(1);
+  else if (p->n2 == 3 * CC) RL_GO(3);
+  else return hipErrorInvalidValue;
+#undef RL_GO
   return hipGetLastError();
 }

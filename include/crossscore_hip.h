@@ -245,6 +245,16 @@ void cs_debug_gemm256_enable(int on);
  * cs_debug_rowln_enable(0): process-wide debug switch back to the two-launch form (see cs_debug_* above). */
 int cs_op_linear_layernorm(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, const float* gamma, const float* beta,
                            float eps, float* out_f32, uint16_t* out_f16, int M, int C, cs_stream stream);
+/* ... and with the sub-block's NEXT linear in the same launch (the forward's default where C = 384 for the C-wide ones: the cross-attention's
+ * Q projection behind norm1, linear1 + ReLU behind norm2, the head's first linear + LeakyReLU behind the last norm3; the 3 C-wide form, the next
+ * layer's packed QKV projection, is built and tested but measured slower than a GEMM of its own, so the forward does not use it;
+ * transformer.py:157-173,182-210, cross_reference.py:45-50): out2 (M, n2) = act2(LN rows, rounded to the operand type, x W2 (n2, C)^T + bias2),
+ * n2 = C or 3 C, act2 0 none / 1 ReLU / 2 LeakyReLU(0.01).  out_f32 / out_f16 may be NULL when only out2 is wanted; out2 may alias A (a
+ * workgroup writes the 64 rows it read at its start). */
+int cs_op_linear_layernorm_linear(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, const float* gamma,
+                                  const float* beta, float eps, float* out_f32, uint16_t* out_f16, const uint16_t* W2, const float* bias2,
+                                  int n2, int act2, uint16_t* out2, int M, int C, cs_stream stream);
+/* 1 (default): both fusions; 2: linear + LayerNorm in one launch, the next linear as a GEMM of its own; 0: GEMM + LayerNorm + GEMM */
 void cs_debug_rowln_enable(int on);
 /* number of column tiles the GEMM launcher uses for N output columns (LayerNorm partial-sum slots per row = 4 x this) */
 int cs_gemm_column_tiles(int N);

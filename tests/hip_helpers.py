@@ -109,6 +109,19 @@ def linear_layernorm(A, W, bias, resid, gamma, beta, eps, want_f32=True, want_f1
     return of, oh
 
 
+def linear_layernorm_linear(A, W, bias, resid, gamma, beta, eps, W2, bias2, act2, want_f32=True, want_f16=False, out2=None):
+    """the same with the sub-block's next linear in the launch: -> (out_f32, out_f16, out2 (M, n2) fp16); out2 may be A itself"""
+    lib = _lib.load()
+    M, Cc = A.shape
+    n2 = W2.shape[0]
+    of = torch.zeros((M, Cc), dtype=torch.float32, device=A.device) if want_f32 else None
+    oh = torch.zeros((M, Cc), dtype=torch.float16, device=A.device) if want_f16 else None
+    o2 = torch.zeros((M, n2), dtype=torch.float16, device=A.device) if out2 is None else out2
+    _lib.check(lib.cs_op_linear_layernorm_linear(_p(A), _p(W), _p(bias), _p(resid), _p(gamma), _p(beta), eps, _p(of), _p(oh), _p(W2), _p(bias2),
+                                                 n2, int(act2), _p(o2), M, Cc, _stream()))
+    return of, oh, o2
+
+
 def pe_interp(pe, gh, gw, mode):
     """mode 0 bilinear, 1 bicubic (align_corners=True): model.pos_enc.multi_view.interpolate_mode"""
     lib = _lib.load()

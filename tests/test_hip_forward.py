@@ -346,8 +346,8 @@ def test_fp16_overflow_is_reported_and_bf16_mode_survives():
 
 
 def test_decoder_fused_linear_layernorm_matches_two_launch_form():
-    """ViT-S width: the decoder closes its sub-blocks with ONE launch each (linear + residual + LayerNorm, csrc/rowln.hip) instead of a GEMM and
-    a LayerNorm launch.  Same operands and fp32 arithmetic in another summation order; the normalised rows are then rounded to fp16 for the next
+    """ViT-S width: the decoder closes its sub-blocks with ONE launch each (linear + residual + LayerNorm + the sub-block's next linear,
+    csrc/rowln.hip) instead of a GEMM, a LayerNorm launch and another GEMM; all three forms of the forward are compared.  Same operands and fp32 arithmetic in another summation order; the normalised rows are then rounded to fp16 for the next
     projection, where a last-bit difference becomes one fp16 ulp (5e-4 relative) of an activation: the score maps of the two forms agree to
     1e-3 max / 1e-4 mean (measured 3.1e-4 / 4e-5), and both hold the oracle bound; with decoder_do_short_cut off (no residual into the LayerNorm) as well."""
     from crossscore_amd import _lib
@@ -357,14 +357,17 @@ def test_decoder_fused_linear_layernorm_matches_two_launch_form():
         q, r = synth.make_inputs(1, 2, 126, 154, 5)
         tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
         fused = net(tq, tr, False, 0, False)["score_map_ref_cross"].clone()
-        lib.cs_debug_rowln_enable(0)
         try:
+            lib.cs_debug_rowln_enable(2)  # linear + LayerNorm in one launch, the next linear as a GEMM of its own
+            mid = net(tq, tr, False, 0, False)["score_map_ref_cross"].clone()
+            lib.cs_debug_rowln_enable(0)  # GEMM + LayerNorm + GEMM
             two = net(tq, tr, False, 0, False)["score_map_ref_cross"].clone()
         finally:
             lib.cs_debug_rowln_enable(1)
         torch.cuda.synchronize()
-        d = (fused - two).abs()
-        assert float(d.max()) < 1e-3 and float(d.mean()) < 1e-4, (over, float(d.max()), float(d.mean()))
+        for other in (mid, two):
+            d = (fused - other).abs()
+            assert float(d.max()) < 1e-3 and float(d.mean()) < 1e-4, (over, float(d.max()), float(d.mean()))
         cfgover = {k.replace("decoder_", ""): v for k, v in over.items()}
         ref = _oracle(arch, sd, q, r, **cfgover)["score_map_ref_cross"]
         mae, mx = _compare(fused, ref)

@@ -657,6 +657,49 @@ def test_linear_layernorm_one_launch(M, with_resid):
         hh.linear_layernorm(A[:, :256].contiguous(), W[:256, :256].contiguous(), b[:256], None, gam[:256], bet[:256], 1e-5)
 
 
+@pytest.mark.parametrize("M,n2,act2", [(1369, 384, 0), (1369, 384, 1), (200, 384, 2), (1369, 1152, 0), (65, 1152, 0), (10952, 384, 1)])
+def test_linear_layernorm_linear_one_launch(M, n2, act2):
+    """The second stage of csrc/rowln.hip: the sub-block's NEXT linear in the same launch (the cross-attention's Q projection behind norm1,
+    linear1 + ReLU behind norm2, the next layer's packed QKV projection / the head's first linear + LeakyReLU behind norm3;
+    transformer.py:157-210, cross_reference.py:45-50).  Its input is the normalised rows rounded to fp16 -- exactly what the separate GEMM
+    reads -- so the reference is built from the one-launch LayerNorm's own fp16 rows: fp32 torch on those and, as the forward's other form,
+    the GEMM kernel with the matching epilogue."""
+    g = _rng(M + n2 + act2)
+    Cc = 384
+    A = _bf(_t(g.standard_normal((M, Cc), dtype=np.float32)))
+    W = _bf(_t(g.standard_normal((Cc, Cc), dtype=np.float32) / math.sqrt(Cc)))
+    b = _t(g.standard_normal((Cc,), dtype=np.float32))
+    res = _t(2.0 * g.standard_normal((M, Cc), dtype=np.float32))
+    gam = _t(1.0 + 0.3 * g.standard_normal((Cc,), dtype=np.float32))
+    bet = _t(0.2 * g.standard_normal((Cc,), dtype=np.float32))
+    W2 = _bf(_t(g.standard_normal((n2, Cc), dtype=np.float32) / math.sqrt(Cc)))
+    b2 = _t(0.5 * g.standard_normal((n2,), dtype=np.float32))
+    of1, oh1 = hh.linear_layernorm(A, W, b, res, gam, bet, 1e-5)
+    of, oh, o2 = hh.linear_layernorm_linear(A, W, b, res, gam, bet, 1e-5, W2, b2, act2, want_f32=True, want_f16=True)
+    torch.cuda.synchronize()
+    assert torch.equal(of, of1) and torch.equal(oh, oh1)  # the first stage is the same code
+    pre = oh.float() @ W2.float().t() + b2
+    ref = {0: pre, 1: torch.relu(pre), 2: torch.nn.functional.leaky_relu(pre, 0.01)}[act2]
+    e = (o2.float() - ref).abs()
+    assert (e <= 6e-4 * ref.abs() + 1e-4).all(), float((e - 6e-4 * ref.abs()).max())  # fp32 accumulation order + one fp16 rounding
+    epi = {0: _lib.EPI_BIAS_F16, 1: _lib.EPI_BIAS_RELU_F16, 2: _lib.EPI_BIAS_LEAKY_F16}[act2]
+    two = hh.gemm(oh, W2, b2, epi)
+    torch.cuda.synchronize()
+    d = (o2.float() - two.float()).abs()
+    assert (d <= 1.1e-3 * ref.abs() + 1e-4).all(), float(d.max())  # at most one fp16 ulp apart
+    assert float((d > 0).float().mean()) < 0.05                      # and almost everywhere identical
+    # only the second output, written over the first stage's input rows (the forward's last sub-block: the head's hidden rows replace linear1's)
+    if n2 == Cc:
+        A2 = A.clone()
+        _, _, o3 = hh.linear_layernorm_linear(A2, W, b, res, gam, bet, 1e-5, W2, b2, act2, want_f32=False, want_f16=False, out2=A2)
+        torch.cuda.synchronize()
+        assert o3 is A2 and torch.equal(A2, o2)
+    with pytest.raises(ValueError):
+        hh.linear_layernorm_linear(A, W, b, res, gam, bet, 1e-5, W2[:200].contiguous(), b2[:200], 0)
+    with pytest.raises(ValueError):
+        hh.linear_layernorm_linear(A, W, b, res, gam, bet, 1e-5, W2, b2, 3)
+
+
 # ------------------------------------------------------------------------------- LayerNorm & position tables
 @pytest.mark.parametrize("M,Cc,eps", [(1370, 384, 1e-6), (77, 768, 1e-5), (5, 128, 1e-6)])
 def test_layernorm(M, Cc, eps):

@@ -27,3 +27,15 @@ def two():
     _lib.check(lib.cs_op_layernorm(hh._p(y), M, C, hh._p(gam), hh._p(bet), 1e-5, hh._p(of), hh._p(oh), hh._stream()))
 print(f"fused: {t(fused):.1f} us; without residual {t(lambda: fused(None)):.1f}; fp32 out only {t(lambda: fused(res, of, None)):.1f}; fp16 out only {t(lambda: fused(res, None, oh)):.1f}")
 print(f"GEMM (fp32 residual epilogue) + LayerNorm: {t(two):.1f} us")
+# second stage: the sub-block's next linear in the same launch (n2 = C: Q projection / linear1 / head; n2 = 3 C: the next layer's QKV)
+for n2, act in ((C, 1), (3 * C, 0)):
+    W2 = (torch.randn(n2, C, generator=g) / math.sqrt(C)).to(dev).half(); b2 = torch.randn(n2, generator=g).to(dev)
+    o2 = torch.zeros((M, n2), dtype=torch.float16, device=dev)
+    epi = _lib.EPI_BIAS_RELU_F16 if act == 1 else _lib.EPI_BIAS_F16
+    def three():
+        _lib.check(lib.cs_op_linear_layernorm_linear(hh._p(A), hh._p(W), hh._p(b), hh._p(res), hh._p(gam), hh._p(bet), 1e-5, hh._p(of), None,
+                                                     hh._p(W2), hh._p(b2), n2, act, hh._p(o2), M, C, hh._stream()))
+    def two_b():
+        fused(res, of, oh)
+        hh.gemm(oh, W2, b2, epi, out=o2)
+    print(f"n2 = {n2}: linear + LayerNorm + linear in one launch {t(three):.1f} us; linear + LayerNorm, then the GEMM {t(two_b):.1f} us")
