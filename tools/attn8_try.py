@@ -36,7 +36,7 @@ if os.environ.get("CS_ATTN_CHILD"):
 import shutil, tempfile
 sys.path.insert(0, R)
 from crossscore_amd import build
-roots = [("four-wave", R, "0"), ("eight-wave", R, "1")]
+roots = [("four-wave", R, "0")] + ([("eight-wave", R, "1")] if os.environ.get("CS_ATTN_TRY8") else [])
 for var in [v for v in os.environ.get("CS_ATTN_VARIANTS", "").split(",") if v]:
     tmp = tempfile.mkdtemp(prefix="attn_var_")
     pkg = os.path.join(tmp, "crossscore_amd")
