@@ -33,13 +33,15 @@ for var in [None] + [v for v in os.environ.get("CS_PANEL_VARIANTS", "").split(",
         pkg = os.path.join(tmp, "crossscore_amd")
         shutil.copytree(os.path.join(R, "crossscore_amd"), pkg, ignore=shutil.ignore_patterns("*.so", "build", "__pycache__"))
         shutil.copytree(os.path.join(R, "include"), os.path.join(tmp, "include"))
-        if var.startswith("file:"):  # another version of the kernel's source (e.g. last round's, exported to tools/_ab/) instead of macros
-            shutil.copy(os.path.join(R, var[5:]), os.path.join(pkg, "csrc", "panel.hip"))
+        defs = var.split("+")
+        if var.startswith("file:"):  # another version of the kernel's source (e.g. last round's, exported to tools/_ab/), optionally "+MACRO+.."
+            shutil.copy(os.path.join(R, defs[0][5:]), os.path.join(pkg, "csrc", "panel.hip"))
+            defs = defs[1:]
         objs, procs = [], []
         for s in build.SOURCES:
             o = os.path.join(tmp, s + ".o"); objs.append(o)
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + build.EXTRA_FLAGS.get(s, [])
-            if s == "panel.hip" and not var.startswith("file:"): cmd += ["-DCS_PANEL_" + d for d in var.split("+")]
+            if s == "panel.hip": cmd += ["-DCS_PANEL_" + d for d in defs]
             procs.append(subprocess.Popen(cmd + ["-c", os.path.join(pkg, "csrc", s), "-o", o]))
         for pr in procs: assert pr.wait() == 0
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(pkg, "libcrossscore_hip.so")] + objs)
