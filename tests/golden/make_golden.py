@@ -68,7 +68,7 @@ def make_cfg(arch: synth.ArchSpec, **over):
         decoder_do_self_attn=over.get("do_self_attn", True), decoder_do_short_cut=over.get("do_short_cut", True),
         need_attn_weights=False, need_attn_weights_head_id=0,
         backbone=NS(from_pretrained=arch.name),
-        pos_enc=NS(multi_view=NS(interpolate_mode="bilinear", req_grad=False, h=arch.pe_h, w=arch.pe_w)),
+        pos_enc=NS(multi_view=NS(interpolate_mode=over.get("pe_interpolate_mode", "bilinear"), req_grad=False, h=arch.pe_h, w=arch.pe_w)),
         predict=NS(metric=metric),
     )
     return NS(model=model)
@@ -210,6 +210,26 @@ def main():
         np.savez_compressed(os.path.join(HERE, "g6_pos_legacy.npz"), seed=31, input_seed=6, B=1, N=2, H=75, W=90,
                             score=out["score_map_ref_cross"].numpy(), last_hidden_state=lhs.numpy(), **res)
         print("g6 done", out["score_map_ref_cross"].shape, sorted(k for k in res if k.endswith("_rows")))
+
+    # G7: model.pos_enc.multi_view.interpolate_mode = bicubic (positional_encoding.py:61-69 passes the key to F.interpolate, align_corners=True):
+    # tiny net at 75x90 (5x6 patch grid != 40x40: the resize is live), the reference's score map and its featmaps behind the PE.
+    if want("g7"):
+        _patch_backbone(DC, DM, tiny)
+        net = core.CrossScoreNet(make_cfg(tiny, pe_interpolate_mode="bicubic")).eval()
+        sd = synth.make_state_dict(tiny, 13)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        q, r = synth.make_inputs(2, 2, 75, 90, 13)
+        taps = {}
+        hk = net.ref_cross.attn.layers[0].register_forward_pre_hook(
+            lambda m, a, k: (taps.__setitem__("featmap_query", (a[0] if a else k["tgt"]).detach().numpy().copy()),
+                             taps.__setitem__("featmap_ref", (a[1] if len(a) > 1 else k["memory"]).detach().numpy().copy()))[0] and None,
+            with_kwargs=True)
+        with torch.no_grad():
+            out = net(torch.from_numpy(q), torch.from_numpy(r), False, 0, False)
+        hk.remove()
+        np.savez_compressed(os.path.join(HERE, "g7_tiny_pe_bicubic.npz"), seed=13, B=2, N=2, H=75, W=90,
+                            score=out["score_map_ref_cross"].numpy(), **taps)
+        print("g7 done", out["score_map_ref_cross"].shape, {k: v.shape for k, v in taps.items()})
 
     def big(name, arch, seed, B, N, H, W):
         _, out, dt = run_reference(core, DC, DM, arch, seed, B, N, H, W)

@@ -385,6 +385,11 @@ def test_multiview_pe_bicubic_mode_end_to_end():
     ref = _oracle(arch, sd, q, r, pe_interpolate_mode="bicubic")["score_map_ref_cross"]
     mae, mx = _compare(out, ref)
     assert mae < MAE_TOL and mx < MAX_TOL, (mae, mx)
+    # the same run by the reference itself (tests/golden/make_golden.py --only g7: same seed, shapes and mode)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_tiny_pe_bicubic.npz"))
+    assert int(g["seed"]) == 13 and (int(g["B"]), int(g["N"]), int(g["H"]), int(g["W"])) == (2, 2, 75, 90)
+    mae_g, mx_g = _compare(out, torch.from_numpy(g["score"]))
+    assert mae_g < MAE_TOL and mx_g < MAX_TOL, (mae_g, mx_g)
     ref_bil = _oracle(arch, sd, q, r)["score_map_ref_cross"]
     assert float((ref - ref_bil).abs().mean()) > 3 * mae
     with pytest.raises(ValueError, match="align_corners"):

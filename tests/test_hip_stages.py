@@ -122,6 +122,20 @@ def test_legacy_pos_embed_last_hidden_state_golden():
     _check("featmap_ref", "g6 featmap_ref", net.debug_read("featmap_ref"), (lhs[:, 1:, 1:] + pe[None, None]).reshape(B, N * pe.shape[0], -1))
 
 
+def test_bicubic_pe_mode_featmaps_match_the_reference():
+    """g7: the reference run with model.pos_enc.multi_view.interpolate_mode = bicubic (positional_encoding.py:61-69); its featmaps behind the
+    PE against the HIP path's taps in that mode (pe_bicubic_ac_kernel), same bounds as the bilinear default's."""
+    g = np.load(os.path.join(GOLD, "g7_tiny_pe_bicubic.npz"))
+    net, sd = _net(int(g["seed"]), **{"pos_enc.multi_view.interpolate_mode": "bicubic"})
+    net.debug_capture(True)
+    q, r = synth.make_inputs(int(g["B"]), int(g["N"]), int(g["H"]), int(g["W"]), int(g["seed"]))
+    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    _check("featmap_query", "g7 featmap_query", net.debug_read("featmap_query"), g["featmap_query"])
+    _check("featmap_ref", "g7 featmap_ref", net.debug_read("featmap_ref"), g["featmap_ref"])
+    assert (out.cpu() - torch.from_numpy(g["score"])).abs().max() < 1e-3
+
+
 def test_bf16_stages_stay_within_the_bf16_budget():
     """The same taps with bfloat16 operands (8 significant bits: 8x the fp16 rounding step)."""
     g = np.load(os.path.join(GOLD, "g0_tiny_all.npz"))

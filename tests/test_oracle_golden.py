@@ -61,6 +61,24 @@ def test_g5_flag_variants(golden_dir, name):
     assert np.abs(out["score_map_ref_cross"].numpy() - g[name]).max() < TOL
 
 
+def test_g7_multiview_pe_bicubic_mode(golden_dir):
+    """model.pos_enc.multi_view.interpolate_mode = bicubic, run by the REFERENCE (positional_encoding.py:61-69 hands the key to F.interpolate
+    with align_corners=True): its score map and the featmaps behind the PE pin the oracle's own bicubic restatement
+    (bicubic_resize_grid_align_corners) end to end, next to the F.interpolate comparison below."""
+    g = _golden(golden_dir, "g7_tiny_pe_bicubic.npz")
+    W = orc.to_torch(synth.make_state_dict(TINY, int(g["seed"])))
+    q, r = synth.make_inputs(int(g["B"]), int(g["N"]), int(g["H"]), int(g["W"]), int(g["seed"]))
+    taps = {}
+    out = orc.forward(W, dict(enc_heads=TINY.enc_heads, pe_interpolate_mode="bicubic"), torch.from_numpy(q), torch.from_numpy(r), taps=taps)
+    for k in ("featmap_query", "featmap_ref"):
+        assert np.abs(taps[k].numpy() - g[k]).max() < TOL, k
+    assert np.abs(out["score_map_ref_cross"].numpy() - g["score"]).max() < TOL
+    # and the mode matters: the bilinear default is measurably different on these featmaps
+    taps_bil = {}
+    orc.forward(W, dict(enc_heads=TINY.enc_heads), torch.from_numpy(q), torch.from_numpy(r), taps=taps_bil)
+    assert np.abs(taps_bil["featmap_query"].numpy() - g["featmap_query"]).max() > 100 * TOL
+
+
 def _compact_check(g, score):
     P = 14
     B, Hs, Ws = score.shape
