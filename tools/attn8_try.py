@@ -36,7 +36,7 @@ if os.environ.get("CS_ATTN_CHILD"):
 import shutil, tempfile
 sys.path.insert(0, R)
 from crossscore_amd import build
-roots = [("four-wave", R, "0")] + ([("eight-wave", R, "1")] if os.environ.get("CS_ATTN_TRY8") else [])
+roots = [("four-wave", R, "0")] + ([("eight-wave", R, "1")] if os.environ.get("CS_ATTN_TRY8") else []) + ([("pipelined", R, "pipe")] if os.environ.get("CS_ATTN_TRYPIPE") else [])
 for var in [v for v in os.environ.get("CS_ATTN_VARIANTS", "").split(",") if v]:
     tmp = tempfile.mkdtemp(prefix="attn_var_")
     pkg = os.path.join(tmp, "crossscore_amd")
@@ -53,4 +53,5 @@ for var in [v for v in os.environ.get("CS_ATTN_VARIANTS", "").split(",") if v]:
     roots.append(("four-wave+" + var, tmp, "0"))
 for rep in range(2):
     for label, root, e in roots:
-        subprocess.call([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, CS_ATTN_CHILD=root, CS_ATTN8=e, CS_ATTN_LABEL=label))
+        extra = {"CS_ATTN8": "0", "CS_ATTN_PIPE": "1"} if e == "pipe" else {"CS_ATTN8": e}
+        subprocess.call([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, CS_ATTN_CHILD=root, CS_ATTN_LABEL=label, **extra))
