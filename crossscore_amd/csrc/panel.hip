@@ -113,6 +113,79 @@ __device__ __forceinline__ float gelu_erf_b(float x, GeluMid m) {
   return x * fmaf(m.c, q, 0.5f);
 }
 
+// ---- packed-half GELU (fp16 operand mode, r5).  The fc1 accumulators are rounded to half FIRST -- the tensor the reference's own
+//      `16-mixed` run hands to its GELU (config/default_predict.yaml:25; HF modeling_dinov2.py:293-297 under autocast) -- and two values
+//      travel through every instruction (v_pk_*_f16): 11 instructions per PAIR behind the conversion instead of 11.5 per value.
+//      A plain Horner form of Phi in x^2 cannot be evaluated in half precision (terms of magnitude 6 cancel to 0.1 at |x| = 4: 1e-2 of error),
+//      so the polynomial runs in a variable in which GELU's correction term is a well-conditioned bump:
+//          GELU(x) = relu(x) - |x| Phi(-|x|),    d = clamp(1 - |x| / 4, 0, 1),   z = d^2 - 1/2,   -|x| Phi(-|x|) ~ P6(z)
+//      (|x| >= 4: z = -1/2, P6 = -1.3e-4, GELU = relu to 1.3e-4; the reflection about |x| = 4 is smooth to 1e-5, so even powers of d suffice;
+//      sum |c_k| 2^-k = 0.76 against a bump of height 0.17: next to no cancellation).  Fit 8.2e-5 (minimax on [0, 4]); as evaluated in half arithmetic, coefficients rounded to half:
+//      rms 2.6e-4 for x ~ N(0, 1) against 2.1e-4 of exact-GELU-of-the-rounded-input-rounded (the reference's own arithmetic) and 1.4e-4 of a
+//      lone output rounding; max 2.1e-3 at |y| = 2.3 (one ulp there); score-map MAE 0.994e-4 against 0.977e-4 with an exact GELU in the oracle's
+//      fp16-operand emulation (tools/gelu_pk16_fit.py writes the coefficients and these numbers).
+//      relu, |x| and the clamp are exact; +-inf and values beyond half range behave as relu; the clamp modifier turns a NaN into 0. ----
+struct PkGeluK { unsigned nk, c5, c4, c3, c2, c1, c0, vc6; };
+__device__ __forceinline__ PkGeluK pk_gelu_consts() {  // seven SGPRs and one VGPR for the whole MLP phase (VOP3P reads one SGPR per instruction)
+  PkGeluK k;
+  asm volatile("s_mov_b32 %0, 0xb400b400" : "=s"(k.nk));   // -1/4
+  asm volatile("s_mov_b32 %0, 0xbd76bd76" : "=s"(k.c5));   // -1.365234375
+  asm volatile("s_mov_b32 %0, 0xb8a3b8a3" : "=s"(k.c4));   // -0.57958984375
+  asm volatile("s_mov_b32 %0, 0x3e8a3e8a" : "=s"(k.c3));   //  1.634765625
+  asm volatile("s_mov_b32 %0, 0x394a394a" : "=s"(k.c2));   //  0.6611328125
+  asm volatile("s_mov_b32 %0, 0xb52cb52c" : "=s"(k.c1));   // -0.3232421875
+  asm volatile("s_mov_b32 %0, 0xb086b086" : "=s"(k.c0));   // -0.141357421875
+  asm volatile("v_mov_b32 %0, 0x3a443a44" : "=v"(k.vc6));  //  0.783203125
+  return k;
+}
+// Two pairs travel together through six asm blocks of (up to) four instructions: [stage s of pair 0, stage s of pair 1, stage s + 1 of
+// pair 0, stage s + 1 of pair 1] -- a dependent instruction never follows its producer directly, and hipcc (which assumes a partial-dword
+// write behind every inline-asm result and puts an s_nop between two asm statements that hand a register on) sees one statement per MFMA gap.
+//   stages: 0 t = |x|   1 t = clamp(1 - t/4)   2 t = t t - 1/2   3 q = c6 t + c5   4..8 q = q t + c4..c0   9 r = max(x, 0)   10 x = q + r
+struct PkGelu { unsigned t0, t1, q0, q1, r0, r1; };
+template <int B>
+__device__ __forceinline__ void pk_gelu_block(PkGelu& g, unsigned& x0, unsigned& x1, const PkGeluK& k) {
+  if constexpr (B == 0)
+    asm("v_pk_max_f16 %0, %2, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_max_f16 %1, %3, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f16 %0, %0, %4, 1.0 op_sel_hi:[1,1,0] clamp\n\t"
+        "v_pk_fma_f16 %1, %1, %4, 1.0 op_sel_hi:[1,1,0] clamp"
+        : "=&v"(g.t0), "=&v"(g.t1) : "v"(x0), "v"(x1), "s"(k.nk));
+  else if constexpr (B == 1)
+    asm("v_pk_fma_f16 %0, %0, %0, -0.5 op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f16 %1, %1, %1, -0.5 op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f16 %2, %0, %4, %5\n\t"
+        "v_pk_fma_f16 %3, %1, %4, %5"
+        : "+v"(g.t0), "+v"(g.t1), "=&v"(g.q0), "=&v"(g.q1) : "v"(k.vc6), "s"(k.c5));
+  else if constexpr (B == 2)
+    asm("v_pk_fma_f16 %0, %0, %2, %4\n\t"
+        "v_pk_fma_f16 %1, %1, %3, %4\n\t"
+        "v_pk_fma_f16 %0, %0, %2, %5\n\t"
+        "v_pk_fma_f16 %1, %1, %3, %5"
+        : "+v"(g.q0), "+v"(g.q1) : "v"(g.t0), "v"(g.t1), "s"(k.c4), "s"(k.c3));
+  else if constexpr (B == 3)
+    asm("v_pk_fma_f16 %0, %0, %2, %4\n\t"
+        "v_pk_fma_f16 %1, %1, %3, %4\n\t"
+        "v_pk_fma_f16 %0, %0, %2, %5\n\t"
+        "v_pk_fma_f16 %1, %1, %3, %5"
+        : "+v"(g.q0), "+v"(g.q1) : "v"(g.t0), "v"(g.t1), "s"(k.c2), "s"(k.c1));
+  else if constexpr (B == 4)
+    asm("v_pk_fma_f16 %0, %0, %4, %6\n\t"
+        "v_pk_fma_f16 %1, %1, %5, %6\n\t"
+        "v_pk_max_f16 %2, %7, 0 op_sel_hi:[1,0]\n\t"
+        "v_pk_max_f16 %3, %8, 0 op_sel_hi:[1,0]"
+        : "+v"(g.q0), "+v"(g.q1), "=&v"(g.r0), "=&v"(g.r1) : "v"(g.t0), "v"(g.t1), "s"(k.c0), "v"(x0), "v"(x1));
+  else
+    asm("v_pk_add_f16 %0, %2, %4\n\t"
+        "v_pk_add_f16 %1, %3, %5"
+        : "=&v"(x0), "=&v"(x1) : "v"(g.q0), "v"(g.q1), "v"(g.r0), "v"(g.r1));  // (early clobber: x0 must not land on q1 / r1)
+}
+// block N of the twelve that activate four pairs: pairs 0 and 1 in blocks 0..5, pairs 2 and 3 in blocks 6..11
+template <int N>
+__device__ __forceinline__ void pk_gelu_op(PkGelu& g, unsigned (&x)[4], const PkGeluK& k) {
+  if constexpr (N >= 0 && N < 12) pk_gelu_block<N % 6>(g, x[2 * (N / 6)], x[2 * (N / 6) + 1], k);
+}
+
 // the lane id from scratch (opaque to the compiler): lane-derived addresses of a late phase are formed from it where they are used, so that
 // nothing lane-derived has to stay in a register (or be spilled) across the MFMA loops, whose B-wave side runs at the 256-register limit
 __device__ __forceinline__ unsigned fresh_lane() {
@@ -141,6 +214,10 @@ __device__ __forceinline__ void lds_read1(unsigned addr, h16x8_t& w) {
 }
 template <int OFF>
 __device__ __forceinline__ void lds_read_f4(unsigned addr, f32x4_t& w) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_u4(unsigned addr, u32x4_t& w) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w) : "v"(addr), "n"(OFF) : "memory");
 }
 template <int OFF>
@@ -333,6 +410,9 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     const unsigned hb_base = lds0 + LDS_HB + pair * HB_PAIR + lane16;
     const unsigned ring = lds0 + LDS_RING + lane16;   // + (t & 1) * TICK: this lane's address of tick t's fragment 0
     GeluMid gm;
+    unsigned xa[4] = {0u, 0u, 0u, 0u}, xb[4];  // (fp16 mode) the previous slice as packed halves: this wave's pairs, the partner's
+    PkGelu pg;
+    const PkGeluK kk = pk_gelu_consts();
     auto boundary = [&](auto FC1_, int v) {  // in front of the first read of unit v + 1
       CS_SB();
       if constexpr (!decltype(FC1_)::value) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // (last tick: no counted waits retire its hand-off writes)
@@ -364,11 +444,29 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
         // for 32x32x16).  In gap 0 the ds_write read the accumulator before MFMAs 22 / 23 had landed (r4: every even slice lost k-steps 22 and
         // 23 in registers 8..15, non-deterministically).  Three MFMAs of this tick (>= 32 cycles of matrix pipe each, issued in order behind
         // that MFMA) lie in between now; the MFMA-free last tick waits explicitly.
-        if constexpr (M == 3) {
-          if (hb_write) {
+        if constexpr (BF) {
+          if constexpr (M == 3) {
+            if (hb_write) {
+              if constexpr (!FC1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+              lds_write16<HB_RAW>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[8], act[9], act[10], act[11]}));
+              lds_write16<HB_RAW + FRAG>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[12], act[13], act[14], act[15]}));
+            }
+          }
+        } else {
+          // fp16 mode (r5): the previous slice is rounded to half here -- compiler-visible conversions, so hipcc places the MFMA -> VALU wait
+          // states itself; gap 1 is two MFMAs behind the instruction that completed `act` -- and the partner's half leaves as 4 packed words
+          // (1 KiB per pair instead of 2)
+          if constexpr (M == 1) {
             if constexpr (!FC1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-            lds_write16<HB_RAW>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[8], act[9], act[10], act[11]}));
-            lds_write16<HB_RAW + FRAG>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[12], act[13], act[14], act[15]}));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xa[i] = pack_h16x2(act[2 * i], act[2 * i + 1]);
+          }
+          if constexpr (M == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xb[i] = pack_h16x2(act[8 + 2 * i], act[9 + 2 * i]);
+          }
+          if constexpr (M == 5) {
+            if (hb_write) lds_write16<HB_RAW>(hb_base + hb_slot * (2 * FRAG), u32x4_t{xb[0], xb[1], xb[2], xb[3]});
           }
         }
         if constexpr (FC1) {
@@ -389,17 +487,28 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
         }
         // GELU of registers 0..7 of the previous slice: 16 half values over gaps 0..11 (two in gaps 6..9); the fragment leaves in gap 11, so that
         // the counted wait of gap 17 has retired the write before the barrier of gap 18 tells the partner to read it
-        if constexpr (M < 12) {
-          constexpr int H0 = M < 6 ? M : (M < 10 ? 6 + 2 * (M - 6) : 14 + (M - 10));
-          constexpr int NH = (M >= 6 && M < 10) ? 2 : 1;
-          sfor<NH>([&](auto I_) {
-            constexpr int HI = H0 + decltype(I_)::value;
-            constexpr int V = HI >> 1;
-            if constexpr ((HI & 1) == 0) { if constexpr (!(ABL & 1)) gm = gelu_erf_a(act[V]); }
-            else gv[V] = (ABL & 1) ? act[V] : gelu_erf_b(act[V], gm);
-          });
+        if constexpr (BF) {
+          if constexpr (M < 12) {
+            constexpr int H0 = M < 6 ? M : (M < 10 ? 6 + 2 * (M - 6) : 14 + (M - 10));
+            constexpr int NH = (M >= 6 && M < 10) ? 2 : 1;
+            sfor<NH>([&](auto I_) {
+              constexpr int HI = H0 + decltype(I_)::value;
+              constexpr int V = HI >> 1;
+              if constexpr ((HI & 1) == 0) { if constexpr (!(ABL & 1)) gm = gelu_erf_a(act[V]); }
+              else gv[V] = (ABL & 1) ? act[V] : gelu_erf_b(act[V], gm);
+            });
+          }
+          if constexpr (M == 11) { if (hb_write) lds_write16<0>(hb_base + hb_slot * FRAG, pack8<BF>(gv)); }
+        } else {
+          // packed-half GELU of this wave's four pairs: 44 instructions; the pairs turn into the B fragment in place
+          // (twelve blocks in gaps 2..11: two in gaps 2 and 7)
+          if constexpr (M >= 2 && M < 12 && !(ABL & 1)) {
+            constexpr int B0 = M < 3 ? 0 : (M < 8 ? M - 1 : M);  // first block of this gap: 0, 2, 3, 4, 5, 6, 8, 9, 10, 11
+            pk_gelu_op<B0>(pg, xa, kk);
+            if constexpr (M == 2 || M == 7) pk_gelu_op<B0 + 1>(pg, xa, kk);
+          }
+          if constexpr (M == 11) { if (hb_write) lds_write16<0>(hb_base + hb_slot * FRAG, u32x4_t{xa[0], xa[1], xa[2], xa[3]}); }
         }
-        if constexpr (M == 11) { if (hb_write) lds_write16<0>(hb_base + hb_slot * FRAG, pack8<BF>(gv)); }
         CS_SB();
       });
     };
@@ -594,6 +703,10 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   u32x4_t hb1;       // B fragment of k-step 1: activated here, in the gaps of the k-step-0 MFMAs, from the partner's raw fp32 values
   f32x4_t rw[2];     // those raw values (registers 8..15 of the partner's fc1 accumulator of the slice)
   GeluMid gm;
+  u32x4_t xr;        // (fp16 mode) those values as 4 packed pairs, rounded by the partner
+  unsigned hx[4];
+  PkGelu pg;
+  const PkGeluK kk = pk_gelu_consts();
   // fc2 tick T = slice + LAGT (same parity): unit boundaries in front of gaps 6 and 18 as on the A side, but a B wave has nothing to wait for
   // except the barrier itself (it issues no LDS-DMA, and its own reads of the released unit were retired by the counted waits long before)
   auto fc2_tick = [&](int slice, bool more) {
@@ -610,8 +723,12 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
           cur += cur_step;
           cur_step = -cur_step;
           lds_read1<0>(hb_base + ((slice + 1) & 1) * FRAG, hb0);  // free from gap 12 on; the partner wrote it before this barrier
-          lds_read_f4<HB_RAW>(hb_base + ((slice + 1) & 1) * (2 * FRAG), rw[0]);
-          lds_read_f4<HB_RAW + FRAG>(hb_base + ((slice + 1) & 1) * (2 * FRAG), rw[1]);
+          if constexpr (BF) {
+            lds_read_f4<HB_RAW>(hb_base + ((slice + 1) & 1) * (2 * FRAG), rw[0]);
+            lds_read_f4<HB_RAW + FRAG>(hb_base + ((slice + 1) & 1) * (2 * FRAG), rw[1]);
+          } else {
+            lds_read_u4<HB_RAW>(hb_base + ((slice + 1) & 1) * (2 * FRAG), xr);
+          }
           CS_SB();
         }
       }
@@ -622,28 +739,42 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       constexpr int F = (M + 6) % 24;  // (after the last tick: re-reads of this tick's first fragments, unused)
       if constexpr (!(ABL & 32)) lds_read1<((F / 12) * 24 + 12 + F % 12) * FRAG>(cur, w[M % 6]);
       // the slice's second fragment: 8 values = 16 half values over gaps 0..11 (two in gaps 6..9), packed pairwise
-      if constexpr (M < 12) {
-        constexpr int H0 = M < 6 ? M : (M < 10 ? 6 + 2 * (M - 6) : 14 + (M - 10));  // first half-value index of this gap
-        constexpr int NH = (M >= 6 && M < 10) ? 2 : 1;
-        sfor<NH>([&](auto I_) {
-          constexpr int HI = H0 + decltype(I_)::value;
-          constexpr int V = HI >> 1;
-          const float x = rw[V >> 2][V & 3];
-          if constexpr ((HI & 1) == 0) { if constexpr (!(ABL & 1)) gm = gelu_erf_a(x); }
-          else {
-            const float y = (ABL & 1) ? x : gelu_erf_b(x, gm);
-            if constexpr ((V & 1) == 0) hb1[V >> 1] = __float_as_uint(y);  // parked in its own target word until the pair is complete
-            else hb1[V >> 1] = pack_o16x2<BF>(__uint_as_float(hb1[V >> 1]), y);
-          }
-        });
+      if constexpr (BF) {
+        if constexpr (M < 12) {
+          constexpr int H0 = M < 6 ? M : (M < 10 ? 6 + 2 * (M - 6) : 14 + (M - 10));  // first half-value index of this gap
+          constexpr int NH = (M >= 6 && M < 10) ? 2 : 1;
+          sfor<NH>([&](auto I_) {
+            constexpr int HI = H0 + decltype(I_)::value;
+            constexpr int V = HI >> 1;
+            const float x = rw[V >> 2][V & 3];
+            if constexpr ((HI & 1) == 0) { if constexpr (!(ABL & 1)) gm = gelu_erf_a(x); }
+            else {
+              const float y = (ABL & 1) ? x : gelu_erf_b(x, gm);
+              if constexpr ((V & 1) == 0) hb1[V >> 1] = __float_as_uint(y);  // parked in its own target word until the pair is complete
+              else hb1[V >> 1] = pack_o16x2<BF>(__uint_as_float(hb1[V >> 1]), y);
+            }
+          });
+        }
+      } else {
+        // packed-half GELU of the partner's four pairs (already halves): one block of four instructions per gap in gaps 0..11, in place
+        if constexpr (M == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) hx[i] = xr[i];
+        }
+        if constexpr (M < 12 && !(ABL & 1)) pk_gelu_op<M>(pg, hx, kk);
+        if constexpr (M == 11) hb1 = u32x4_t{hx[0], hx[1], hx[2], hx[3]};
       }
       CS_SB();
     });
   };
   cur = lds0 + LDS_RING + lane16;  // tick LAGT (even): slice 0
   lds_read1<0>(hb_base, hb0);
-  lds_read_f4<HB_RAW>(hb_base, rw[0]);
-  lds_read_f4<HB_RAW + FRAG>(hb_base, rw[1]);
+  if constexpr (BF) {
+    lds_read_f4<HB_RAW>(hb_base, rw[0]);
+    lds_read_f4<HB_RAW + FRAG>(hb_base, rw[1]);
+  } else {
+    lds_read_u4<HB_RAW>(hb_base, xr);
+  }
   sfor<6>([&](auto F_) { lds_read1<(12 + decltype(F_)::value) * FRAG>(cur, w[decltype(F_)::value]); });
   for (int sl = 0; sl < NSL - 1; ++sl) fc2_tick(sl, true);
   fc2_tick(NSL - 1, false);
