@@ -334,7 +334,12 @@ def plumbing_test(args, rank, world):
 
     elapsed, _ = timed_steps(step, lambda: None, args.steps, args.warmup, dev)
     means = parallel.gather_means(torch.full((2,), float(rank)), 2 * world)
-    census = parallel.rank_census(dev, ms_per_step=1e3 * timed_steps.last_rank_seconds / args.steps)
+    t0 = time.perf_counter()
+    step()
+    census = parallel.rank_census(dev, ms_per_step=1e3 * timed_steps.last_rank_seconds / args.steps,
+                                  host_enqueue_ms_per_forward=1e3 * (time.perf_counter() - t0), launches_per_forward=0)  # (stub: the keys of the real line)
+    if os.environ.get("CS_PLUMBING_FAIL_RANK") == str(rank):  # rehearsal of the per-rank failure line
+        raise RuntimeError("rehearsed failure")
     # the strong-scaling leg's plumbing (scaling_cfg4): a fixed global batch split by parallel.shard_bounds, a stub that costs 1 ms per item
     G = args.global_batch
     lo, hi = parallel.shard_bounds(G, world, rank)
@@ -421,7 +426,11 @@ def main():
     elapsed, ticket = timed_steps(wl.step, sync, args.steps, args.warmup, dev)
     score = wl.pipe.result(ticket)["score_map_ref_cross"]  # the output of the last timed step
     # who took part: one record per rank (device identity + that rank's own time for the K steps), gathered over the process group
-    census = parallel.rank_census(dev, ms_per_step=1e3 * timed_steps.last_rank_seconds / args.steps)
+    # what a forward costs THIS rank's CPU thread (cs_forward_stats of the replica that ran the last timed step: kernel launches of one forward
+    # and the wall time of the enqueueing call; nothing is waited for inside it) -- the host-side budget of N ranks on one node
+    fstats = wl.pipe.nets[(wl.pipe._n - 1) % len(wl.pipe.nets)].forward_stats() if getattr(wl.pipe, "nets", None) else wl.net.forward_stats()
+    census = parallel.rank_census(dev, ms_per_step=1e3 * timed_steps.last_rank_seconds / args.steps,
+                                  host_enqueue_ms_per_forward=round(fstats["host_enqueue_ms"], 4), launches_per_forward=fstats["launches"])
     # the timed region is short (K steps of a few ms with batches in flight: pipeline fill / drain and clock ramp are inside it), so
     # four more K-step regions follow and the median of the five is reported beside `value` (which stays the FIRST region's, per the
     # bench contract: exactly K timed steps after W warm-up steps)
@@ -511,6 +520,7 @@ def main():
             "value_median_of_5": (sorted(world * B * args.steps / e for e in repeats)[len(repeats) // 2] if len(repeats) == 5 else None),
             "value_repeats": [round(world * B * args.steps / e, 1) for e in repeats],
             "ranks_seen": census, "process_group": parallel.backend_info(),
+            "host_enqueue_ms_per_forward": fstats["host_enqueue_ms"], "launches_per_forward": fstats["launches"], "launches_by_kernel": fstats["kernels"],
             "dtype": args.dtype, "data": "synthetic",  # 16-bit MFMA operands (IEEE half by default: the bf16 MFMA rate, 3 more mantissa bits), fp32 accumulate / softmax / LayerNorm / output
             "nonfinite_score_values": wl.pipe.nonfinite_count(),
             "batches_in_flight_measured": overlap,  # of the fifth K-step region (warm-up step included), HIP events per forward
@@ -595,5 +605,27 @@ def main():
     parallel.shutdown()
 
 
+def _report_failure(exc: BaseException) -> None:
+    """One line per failing rank on stderr (rank, local rank, device, stage of the exception): with N ranks under torch.distributed.run the
+    launcher's own summary names only the first failing child, and the driver keeps just the tail of the output."""
+    import traceback
+    tb = traceback.extract_tb(exc.__traceback__)
+    where = f"{os.path.basename(tb[-1].filename)}:{tb[-1].lineno} in {tb[-1].name}" if tb else "?"
+    dev = "?"
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            dev = f"cuda:{torch.cuda.current_device()} of {torch.cuda.device_count()} visible"
+    except Exception:
+        pass
+    print(f"bench.py FAILED rank={os.environ.get('RANK', '0')} local_rank={os.environ.get('LOCAL_RANK', '0')} world={os.environ.get('WORLD_SIZE', '1')} "
+          f"pid={os.getpid()} device={dev} at {where}: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:  # noqa: BLE001 -- reported per rank, then re-raised unchanged
+        _report_failure(exc)
+        raise

@@ -42,6 +42,7 @@ SYMBOLS = {
     "cs_forward_cached": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "cs_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "cs_nonfinite_count": (_i, [_vp, C.POINTER(C.c_longlong)]),
+    "cs_forward_stats": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_char_p, _sz]),
     "cs_debug_set_op_operand_dtype": (_i, [_i]),
     "cs_debug_capture": (_i, [_vp, _i]),
     "cs_debug_read": (_i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), _vp]),
@@ -71,6 +72,7 @@ SYMBOLS = {
     "cs_op_ln_fold_consts": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cs_gemm_column_tiles": (_i, [_i]),
     "cs_debug_gemm256_enable": (None, [_i]),
+    "cs_debug_gemm256_kmin": (None, [_i]),
     "cs_panel_supported": (_i, [_i, _i]),
     "cs_panel_image_bytes": (_sz, [_i]),
     "cs_op_panel_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

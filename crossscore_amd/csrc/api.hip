@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -116,6 +117,9 @@ struct cs_model {
   int Kp = 0;  // padded patch K
   int qkv_n = 0;  // columns of the encoder's packed QKV projection: 3C, or 3C padded to whole 256-column tiles (zero rows) when that lets the
                   // large-tile GEMM take it (ViT-S: 1152 -> 1280; measured 47.5 -> 36.9 us per 24-image chunk, r4); attention reads with this stride
+  // launch census of the last forward (cs_forward_stats): kernel launches by kernel, and the host time the call spent enqueueing them
+  std::map<std::string, int> census;
+  double host_enqueue_ms = 0.0;
   bool panel = false;   // encoder layers run as QKV GEMM + attention + ONE token-panel kernel (panel.hip; hidden == 384 only)
   float *ones = nullptr, *zeros = nullptr;  // [C]: layer 0's norm1 without gamma/beta (they are folded into its QKV projection)
   bool lnfold = false;  // encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass)
@@ -265,6 +269,8 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
 // the optional second stage of Launcher::rowln: the sub-block's following linear, out (M, n) = act(LN rows x W^T + b)
 struct NextLinear { const h16_t* W = nullptr; const float* b = nullptr; h16_t* out = nullptr; int n = 0, act = 0; };
 
+extern "C" int cs_gemm256_supported(const CsGemmParams* p, int epi);  // gemm256.hip: the shapes cs_gemm_launch routes to the 256-tile kernel
+
 struct Launcher {
   cs_model* m; hipStream_t st; int rc = 0;
   int bpc = 0;  // GEMM blocks per CU hint (CsGemmParams::bpc)
@@ -288,6 +294,7 @@ struct Launcher {
     if ((epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN) && g.resid) bytes += 4.0 * mn;
     if (epi == CS_EPI_PATCH_F32) bytes += 4.0 * g.Np * g.N;
     begin(epi, 2.0 * g.M * g.N * (k_real > 0 ? k_real : g.K), bytes);
+    m->census[cs_gemm256_supported(&g, epi) ? "gemm256" : "gemm128"]++;
     hipError_t e = cs_gemm_launch(&g, epi, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "gemm launch: %s", hipGetErrorString(e)); return false; }
@@ -299,6 +306,7 @@ struct Launcher {
     if (const char* e = cs_attn_check(&a, dh, batch)) { rc = fail(CS_ERR_BAD_ARG, "%s", e); return false; }
     // Q and O once, K and V once per (batch, head): 2 bytes each
     begin(16 + dh / 16, 4.0 * batch * a.heads * (double)a.Lq * a.Lk * dh, 2.0 * batch * a.heads * dh * (2.0 * a.Lq + 2.0 * a.Lk));
+    m->census["attn" + std::to_string(dh)]++;
     hipError_t e = cs_attn_launch(&a, dh, batch, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "attention launch: %s", hipGetErrorString(e)); return false; }
@@ -312,6 +320,7 @@ struct Launcher {
     // algorithmic bytes: x read + written (fp32), attention output read, u written (fp16), the weight stream once
     begin(40, 2.0 * M * C * C * (q.attn_o ? 1 : 0) + 4.0 * M * C * F,
           M * C * (8.0 + (q.attn_o ? 2.0 : 0.0) + (q.u_out ? 2.0 : 0.0)) + (double)cs_panel_image_bytes(q.attn_o ? 1 : 0));
+    m->census["panel"]++;
     hipError_t e = cs_panel_launch(&q, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "panel launch: %s", hipGetErrorString(e)); return false; }
@@ -330,12 +339,14 @@ struct Launcher {
     // algorithmic bytes: A and W once, the residual rows in, the normalised rows out (fp32, and 16-bit where asked); second stage: W2 in, rows out
     begin(42, 2.0 * M * C * (double)(C + next.n),
           2.0 * M * C + 2.0 * C * C + (resid ? 4.0 : 0.0) * M * C + (out_f32 ? 4.0 : 0.0) * M * C + (out_f16 ? 2.0 : 0.0) * M * C + 2.0 * next.n * C + 2.0 * M * next.n);
+    m->census["rowln"]++;
     hipError_t e = cs_rowln_launch(&q, C, m->cfg.operand_dtype, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "linear + LayerNorm launch: %s", hipGetErrorString(e)); return false; }
     return true;
   }
   bool misc(hipError_t e, const char* what) {
+    m->census[what]++;
     if (rc) return false;
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e)); return false; }
     return true;
@@ -1151,7 +1162,10 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
   if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
   hipStream_t st = (hipStream_t)stream;
   if (h->ev_done && h->last_stream != st) HIPCHK(hipStreamWaitEvent(st, h->ev_done, 0));
+  h->census.clear();
+  const auto t0 = std::chrono::steady_clock::now();
   const int rc = forward_body(h, mode, query, refs, ref_tokens, tokens_out, B, N, H, W, score_out, attn_out, head_id, mean_out, stream);
+  h->host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!h->ev_done) HIPCHK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
   HIPCHK(hipEventRecord(h->ev_done, st));
   h->last_stream = st;
@@ -1170,6 +1184,21 @@ int cs_encode_references(cs_handle h, const float* imgs, int R, int H, int W, ui
 int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_tokens, int B, int N, int H, int W, float* score_out,
                       float* attn_out, int head_id, float* mean_out, cs_stream stream) {
   return forward_impl(h, 1, query, nullptr, ref_tokens, nullptr, B, N, H, W, score_out, attn_out, head_id, mean_out, stream);
+}
+
+// What the last forward-class call on this handle launched, and what it cost the host: `launches` = kernel launches (memcpy taps of capture
+// mode not counted), `host_ms` = wall time of the call on the calling thread (everything is enqueued, nothing waited for), `names` (optional,
+// `names_bytes` long) = "kernel=count kernel=count ..." by kernel: gemm256 / gemm128 (cs_gemm256_kernel / cs_gemm_kernel), attn<dh>, panel,
+// rowln, patch, im2col, ln1 / ln2 / ln (layernorm_kernel), cls, final_ln, score_check, score_mean, ...
+int cs_forward_stats(cs_handle h, int* launches, double* host_ms, char* names, size_t names_bytes) {
+  if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
+  int n = 0;
+  std::string txt;
+  for (const auto& kv : h->census) { n += kv.second; txt += (txt.empty() ? "" : " ") + kv.first + "=" + std::to_string(kv.second); }
+  if (launches) *launches = n;
+  if (host_ms) *host_ms = h->host_enqueue_ms;
+  if (names && names_bytes) { std::strncpy(names, txt.c_str(), names_bytes - 1); names[names_bytes - 1] = 0; }
+  return 0;
 }
 
 // Debug taps for the stage-level parity tests: with capture on, every forward also copies its intermediate tensors (stream-ordered

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
   const int panels_x = (tiles_m - xcd + 7) / 8;
   const int ntile_x = panels_x * tiles_n;
   if (slot >= ntile_x) return;  // whole workgroup, before any barrier
-  const int T = p.K / G_BK;     // K tiles per output tile (even, >= 8: cs_gemm256_supported)
+  const int T = p.K / G_BK;     // K tiles per output tile (even, >= 6: cs_gemm256_supported)
   auto tile_of = [&](int idx, int& m0, int& n0) {
     const int pl = idx / tiles_n;
     m0 = (pl * 8 + xcd) * G_BM;
@@ -412,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
 }
 
 int g_enabled = 1;
+int g_kmin = 384;  // cs_debug_gemm256_kmin
 
 template <int EPI, bool BF, bool RES = false>
 hipError_t launch256(const CsGemmParams& p, hipStream_t st) {
@@ -449,6 +450,8 @@ int cs_gemm256_debug_read(unsigned long long* dst) { return (int)hipMemcpyFromSy
 
 // tools / tests: 0 routes every GEMM to gemm.hip's kernel again
 void cs_debug_gemm256_enable(int on) { g_enabled = on; }
+// tools (tools/qkv_k384_try.py): smallest K the kernel takes; 384 by default
+void cs_debug_gemm256_kmin(int k) { g_kmin = k > 0 ? k : 384; }
 
 // Shapes this kernel takes (everything else stays with gemm.hip): whole 256-column tiles, an even number of 64-deep K tiles and
 // K >= 384, the plain epilogues.
@@ -457,8 +460,7 @@ int cs_gemm256_supported(const CsGemmParams* p, int epi) {
   if (epi > CS_EPI_RESID_F32) return 0;
   // K >= 384 (r4; 512 before): at K = 384 the large tile already wins clearly -- ViT-S QKV (32 880 x 1280 x 384) 36.9 us against 52.9 on the
   // 128-row kernel (47.5 at the unpadded 1152 columns), tools/qkv_k384_try.py.  The K loop itself takes any even number >= 4 of K tiles.
-  static const int kmin = getenv("CS_G256_KMIN") ? atoi(getenv("CS_G256_KMIN")) : 384;
-  if (p->N % G_BN || p->N > G_NLIM || p->K % (2 * G_BK) || p->K < kmin || p->K < 4 * G_BK || p->M < G_BM) return 0;
+  if (p->N % G_BN || p->N > G_NLIM || p->K % (2 * G_BK) || p->K < g_kmin || p->K < 4 * G_BK || p->M < G_BM) return 0;
   if (p->lda % 8 || p->ldw % 8 || p->ldc % 8) return 0;
   if ((long long)p->M * p->lda * 2 >= (1ll << 32) || (long long)p->N * p->ldw * 2 >= (1ll << 32)) return 0;
   if (epi == CS_EPI_RESID_F32 && p->resid && (p->ldr % 4 || (long long)p->M * p->ldr * 4 >= (1ll << 32))) return 0;

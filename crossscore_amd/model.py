@@ -150,6 +150,16 @@ class CrossScoreNet(torch.nn.Module):
         _lib.check(_lib.load().cs_nonfinite_count(self._handle, C.byref(n)))
         return int(n.value)
 
+    def forward_stats(self) -> dict:
+        """Launch census of this module's last forward (cs_forward_stats): {"launches": kernel launches, "host_enqueue_ms": wall time the call
+        took on the calling thread, "kernels": {name: count}}."""
+        if self._handle is None:
+            return {"launches": 0, "host_enqueue_ms": 0.0, "kernels": {}}
+        n, ms, buf = C.c_int(0), C.c_double(0.0), C.create_string_buffer(1024)
+        _lib.check(_lib.load().cs_forward_stats(self._handle, C.byref(n), C.byref(ms), buf, 1024))
+        kern = {k: int(v) for k, v in (kv.split("=") for kv in buf.value.decode().split() if "=" in kv)}
+        return {"launches": int(n.value), "host_enqueue_ms": float(ms.value), "kernels": kern}
+
     def _release(self):
         if self._handle is not None:
             _lib.load().cs_destroy(self._handle)

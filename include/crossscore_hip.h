@@ -131,6 +131,13 @@ size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
 int cs_set_lanes(cs_handle h, int lanes);
 int cs_redraw_lane_streams(cs_handle h);
 
+/* Launch census of the last cs_forward / cs_forward_cached / cs_encode_references on this handle: kernel launches, host wall time of the
+ * call (all work is enqueued, nothing is waited for: this is what a rank's CPU thread pays per forward -- bench.py reports it per rank, the
+ * reference pays the same kind of cost in Lightning's predict loop, task/predict.py:119-135) and, optionally, the launches by kernel as
+ * "name=count ..." text (gemm256, gemm128, attn<dh>, panel, rowln, patch, im2col, ln*, cls, final_ln, ...; the parity tests use it to prove
+ * which kernels a shape was routed to). */
+int cs_forward_stats(cs_handle h, int* launches, double* host_ms, char* names, size_t names_bytes);
+
 /* Stage-level taps for the parity tests (tests/test_hip_stages.py): with capture on, every forward of this handle also copies its
  * intermediate tensors into library-owned buffers (stream-ordered device-to-device copies; the first captured forward of a shape
  * allocates -- not for timed runs).  Names follow the reference's module outputs (tests/golden/make_golden.py hooks the same points):
@@ -235,10 +242,12 @@ int cs_op_panel_pack(const float* wo, const float* ls1, const float* w1, const f
                      uint16_t* img, cs_stream stream);
 int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, const float* bo, const float* b1, const float* b2,
                         uint16_t* u_out, int M, float eps, cs_stream stream);
-/* debug switch, process-wide (see cs_debug_* above).  Kernel selection of cs_op_gemm / the forward's linears: 1 (default) = shapes with K >= 512, N a multiple of
+/* debug switch, process-wide (see cs_debug_* above).  Kernel selection of cs_op_gemm / the forward's linears: 1 (default) = shapes with K >= 384, N a multiple of
  * 256 and M >= 256 run on the 256 x 256 x 64-tile kernel (csrc/gemm256.hip), everything else on the 128-row kernel (csrc/gemm.hip);
  * 0 = the 128-row kernel for every shape.  The two kernels add the same products in the same order: their results are bit-identical (tested). */
 void cs_debug_gemm256_enable(int on);
+/* debug switch, process-wide: the smallest K the 256-tile kernel takes (default 384; tools/qkv_k384_try.py compares 384 with 512) */
+void cs_debug_gemm256_kmin(int k);
 /* The decoder's sub-block closing  x = LN(x + Linear(y))  (model/customised_transformer/transformer.py:157-173) in one launch (csrc/rowln.hip;
  * K = N = C = 384: the ViT-S decoder): out_f32 / out_f16 (M, C) = LayerNorm(resid + A W^T + bias; gamma, beta, eps); resid may be NULL
  * (decoder_do_short_cut off) and may alias out_f32.  CS_ERR_BAD_ARG for other widths (the forward then runs GEMM + LayerNorm).

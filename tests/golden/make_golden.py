@@ -231,6 +231,41 @@ def main():
                             score=out["score_map_ref_cross"].numpy(), **taps)
         print("g7 done", out["score_map_ref_cross"].shape, {k: v.shape for k, v in taps.items()})
 
+    # G8: the ViT-S WIDTH (C = 384, 6 encoder heads of 64, decoder heads of 48) with two encoder layers, every module output of the reference:
+    # at this width the HIP path runs its production kernels (token-panel kernel, 256-tile GEMM at >= 256 rows, row-complete linear +
+    # LayerNorm, one-launch patch embedding, attention at dh 64 / 48), which g0's C = 128 net never reaches.  B = 2, N = 3, 98 x 112 ->
+    # 7 x 8 patches: 8 images x 57 tokens = 456 encoder rows, 336 memory rows; encoder table 5 x 5 -> 7 x 8 bicubic, PE 40 x 40 -> 7 x 8.
+    if want("g8"):
+        s2 = synth.BACKBONES["synthetic/dinov2-small-2l"]
+        _patch_backbone(DC, DM, s2)
+        net = core.CrossScoreNet(make_cfg(s2)).eval()
+        sd = synth.make_state_dict(s2, 8)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        Bq, Nq, Hq, Wq = 2, 3, 98, 112
+        q, r = synth.make_inputs(Bq, Nq, Hq, Wq, 8)
+        tq, tr = torch.from_numpy(q), torch.from_numpy(r)
+        taps = {}
+        hooks = []
+        bb = net.backbone
+        hooks.append(bb.embeddings.register_forward_hook(lambda m, i, o: taps.__setitem__("embeddings", o.detach().numpy().copy())))
+        for li, layer in enumerate(bb.encoder.layer):
+            hooks.append(layer.register_forward_hook(
+                lambda m, i, o, li=li: taps.__setitem__(f"enc_layer_{li}", (o[0] if isinstance(o, tuple) else o).detach().numpy().copy())))
+        for li, layer in enumerate(net.ref_cross.attn.layers):
+            hooks.append(layer.register_forward_hook(lambda m, i, o, li=li: taps.__setitem__(f"dec{li}_out", o[0].detach().numpy().copy())))
+        hooks.append(net.ref_cross.head[2].register_forward_hook(lambda m, i, o: taps.__setitem__("head_pre_activation", o.detach().numpy().copy())))
+        hooks.append(net.ref_cross.attn.layers[0].register_forward_pre_hook(
+            lambda m, a, k: (taps.__setitem__("featmap_query", (a[0] if a else k["tgt"]).detach().numpy().copy()),
+                             taps.__setitem__("featmap_ref", (a[1] if len(a) > 1 else k["memory"]).detach().numpy().copy()))[0] and None,
+            with_kwargs=True))
+        with torch.no_grad():
+            out = net(tq, tr, True, 3, False)
+        for hk in hooks:
+            hk.remove()
+        np.savez_compressed(os.path.join(HERE, "g8_vits_width_all.npz"), seed=8, B=Bq, N=Nq, H=Hq, W=Wq,
+                            score=out["score_map_ref_cross"].numpy(), attn_head3=out["attn_weights_map_ref_cross"].numpy(), **taps)
+        print("g8 done", out["score_map_ref_cross"].shape, {k: v.shape for k, v in taps.items()})
+
     def big(name, arch, seed, B, N, H, W):
         _, out, dt = run_reference(core, DC, DM, arch, seed, B, N, H, W)
         s = out["score_map_ref_cross"].numpy()

@@ -101,7 +101,7 @@ def test_gemm_resid_f32(M, with_scale, with_resid):
     assert (out - ref).abs().max() < 2e-4  # fp32 out; only accumulation order differs
 
 
-# ---- the 256 x 256 x 64-tile kernel (csrc/gemm256.hip): shapes with K >= 512, N % 256 == 0, M >= 256 ----
+# ---- the 256 x 256 x 64-tile kernel (csrc/gemm256.hip): shapes with K >= 384 (six K tiles: ViT-S QKV / decoder K/V), N % 256 == 0, M >= 256 ----
 def _gemm256(on):
     _lib.load().cs_debug_gemm256_enable(1 if on else 0)
 
@@ -109,7 +109,11 @@ def _gemm256(on):
 def test_gemm256_exact_integer_layout():
     """Asymmetric integer operands over several K tiles, ragged M: any row<->column swap, fragment mis-mapping, swizzle error or a K tile
     read before it landed is an exact mismatch (all products and sums are small integers: exact in fp16 x fp16 -> fp32)."""
-    M, N, K = 700, 512, 1024
+    _gemm256_integer_layout(700, 512, 1024)
+    _gemm256_integer_layout(1370, 1280, 384)   # six K tiles: the shortest K loop the kernel takes (prologue + seam with nothing in between)
+
+
+def _gemm256_integer_layout(M, N, K):
     A = ((torch.arange(M, device=DEV)[:, None] * 5 + torch.arange(K, device=DEV)[None, :] * 3) % 7 - 3.0)
     W = ((torch.arange(N, device=DEV)[:, None] * 3 + torch.arange(K, device=DEV)[None, :] * 7) % 5 - 2.0)
     b = (torch.arange(N, device=DEV) % 11 - 5.0)
@@ -126,7 +130,8 @@ def test_gemm256_exact_integer_layout():
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 512), (300, 768, 768), (1370, 2304, 768), (10960, 768, 3072), (10960, 3072, 768),
-                                   (2740, 768, 1536), (513, 256, 640), (700, 4096, 1024)])  # (N > 3072: bias read from memory per tile)
+                                   (2740, 768, 1536), (513, 256, 640), (700, 4096, 1024),  # (N > 3072: bias read from memory per tile)
+                                   (1370, 1280, 384), (10952, 1536, 384), (32880, 1280, 384)])  # K = 384: ViT-S QKV (padded) and decoder K/V
 def test_gemm256_matches_reference_and_small_tile_kernel(M, N, K):
     g = _rng(M + N + K + 1)
     A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))

@@ -40,6 +40,26 @@ def test_g0_tiny_all_intermediates(golden_dir):
     assert np.abs(out["score_map_ref_cross"].numpy() - g["score_no_weights"]).max() < TOL
 
 
+def test_g8_vits_width_all_intermediates(golden_dir):
+    """g8: the ViT-S width (C = 384, two encoder layers), every module output of the reference (tests/golden/make_golden.py): the oracle's
+    taps at the width whose HIP kernels carry the benchmark (tests/test_hip_stages.py compares those kernels with the same arrays)."""
+    arch = synth.BACKBONES["synthetic/dinov2-small-2l"]
+    g = _golden(golden_dir, "g8_vits_width_all.npz")
+    W = orc.to_torch(synth.make_state_dict(arch, int(g["seed"])))
+    q, r = synth.make_inputs(int(g["B"]), int(g["N"]), int(g["H"]), int(g["W"]), int(g["seed"]))
+    taps = {}
+    out = orc.forward(W, dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), True, 3, taps=taps)
+    checked = 0
+    for k in g.files:
+        if k in taps:
+            # residual-stream values reach |x| ~ 30 at this width: 2e-5 relative to the stage's largest magnitude
+            assert np.abs(taps[k].numpy() - g[k]).max() < TOL * max(1.0, float(np.abs(g[k]).max())), k
+            checked += 1
+    assert checked >= 8
+    assert np.abs(out["score_map_ref_cross"].numpy() - g["score"]).max() < TOL
+    assert np.abs(out["attn_weights_map_ref_cross"].numpy() - g["attn_head3"]).max() < TOL
+
+
 VARIANTS = {
     "no_self_attn": dict(do_self_attn=False),
     "no_short_cut": dict(do_short_cut=False),

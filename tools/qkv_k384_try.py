@@ -1,5 +1,5 @@
 """Would the 256 x 256 x 64-tile GEMM beat the 128-row kernel on the ViT-S QKV shape (K = 384)?  N must be a multiple of 256 for it: the
-1152 QKV columns padded to 1280.  CS_G256_KMIN=384 lets the large-tile kernel take K = 384 (set before the library loads)."""
+1152 QKV columns padded to 1280.  The large-tile kernel takes K >= 384 since round 4 (cs_debug_gemm256_kmin moves the gate)."""
 import os, sys, math
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
