@@ -79,41 +79,7 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F&
 template <int N, class F>
 __device__ __forceinline__ void sfor(F&& f) { static_for(std::make_integer_sequence<int, N>{}, f); }
 
-// exact-erf GELU, the degree-7 minimax fit of Phi of cs_common.h (gelu_erf4), one value per call in plain fma form: in the A wave the
-// VALU work shares the wave's issue stream with its MFMAs, so it must be schedulable instruction by instruction
-__device__ __forceinline__ float gelu_erf1(float x) {
-  const float c = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f);
-  const float t = c * c;
-  float q = fmaf(-9.6129670387e-10f, t, 8.3297297734e-08f);
-  q = fmaf(q, t, -3.1398569575e-06f);
-  q = fmaf(q, t, 6.8266010957e-05f);
-  q = fmaf(q, t, -9.6075936689e-04f);
-  q = fmaf(q, t, 9.3374518106e-03f);
-  q = fmaf(q, t, -6.5599355124e-02f);
-  q = fmaf(q, t, 3.9850871469e-01f);
-  return x * fmaf(c, q, 0.5f);
-}
-
-// the same arithmetic in two halves (5 + 6 instructions) so that a value can be spread over two MFMA gaps; c, t, q travel between them
-struct GeluMid { float c, t, q; };
-__device__ __forceinline__ GeluMid gelu_erf_a(float x) {
-  GeluMid m;
-  m.c = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f);
-  m.t = m.c * m.c;
-  m.q = fmaf(-9.6129670387e-10f, m.t, 8.3297297734e-08f);
-  m.q = fmaf(m.q, m.t, -3.1398569575e-06f);
-  m.q = fmaf(m.q, m.t, 6.8266010957e-05f);
-  return m;
-}
-__device__ __forceinline__ float gelu_erf_b(float x, GeluMid m) {
-  float q = fmaf(m.q, m.t, -9.6075936689e-04f);
-  q = fmaf(q, m.t, 9.3374518106e-03f);
-  q = fmaf(q, m.t, -6.5599355124e-02f);
-  q = fmaf(q, m.t, 3.9850871469e-01f);
-  return x * fmaf(m.c, q, 0.5f);
-}
-
-// ---- packed-half GELU (fp16 operand mode, r5).  The fc1 accumulators are rounded to half FIRST -- the tensor the reference's own
+// ---- packed-half GELU (r5; both operand modes).  The fc1 accumulators are rounded to half FIRST -- the tensor the reference's own
 //      `16-mixed` run hands to its GELU (config/default_predict.yaml:25; HF modeling_dinov2.py:293-297 under autocast) -- and two values
 //      travel through every instruction (v_pk_*_f16): 11 instructions per PAIR behind the conversion instead of 11.5 per value.
 //      A plain Horner form of Phi in x^2 cannot be evaluated in half precision (terms of magnitude 6 cancel to 0.1 at |x| = 4: 1e-2 of error),
@@ -124,7 +90,10 @@ __device__ __forceinline__ float gelu_erf_b(float x, GeluMid m) {
 //      rms 2.6e-4 for x ~ N(0, 1) against 2.1e-4 of exact-GELU-of-the-rounded-input-rounded (the reference's own arithmetic) and 1.4e-4 of a
 //      lone output rounding; max 2.1e-3 at |y| = 2.3 (one ulp there); score-map MAE 0.994e-4 against 0.977e-4 with an exact GELU in the oracle's
 //      fp16-operand emulation (tools/gelu_pk16_fit.py writes the coefficients and these numbers).
-//      relu, |x| and the clamp are exact; +-inf and values beyond half range behave as relu; the clamp modifier turns a NaN into 0. ----
+//      relu, |x| and the clamp are exact; +-inf and values beyond half range behave as relu; the clamp modifier turns a NaN into 0.
+//      bf16 operand mode (fp32's range is the point of that mode): only the bounded correction term P6(z) is computed in halves (the rounded
+//      input saturates to d = 0 beyond 65504, where the term is -1.3e-4 anyway); relu(x) stays fp32, the sum is formed in fp32
+//      (v_fma_mix_f32 reads the half) and rounded once to bf16: 15 instructions per pair instead of 23. ----
 struct PkGeluK { unsigned nk, c5, c4, c3, c2, c1, c0, vc6; };
 __device__ __forceinline__ PkGeluK pk_gelu_consts() {  // seven SGPRs and one VGPR for the whole MLP phase (VOP3P reads one SGPR per instruction)
   PkGeluK k;
@@ -143,8 +112,9 @@ __device__ __forceinline__ PkGeluK pk_gelu_consts() {  // seven SGPRs and one VG
 // write behind every inline-asm result and puts an s_nop between two asm statements that hand a register on) sees one statement per MFMA gap.
 //   stages: 0 t = |x|   1 t = clamp(1 - t/4)   2 t = t t - 1/2   3 q = c6 t + c5   4..8 q = q t + c4..c0   9 r = max(x, 0)   10 x = q + r
 struct PkGelu { unsigned t0, t1, q0, q1, r0, r1; };
-template <int B>
-__device__ __forceinline__ void pk_gelu_block(PkGelu& g, unsigned& x0, unsigned& x1, const PkGeluK& k) {
+// (a: the two pairs' four pre-activations in fp32 -- bf16 mode only)
+template <int B, bool BF>
+__device__ __forceinline__ void pk_gelu_block(PkGelu& g, unsigned& x0, unsigned& x1, const PkGeluK& k, float a0, float a1, float a2, float a3) {
   if constexpr (B == 0)
     asm("v_pk_max_f16 %0, %2, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_max_f16 %1, %3, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -169,7 +139,25 @@ __device__ __forceinline__ void pk_gelu_block(PkGelu& g, unsigned& x0, unsigned&
         "v_pk_fma_f16 %0, %0, %2, %5\n\t"
         "v_pk_fma_f16 %1, %1, %3, %5"
         : "+v"(g.q0), "+v"(g.q1) : "v"(g.t0), "v"(g.t1), "s"(k.c2), "s"(k.c1));
-  else if constexpr (B == 4)
+  else if constexpr (B == 4 && BF)
+    asm("v_pk_fma_f16 %0, %0, %2, %4\n\t"
+        "v_pk_fma_f16 %1, %1, %3, %4"
+        : "+v"(g.q0), "+v"(g.q1) : "v"(g.t0), "v"(g.t1), "s"(k.c0));
+  else if constexpr (B == 5 && BF) {
+    float y0, y1, y2, y3;
+    asm("v_max_f32 %2, 0, %6\n\t"
+        "v_max_f32 %3, 0, %7\n\t"
+        "v_max_f32 %4, 0, %8\n\t"
+        "v_max_f32 %5, 0, %9\n\t"
+        "v_fma_mix_f32 %2, %10, 1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %10, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %4, %11, 1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %11, 1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_bf16_f32 %0, %2, %3\n\t"
+        "v_cvt_pk_bf16_f32 %1, %4, %5"
+        : "=&v"(x0), "=&v"(x1), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(g.q0), "v"(g.q1));
+  } else if constexpr (B == 4)
     asm("v_pk_fma_f16 %0, %0, %4, %6\n\t"
         "v_pk_fma_f16 %1, %1, %5, %6\n\t"
         "v_pk_max_f16 %2, %7, 0 op_sel_hi:[1,0]\n\t"
@@ -181,9 +169,12 @@ __device__ __forceinline__ void pk_gelu_block(PkGelu& g, unsigned& x0, unsigned&
         : "=&v"(x0), "=&v"(x1) : "v"(g.q0), "v"(g.q1), "v"(g.r0), "v"(g.r1));  // (early clobber: x0 must not land on q1 / r1)
 }
 // block N of the twelve that activate four pairs: pairs 0 and 1 in blocks 0..5, pairs 2 and 3 in blocks 6..11
-template <int N>
-__device__ __forceinline__ void pk_gelu_op(PkGelu& g, unsigned (&x)[4], const PkGeluK& k) {
-  if constexpr (N >= 0 && N < 12) pk_gelu_block<N % 6>(g, x[2 * (N / 6)], x[2 * (N / 6) + 1], k);
+template <int N, bool BF>
+__device__ __forceinline__ void pk_gelu_op(PkGelu& g, unsigned (&x)[4], const PkGeluK& k, const float (&a)[8]) {
+  if constexpr (N >= 0 && N < 12) {
+    constexpr int P = 2 * (N / 6);
+    pk_gelu_block<N % 6, BF>(g, x[P], x[P + 1], k, a[2 * P], a[2 * P + 1], a[2 * P + 2], a[2 * P + 3]);
+  }
 }
 
 // the lane id from scratch (opaque to the compiler): lane-derived addresses of a late phase are formed from it where they are used, so that
@@ -385,7 +376,6 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     //      (t-1) & 1 before the tick's transition (gap 18): the partner multiplies them from tick t+1 on ----
     f32x16_t acE, acO;  // even / odd slices
     const unsigned bias_addr = lds0 + LDS_B1 + 64 * h;
-    float gv[8];
     f32x4_t bb[4];
     auto read_bias = [&](int t) {  // this lane's 16 hidden units of slice t: 32 t + 16 h + r
       const unsigned a = bias_addr + t * 128;
@@ -409,7 +399,6 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
     // and the loader refills the slot of unit v - 1 with unit v + 3 (one 1-KiB piece per gap, 6 per A wave) two boundaries ahead of its use.
     const unsigned hb_base = lds0 + LDS_HB + pair * HB_PAIR + lane16;
     const unsigned ring = lds0 + LDS_RING + lane16;   // + (t & 1) * TICK: this lane's address of tick t's fragment 0
-    GeluMid gm;
     unsigned xa[4] = {0u, 0u, 0u, 0u}, xb[4];  // (fp16 mode) the previous slice as packed halves: this wave's pairs, the partner's
     PkGelu pg;
     const PkGeluK kk = pk_gelu_consts();
@@ -444,29 +433,30 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
         // for 32x32x16).  In gap 0 the ds_write read the accumulator before MFMAs 22 / 23 had landed (r4: every even slice lost k-steps 22 and
         // 23 in registers 8..15, non-deterministically).  Three MFMAs of this tick (>= 32 cycles of matrix pipe each, issued in order behind
         // that MFMA) lie in between now; the MFMA-free last tick waits explicitly.
-        if constexpr (BF) {
-          if constexpr (M == 3) {
-            if (hb_write) {
-              if constexpr (!FC1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-              lds_write16<HB_RAW>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[8], act[9], act[10], act[11]}));
-              lds_write16<HB_RAW + FRAG>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[12], act[13], act[14], act[15]}));
-            }
-          }
-        } else {
-          // fp16 mode (r5): the previous slice is rounded to half here -- compiler-visible conversions, so hipcc places the MFMA -> VALU wait
-          // states itself; gap 1 is two MFMAs behind the instruction that completed `act` -- and the partner's half leaves as 4 packed words
-          // (1 KiB per pair instead of 2)
-          if constexpr (M == 1) {
-            if constexpr (!FC1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // The previous slice is rounded to half here -- compiler-visible conversions, so hipcc places the MFMA -> VALU wait states itself; gap 1
+        // is two MFMAs behind the instruction that completed `act` (the MFMA-free last tick waits explicitly).  The partner's half leaves in
+        // gap 5: fp16 mode as 4 packed words (1 KiB per pair), bf16 mode as the fp32 accumulators (2 KiB; its relu must keep fp32's range).
+        if constexpr (M == 1) {
+          if constexpr (!FC1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xa[i] = pack_h16x2(act[2 * i], act[2 * i + 1]);
-          }
+          for (int i = 0; i < 4; ++i) xa[i] = pack_h16x2(act[2 * i], act[2 * i + 1]);
+        }
+        if constexpr (!BF) {
           if constexpr (M == 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) xb[i] = pack_h16x2(act[8 + 2 * i], act[9 + 2 * i]);
           }
           if constexpr (M == 5) {
             if (hb_write) lds_write16<HB_RAW>(hb_base + hb_slot * (2 * FRAG), u32x4_t{xb[0], xb[1], xb[2], xb[3]});
+          }
+        } else {
+          // (an inline-asm consumer of an MFMA result gets none of hipcc's wait states: five MFMAs of this tick lie between the instruction
+          //  that completed `act` and these stores, r4's finding at gap 0; the compiler-visible conversions of gap 1 carry the explicit ones)
+          if constexpr (M == 5) {
+            if (hb_write) {
+              lds_write16<HB_RAW>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[8], act[9], act[10], act[11]}));
+              lds_write16<HB_RAW + FRAG>(hb_base + hb_slot * (2 * FRAG), __builtin_bit_cast(u32x4_t, f32x4_t{act[12], act[13], act[14], act[15]}));
+            }
           }
         }
         if constexpr (FC1) {
@@ -487,28 +477,14 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
         }
         // GELU of registers 0..7 of the previous slice: 16 half values over gaps 0..11 (two in gaps 6..9); the fragment leaves in gap 11, so that
         // the counted wait of gap 17 has retired the write before the barrier of gap 18 tells the partner to read it
-        if constexpr (BF) {
-          if constexpr (M < 12) {
-            constexpr int H0 = M < 6 ? M : (M < 10 ? 6 + 2 * (M - 6) : 14 + (M - 10));
-            constexpr int NH = (M >= 6 && M < 10) ? 2 : 1;
-            sfor<NH>([&](auto I_) {
-              constexpr int HI = H0 + decltype(I_)::value;
-              constexpr int V = HI >> 1;
-              if constexpr ((HI & 1) == 0) { if constexpr (!(ABL & 1)) gm = gelu_erf_a(act[V]); }
-              else gv[V] = (ABL & 1) ? act[V] : gelu_erf_b(act[V], gm);
-            });
-          }
-          if constexpr (M == 11) { if (hb_write) lds_write16<0>(hb_base + hb_slot * FRAG, pack8<BF>(gv)); }
-        } else {
-          // packed-half GELU of this wave's four pairs: 44 instructions; the pairs turn into the B fragment in place
-          // (twelve blocks in gaps 2..11: two in gaps 2 and 7)
-          if constexpr (M >= 2 && M < 12 && !(ABL & 1)) {
-            constexpr int B0 = M < 3 ? 0 : (M < 8 ? M - 1 : M);  // first block of this gap: 0, 2, 3, 4, 5, 6, 8, 9, 10, 11
-            pk_gelu_op<B0>(pg, xa, kk);
-            if constexpr (M == 2 || M == 7) pk_gelu_op<B0 + 1>(pg, xa, kk);
-          }
-          if constexpr (M == 11) { if (hb_write) lds_write16<0>(hb_base + hb_slot * FRAG, u32x4_t{xa[0], xa[1], xa[2], xa[3]}); }
+        // packed-half GELU of this wave's four pairs: twelve blocks in gaps 2..11 (two in gaps 2 and 7); the pairs turn into the B fragment in place
+        if constexpr (M >= 2 && M < 12 && !(ABL & 1)) {
+          constexpr int B0 = M < 3 ? 0 : (M < 8 ? M - 1 : M);  // first block of this gap: 0, 2, 3, 4, 5, 6, 8, 9, 10, 11
+          const float a8[8] = {act[0], act[1], act[2], act[3], act[4], act[5], act[6], act[7]};
+          pk_gelu_op<B0, BF>(pg, xa, kk, a8);
+          if constexpr (M == 2 || M == 7) pk_gelu_op<B0 + 1, BF>(pg, xa, kk, a8);
         }
+        if constexpr (M == 11) { if (hb_write) lds_write16<0>(hb_base + hb_slot * FRAG, u32x4_t{xa[0], xa[1], xa[2], xa[3]}); }
         CS_SB();
       });
     };
@@ -702,7 +678,6 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
   h16x8_t hb0;       // B fragment of k-step 0 of the current slice (activated by the partner)
   u32x4_t hb1;       // B fragment of k-step 1: activated here, in the gaps of the k-step-0 MFMAs, from the partner's raw fp32 values
   f32x4_t rw[2];     // those raw values (registers 8..15 of the partner's fc1 accumulator of the slice)
-  GeluMid gm;
   u32x4_t xr;        // (fp16 mode) those values as 4 packed pairs, rounded by the partner
   unsigned hx[4];
   PkGelu pg;
@@ -739,31 +714,20 @@ __global__ __launch_bounds__(512, 2) void cs_panel_kernel(CsPanelParams p) {
       constexpr int F = (M + 6) % 24;  // (after the last tick: re-reads of this tick's first fragments, unused)
       if constexpr (!(ABL & 32)) lds_read1<((F / 12) * 24 + 12 + F % 12) * FRAG>(cur, w[M % 6]);
       // the slice's second fragment: 8 values = 16 half values over gaps 0..11 (two in gaps 6..9), packed pairwise
-      if constexpr (BF) {
-        if constexpr (M < 12) {
-          constexpr int H0 = M < 6 ? M : (M < 10 ? 6 + 2 * (M - 6) : 14 + (M - 10));  // first half-value index of this gap
-          constexpr int NH = (M >= 6 && M < 10) ? 2 : 1;
-          sfor<NH>([&](auto I_) {
-            constexpr int HI = H0 + decltype(I_)::value;
-            constexpr int V = HI >> 1;
-            const float x = rw[V >> 2][V & 3];
-            if constexpr ((HI & 1) == 0) { if constexpr (!(ABL & 1)) gm = gelu_erf_a(x); }
-            else {
-              const float y = (ABL & 1) ? x : gelu_erf_b(x, gm);
-              if constexpr ((V & 1) == 0) hb1[V >> 1] = __float_as_uint(y);  // parked in its own target word until the pair is complete
-              else hb1[V >> 1] = pack_o16x2<BF>(__uint_as_float(hb1[V >> 1]), y);
-            }
-          });
-        }
-      } else {
-        // packed-half GELU of the partner's four pairs (already halves): one block of four instructions per gap in gaps 0..11, in place
-        if constexpr (M == 0) {
+      // packed-half GELU of the partner's four pairs: one block per gap in gaps 0..11, in place (fp16 mode: the partner rounded them; bf16 mode:
+      // its fp32 accumulators arrive and are rounded here for the correction term, their relu stays fp32)
+      if constexpr (M == 0) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) hx[i] = xr[i];
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (BF) hx[i] = pack_h16x2(rw[i >> 1][2 * (i & 1)], rw[i >> 1][2 * (i & 1) + 1]);
+          else hx[i] = xr[i];
         }
-        if constexpr (M < 12 && !(ABL & 1)) pk_gelu_op<M>(pg, hx, kk);
-        if constexpr (M == 11) hb1 = u32x4_t{hx[0], hx[1], hx[2], hx[3]};
       }
+      if constexpr (M < 12 && !(ABL & 1)) {
+        const float a8[8] = {rw[0][0], rw[0][1], rw[0][2], rw[0][3], rw[1][0], rw[1][1], rw[1][2], rw[1][3]};
+        pk_gelu_op<M, BF>(pg, hx, kk, a8);
+      }
+      if constexpr (M == 11) hb1 = u32x4_t{hx[0], hx[1], hx[2], hx[3]};
       CS_SB();
     });
   };

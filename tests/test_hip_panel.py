@@ -91,3 +91,45 @@ def test_panel_bad_arguments():
     img = hh.panel_pack(None, None, w["w1"], w["g2"], w["w2"], w["ls2"])
     with pytest.raises(ValueError):
         hh.encoder_panel(x, o, img, None, w["b1"], w["b2"])  # out-projection without its bias
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_panel_full_chip_launches_repeat_bit_identically_under_concurrent_streams(bf16):
+    """The chip-filling launch of cfg-2 (48 images x 1370 rows = 514 panels, 2.008 rounds) three times on each of two streams at once, as the
+    forward's lanes and batches in flight run it: every run bit-identical to a launch that had the chip to itself.  The hand-offs between the
+    wave pairs (inline-asm LDS writes behind MFMA results, counted waits, unit barriers: ADVICE r4) are timing-sensitive by construction;
+    a hazard shows up as a run that differs.  Both operand modes (their GELU hand-offs differ: packed halves / fp32 accumulators)."""
+    from crossscore_amd import _lib
+    import hip_helpers as hh
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    M = 48 * 1370
+    x, o, w = _make(M, 21, dev)
+    assert lib.cs_debug_set_op_operand_dtype(1 if bf16 else 0) == 0
+    try:
+        img = hh.panel_pack(w["wo"], w["ls1"], w["w1"], w["g2"], w["w2"], w["ls2"])
+        ob = o.float().to(torch.bfloat16).view(torch.float16) if bf16 else o
+        x0 = x.clone()
+        u0 = hh.encoder_panel(x0, ob, img, w["bo"], w["b1"], w["b2"])
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        runs = []
+        for rep in range(3):
+            for st in (s1, s2):
+                with torch.cuda.stream(st):
+                    xr = x.clone()
+                    ur = hh.encoder_panel(xr, ob, img, w["bo"], w["b1"], w["b2"])
+                    runs.append((xr, ur))
+        torch.cuda.synchronize()
+        for xr, ur in runs:
+            assert torch.equal(xr, x0) and torch.equal(ur, u0)
+        # and the result is right (fp32 restatement with the same operand roundings; bf16: 8 significant bits)
+        r = (lambda t: t.to(torch.bfloat16).float()) if bf16 else _bf
+        x1 = x[:4096] + ob[:4096].view(torch.bfloat16 if bf16 else torch.float16).float() @ r(w["wo"] * w["ls1"][:, None]).T + w["bo"]
+        hdn = torch.nn.functional.gelu(r(_norm(x1)) @ r(w["w1"] * w["g2"][None, :]).T + w["b1"])
+        ref = x1 + r(hdn) @ r(w["w2"] * w["ls2"][:, None]).T + w["b2"]
+        err = (x0[:4096] - ref).abs()
+        assert float(err.mean()) < (2.4e-3 if bf16 else 3e-4) and float(err.max()) < (3.2e-2 if bf16 else 4e-3), (float(err.mean()), float(err.max()))
+    finally:
+        lib.cs_debug_set_op_operand_dtype(0)
