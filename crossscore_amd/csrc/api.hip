@@ -31,6 +31,7 @@ hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, hipStream_t 
 hipError_t cs_im2col_launch(const float* q, const float* refs, int N, int img0, h16_t* out, int I, int H, int W, int P, int Kp,
                             float* pmean, int bf, hipStream_t st);
 hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipStream_t st);
+hipError_t cs_ln_finalize_launch(const float* part, int M, int rows_padded, int sp, int C, float eps, float* stat, hipStream_t st);
 hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32, h16_t* obf,
                                int bf, hipStream_t st);
 hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
@@ -38,7 +39,7 @@ hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int
 hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, const float* pos, h16_t* xb, float* stats, int sp,
                               int bf, hipStream_t st);
 hipError_t cs_ln_fold_consts_launch(const h16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
-                                    float* s_out, float* c_out, hipStream_t st);
+                                    float* s_out, float* c_out, int bf, hipStream_t st);
 int cs_gemm_column_tiles(int N);
 hipError_t cs_pos_bicubic_launch(const float* pos, int G, int C, int gh, int gw, float grow, float* out, hipStream_t st);
 hipError_t cs_pe_bilinear_launch(const float* pe, int ph, int pw, int C, int gh, int gw, float* out, hipStream_t st);
@@ -123,6 +124,7 @@ struct cs_model {
   bool panel = false;   // encoder layers run as QKV GEMM + attention + ONE token-panel kernel (panel.hip; hidden == 384 only)
   float *ones = nullptr, *zeros = nullptr;  // [C]: layer 0's norm1 without gamma/beta (they are folded into its QKV projection)
   bool lnfold = false;  // encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass)
+  bool fold256 = false; // the same fold on the 256-tile GEMM (gemm256.hip LN = 1 / 2; r5): the default of the wide backbones (hidden 768 / 1024) for chunks of >= 256 rows
   int ln_sp = 0;        // partial-sum slots per row the producing epilogues write (4 per column tile)
   std::vector<void*> owned;  // device allocations of packed weights
   // packed
@@ -212,6 +214,7 @@ struct Plan {
   // encoder chunk buffers, one set per lane
   float* x[CS_MAX_LANES]; h16_t* u[CS_MAX_LANES]; h16_t* r1[CS_MAX_LANES];
   h16_t* ob[CS_MAX_LANES]; float* stats[CS_MAX_LANES];  // LayerNorm fold: attention output, per-row partial sums
+  float* lnstat[CS_MAX_LANES];                           // fold256: finalised (mean, rstd) per row, whole 256-row tiles
   float* pmean[CS_MAX_LANES];                            // per-patch channel means removed by im2col
   // decoder
   float *xq, *y, *lse; h16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
@@ -247,9 +250,11 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
     p.x[l] = a.take<float>(Mc * C);
     p.u[l] = a.take<h16_t>(Mc * C);
     p.r1[l] = a.take<h16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * (size_t)m->qkv_n, (size_t)p.Ic * p.Np * m->Kp)));
-    p.ob[l] = a.take<h16_t>(m->lnfold ? Mc * C : 0);
+    p.ob[l] = a.take<h16_t>(m->lnfold || m->fold256 ? Mc * C : 0);
     p.pmean[l] = a.take<float>((size_t)p.Ic * p.Np * 4);
-    p.stats[l] = a.take<float>(m->lnfold ? Mc * (size_t)m->ln_sp * 2 : 0);
+    const size_t Mpad = (Mc + 255) / 256 * 256;
+    p.stats[l] = a.take<float>(m->lnfold ? Mc * (size_t)m->ln_sp * 2 : (m->fold256 ? Mpad * (C / 64) * 2 : 0));
+    p.lnstat[l] = a.take<float>(m->fold256 ? Mpad * 2 : 0);
   }
   p.xq = a.take<float>(M * C);
   p.y = a.take<float>(M * C);
@@ -462,6 +467,8 @@ cs_handle cs_create(const cs_config* cfg) {
   m->lnfold = c.ln_fold == 1 && (m->ln_sp == 4 || m->ln_sp == 8 || m->ln_sp == 16);
   // default for ViT-S: out-proj + norm2 + MLP + next norm1 in one launch per layer, the 4C hidden never leaves the registers
   m->panel = c.enc_fused != 1 && !m->lnfold && cs_panel_supported(c.hidden, c.mlp_ratio);
+  // wide backbones (r5): the encoder's LayerNorms ride in the 256-tile GEMM's epilogues; ln_fold = 2 keeps the separate LayerNorm launches
+  m->fold256 = c.ln_fold == 0 && !m->panel && c.hidden >= 512 && c.hidden % 256 == 0 && (c.mlp_ratio * c.hidden) % 256 == 0;
   return m;
 }
 
@@ -610,7 +617,7 @@ int cs_finalize(cs_handle h) {
     const size_t NQ = (size_t)h->qkv_n;  // >= 3C: the padding rows of the weights and the padding entries of the bias / fold vectors are zero
     ALLOC_BF(wqkv, NQ * C) ALLOC_F(bqkv, NQ)
     if (NQ > 3 * C) { HIPCHK(hipMemset(wqkv + 3 * C * C, 0, (NQ - 3 * C) * C * sizeof(h16_t))); HIPCHK(hipMemset(bqkv + 3 * C, 0, (NQ - 3 * C) * sizeof(float))); }
-    const bool fold = h->lnfold || h->panel;
+    const bool fold = h->lnfold || h->panel || h->fold256;
     const float* g1 = fold ? n1w->d : nullptr;  // LayerNorm gamma folded into the columns of the consuming projection
     const float* g2 = fold ? n2w->d : nullptr;
     if (int r = pack(qw->d, (int)C, (int)C, (int)C, wqkv, qs_enc, g1)) return r;
@@ -637,14 +644,14 @@ int cs_finalize(cs_handle h) {
       const float* bsrc[3] = {qb->d, kb->d, vb->d};
       for (int part = 0; part < 3; ++part)
         HIPCHK(cs_ln_fold_consts_launch(wqkv + (size_t)part * C * C, (int)C, wsrc[part], n1b->d, bsrc[part], (int)C, (int)C,
-                                        sq + part * C, cq + part * C, st));
+                                        sq + part * C, cq + part * C, c.operand_dtype, st));
       HIPCHK(cs_vec_mul_launch(cq, qs_enc, cq, (int)C, st));  // c = b + W beta of the Q rows carries the softmax scale too
-      HIPCHK(cs_ln_fold_consts_launch(w1, (int)C, f1w->d, n2b->d, f1b->d, (int)F, (int)C, s1v, c1v, st));
+      HIPCHK(cs_ln_fold_consts_launch(w1, (int)C, f1w->d, n2b->d, f1b->d, (int)F, (int)C, s1v, c1v, c.operand_dtype, st));
       L.s_qkv = sq; L.c_qkv = cq; L.s_1 = s1v; L.c_1 = c1v;
     }
   }
   { NEED(g, "backbone.layernorm.weight", C) NEED(b, "backbone.layernorm.bias", C) h->lnfg = g->d; h->lnfb = b->d; }
-  if (h->panel) {
+  if (h->panel || h->fold256) {
     ALLOC_F(on, (size_t)C) ALLOC_F(ze, (size_t)C)
     std::vector<float> hv((size_t)C, 1.0f);
     HIPCHK(hipMemcpy(on, hv.data(), (size_t)C * sizeof(float), hipMemcpyHostToDevice));
@@ -909,6 +916,45 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         tap_layer(l);
         continue;
       }
+      if (h->fold256 && Mc >= 256) {
+        // Wide backbones (r5): LayerNorm folded into the 256-tile GEMM's epilogues.  The residual epilogues (out-projection, fc2) also write
+        // u = 16-bit(x) and per-row partial sums, a row-statistics kernel (one thread per row) turns them into (mean, rstd), and the consuming
+        // projection (QKV, fc1) applies rstd * (acc - mean * s[n]) + c[n].  No LayerNorm pass over the fp32 stream except layer 0's norm1
+        // (its rows come from the patch embedding).  Chunks below 256 rows (tiny images) take the plain path below.
+        const int sp = C / 64, Mpad = (Mc + 255) / 256 * 256;
+        float* part = p.stats[slot];
+        float* stat = p.lnstat[slot];
+        auto row_stats = [&]() { L.begin(32, 0); L.misc(cs_ln_finalize_launch(part, Mc, Mpad, sp, C, 1e-6f, stat, s), "ln_stats"); L.end(); };
+        auto consumer = [&](const h16_t* W, const float* cvec, const float* svec, h16_t* out, int n, int epi) {
+          CsGemmParams g = gp(u, C, W, C, Mc, n, C, cvec, out, n);
+          g.col_s = svec; g.ln_part = stat; g.ln_sp = 1; g.ln_eps = 1e-6f;
+          L.gemm(g, epi);
+        };
+        if (l == 0) {
+          L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, h->ones, h->zeros, 1e-6f, nullptr, u, bf, s), "ln1"); L.end();
+          L.gemm(gp(u, C, E.Wqkv, C, Mc, NQ, C, E.c_qkv, r1, NQ), CS_EPI_BIAS_F16);  // (gamma is in the packed weights, beta in c)
+        } else {
+          consumer(E.Wqkv, E.c_qkv, E.s_qkv, r1, NQ, CS_EPI_LN_F16);
+        }
+        a.O = ob;
+        L.attn(a, enc_dh, ic);
+        {
+          CsGemmParams g = gp(ob, C, E.Wo, C, Mc, C, C, E.bo, x, C);
+          g.resid = x; g.ldr = C; g.out_f16 = u; g.stats_out = part; g.stats_sp = sp;
+          L.gemm(g, CS_EPI_RESID_F32_LN);
+        }
+        row_stats();
+        consumer(E.W1, E.c_1, E.s_1, r1, F, CS_EPI_LN_GELU_F16);
+        {
+          CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);
+          g.resid = x; g.ldr = C;
+          if (!last) { g.out_f16 = u; g.stats_out = part; g.stats_sp = sp; }
+          L.gemm(g, last ? CS_EPI_RESID_F32 : CS_EPI_RESID_F32_LN);  // the final LayerNorm reads the fp32 stream
+        }
+        if (!last) row_stats();
+        tap_layer(l);
+        continue;
+      }
       if (fold) {
         // u holds fp16(x) and `stats` the per-row partial sums, both written by the epilogue that produced x: LayerNorm is
         // applied inside the consuming projection's epilogue (CS_EPI_LN_*), there is no separate LN pass over x
@@ -938,8 +984,11 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         tap_layer(l);
         continue;
       }
-      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln1g, E.ln1b, 1e-6f, nullptr, u, bf, s), "ln1"); L.end();
-      L.gemm(gp(u, C, E.Wqkv, C, Mc, NQ, C, E.bqkv, r1, NQ), CS_EPI_BIAS_F16);
+      // (a fold256 handle's chunk of fewer than 256 rows lands here with gamma folded into its packed weights and beta into the c vectors:
+      //  LayerNorm without gamma / beta then, as in the panel path)
+      const bool pf = h->fold256;
+      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, pf ? h->ones : E.ln1g, pf ? h->zeros : E.ln1b, 1e-6f, nullptr, u, bf, s), "ln1"); L.end();
+      L.gemm(gp(u, C, E.Wqkv, C, Mc, NQ, C, pf ? E.c_qkv : E.bqkv, r1, NQ), CS_EPI_BIAS_F16);
       a.O = u;
       L.attn(a, enc_dh, ic);
       {
@@ -947,8 +996,8 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         g.resid = x; g.ldr = C;
         L.gemm(g, CS_EPI_RESID_F32);
       }
-      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, E.ln2g, E.ln2b, 1e-6f, nullptr, u, bf, s), "ln2"); L.end();
-      L.gemm(gp(u, C, E.W1, C, Mc, F, C, E.b1, r1, F), CS_EPI_BIAS_GELU_F16);
+      L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, pf ? h->ones : E.ln2g, pf ? h->zeros : E.ln2b, 1e-6f, nullptr, u, bf, s), "ln2"); L.end();
+      L.gemm(gp(u, C, E.W1, C, Mc, F, C, pf ? E.c_1 : E.b1, r1, F), CS_EPI_BIAS_GELU_F16);
       {
         CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);
         g.resid = x; g.ldr = C;
@@ -1385,6 +1434,12 @@ int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const floa
   return 0;
 }
 
+int cs_op_ln_finalize(const float* part, int M, int rows_padded, int sp, int C, float eps, float* stat, cs_stream stream) {
+  if (!part || !stat || M <= 0 || rows_padded < M || sp <= 0 || C <= 0) return fail(CS_ERR_BAD_ARG, "ln_finalize: bad arguments");
+  HIPCHK(cs_ln_finalize_launch(part, M, rows_padded, sp, C, eps, stat, (hipStream_t)stream));
+  return 0;
+}
+
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream) {
   if (!x || !out || I <= 0 || P <= 0 || H < P || W < P || Kp % 8 || Kp < 3 * P * P) return fail(CS_ERR_BAD_ARG, "im2col: bad arguments");
   HIPCHK(cs_im2col_launch(x, nullptr, 0, 0, out, I, H, W, P, Kp, nullptr, g_op_bf16, (hipStream_t)stream));
@@ -1526,7 +1581,7 @@ int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, c
 int cs_op_ln_fold_consts(const uint16_t* w_packed, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
                          float* s_out, float* c_out, cs_stream stream) {
   if (!w || !beta || !c_out || (w_packed && (!s_out || ldp < K)) || N <= 0 || K <= 0) return fail(CS_ERR_BAD_ARG, "ln_fold_consts: bad arguments");
-  HIPCHK(cs_ln_fold_consts_launch(w_packed, ldp, w, beta, bias, N, K, s_out, c_out, (hipStream_t)stream));
+  HIPCHK(cs_ln_fold_consts_launch(w_packed, ldp, w, beta, bias, N, K, s_out, c_out, g_op_bf16, (hipStream_t)stream));
   return 0;
 }
 

@@ -374,13 +374,13 @@ __global__ void pack_f16_kernel(const float* __restrict__ w, int rows, int K, h1
 //   c[n] = bias[n] + sum_k beta[k] W[n][k]   in fp32 from the original weights
 __global__ __launch_bounds__(256) void ln_fold_consts_kernel(const h16_t* __restrict__ wp, int ldp, const float* __restrict__ w,
                                                              const float* __restrict__ beta, const float* __restrict__ bias, int N,
-                                                             int K, float* __restrict__ s_out, float* __restrict__ c_out) {
+                                                             int K, float* __restrict__ s_out, float* __restrict__ c_out, int bf) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   float s = 0.f, c = 0.f;
   for (int k = lane; k < K; k += 64) {
-    if (wp) s += h2f(wp[(size_t)n * ldp + k]);
+    if (wp) s += o2f(wp[(size_t)n * ldp + k], bf);  // (the packed weights' own type: bf16 handles sum bf16 values)
     c += beta[k] * w[(size_t)n * K + k];
   }
   s = wave_sum(s);
@@ -469,7 +469,30 @@ __global__ __launch_bounds__(256) void score_check_kernel(const float* __restric
 
 }  // namespace
 
+// Row statistics of the LayerNorm folded into the 256-tile GEMM's epilogues (gemm256.hip): the producing epilogue left `sp` partial (sum, sum of
+// squares) pairs per row, one per 64-column wave slice; a row's (mean, rstd) = biased variance, eps inside the root (HF modeling_dinov2.py:361-380
+// LayerNorm).  One thread per row; rows [M, rows_padded) (the consumer fetches whole 256-row tiles) get (0, 0).
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int M, int rows_padded, int sp, float inv_c, float eps,
+                                                          float* __restrict__ stat) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= rows_padded) return;
+  float2 o = make_float2(0.f, 0.f);
+  if (m < M) {
+    const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)m * sp;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < sp; ++k) { const float2 v = pp[k]; a += v.x; b += v.y; }
+    const float mu = a * inv_c;
+    o = make_float2(mu, 1.0f / sqrtf(fmaxf(b * inv_c - mu * mu, 0.f) + eps));
+  }
+  reinterpret_cast<float2*>(stat)[m] = o;
+}
+
 extern "C" {
+
+hipError_t cs_ln_finalize_launch(const float* part, int M, int rows_padded, int sp, int C, float eps, float* stat, hipStream_t st) {
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows_padded + 255) / 256), dim3(256), 0, st, part, M, rows_padded, sp, 1.0f / (float)C, eps, stat);
+  return hipGetLastError();
+}
 
 hipError_t cs_score_check_launch(const float* score, size_t n, unsigned* counter, hipStream_t st) {
   const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
@@ -533,8 +556,8 @@ hipError_t cs_cls_rows_launch(float* x, int I, int T, int C, const float* cls, c
 }
 
 hipError_t cs_ln_fold_consts_launch(const h16_t* wp, int ldp, const float* w, const float* beta, const float* bias, int N, int K,
-                                    float* s_out, float* c_out, hipStream_t st) {
-  hipLaunchKernelGGL(ln_fold_consts_kernel, dim3((N + 3) / 4), dim3(256), 0, st, wp, ldp, w, beta, bias, N, K, s_out, c_out);
+                                    float* s_out, float* c_out, int bf, hipStream_t st) {
+  hipLaunchKernelGGL(ln_fold_consts_kernel, dim3((N + 3) / 4), dim3(256), 0, st, wp, ldp, w, beta, bias, N, K, s_out, c_out, bf);
   return hipGetLastError();
 }
 

@@ -759,7 +759,11 @@ namespace {
 
 // Host-side shape contract (checked here so a bad call fails loudly instead of faulting on the GPU).
 extern "C" int cs_gemm_column_tiles(int N);
+extern "C" int cs_gemm256_supported(const CsGemmParams* p, int epi);
 extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
+  // the LayerNorm-folded forms of the 256-tile kernel (gemm256.hip) have their own statistics layout: finalised (mean, rstd) rows on the consumer
+  // side (ln_sp == 1), N / 64 partial slots per row on the producer side; both operand types
+  const bool ln256 = epi >= CS_EPI_LN_F16 && cs_gemm256_supported(p, epi);
   if (p->M <= 0 || p->N <= 0 || p->K <= 0) return "gemm: empty shape";
   if (p->K % 64) return "gemm: K must be a multiple of 64";
   if (p->N % 4 || p->ldc % 4) return "gemm: N and ldc must be multiples of 4";
@@ -767,13 +771,13 @@ extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
   if (p->lda % 8 || p->ldw % 8) return "gemm: lda/ldw must be multiples of 8 (16-byte rows)";
   if (p->lda < p->K || p->ldw < p->K) return "gemm: lda/ldw smaller than K";
   if (!p->A || !p->W || !p->out) return "gemm: null operand";
-  if (p->bf16 && epi >= CS_EPI_LN_F16) return "gemm: the LayerNorm-folded epilogues are built for fp16 operands only";
+  if (p->bf16 && epi >= CS_EPI_LN_F16 && !ln256) return "gemm: the 128-row kernel's LayerNorm-folded epilogues are built for fp16 operands only";
   if (p->scale) return "gemm: a per-column scale is folded into the packed weights (cs_op_pack_f16 row_scale), it is not an epilogue operand";
   if ((epi == CS_EPI_RESID_F32 || epi == CS_EPI_RESID_F32_LN) && p->resid && p->ldr % 4) return "gemm: ldr must be a multiple of 4";
   if (epi == CS_EPI_RESID_F32_LN && (!p->out_f16 || !p->stats_out)) return "gemm: RESID_F32_LN needs out_f16 and stats_out";
-  if ((epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32) && p->stats_out && p->stats_sp != 4 * cs_gemm_column_tiles(p->N))
+  if (!ln256 && (epi == CS_EPI_RESID_F32_LN || epi == CS_EPI_PATCH_F32) && p->stats_out && p->stats_sp != 4 * cs_gemm_column_tiles(p->N))
     return "gemm: stats_sp must be 4 x the number of column tiles";
-  if ((epi == CS_EPI_LN_F16 || epi == CS_EPI_LN_GELU_F16) &&
+  if (!ln256 && (epi == CS_EPI_LN_F16 || epi == CS_EPI_LN_GELU_F16) &&
       (!p->ln_part || !p->col_s || !p->bias || (p->ln_sp != 4 && p->ln_sp != 8 && p->ln_sp != 16) || p->N % 8 || p->ldc % 8))
     return "gemm: LayerNorm-folded epilogue needs ln_part, col_s, bias (= c), ln_sp in {4,8,16}";
   if (epi == CS_EPI_PATCH_F32 && (!p->pos || p->Np <= 0 || p->M % p->Np)) return "gemm: bad patch epilogue params";
@@ -787,7 +791,6 @@ extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
 extern "C" int cs_gemm_dbg_set(long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cs_dbg), &buf, sizeof(buf)); }
 #endif
 
-extern "C" int cs_gemm256_supported(const CsGemmParams* p, int epi);
 extern "C" hipError_t cs_gemm256_launch(const CsGemmParams* p, int epi, int bf16, hipStream_t st);
 
 extern "C" hipError_t cs_gemm_launch(const CsGemmParams* p0, int epi, hipStream_t stream) {

@@ -26,6 +26,17 @@
 // The MFMA takes the W fragment as its first operand, so a lane owns 4 consecutive output columns of one row; the epilogue goes
 // through a wave-private LDS patch (inline-asm ds ops: the compiler must not order them against the LDS-DMA in flight) and stores
 // whole 128-byte lines; the bias vector lives in LDS and is the accumulators' initial value.
+//
+// LayerNorm folded into the epilogues (r5; ViT-B's encoder, no separate LayerNorm pass over the fp32 residual stream; HF modeling_dinov2.py:361-380):
+//   LN = 2, producer (residual epilogue: out-projection, fc2): besides the fp32 rows it writes their 16-bit copy (the consuming projection's A
+//           operand, UN-normalised) and, per row and 64-column wave slice, the partial (sum, sum of squares) of the new fp32 values
+//           [rows][N / 64][2]; cs_ln_finalize_kernel (elementwise.hip) turns the partials of a row into (mean, rstd).
+//   LN = 1, consumer (QKV, fc1 [+ GELU]): out = rstd[m] * (acc - mean[m] * s[n]) + c[n] with W' = W * gamma packed, s[n] = sum_k W'[n][k],
+//           c[n] = b[n] + sum_k beta[k] W[n][k] (cs_finalize).  A wave's 128 (mean, rstd) pairs and its 64 s / c values travel into its
+//           private patch by three LDS-DMA instructions at the START of the tile (they land under the K loop: the loop's counted waits retire
+//           them, being older than everything those waits leave in flight) and are read into registers before the patch is reused.
+//   fp16(x) instead of fp16(LN(x)) as the MFMA operand: the same RELATIVE rounding step per element (the row's 1/sigma scales value and error
+//   alike), so an outlier channel at 300 in a row of sigma 20 carries 0.125 / 20 = 6e-3 against 3.9e-3 for the rounded normalised value 15.
 #include "cs_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -72,6 +83,14 @@ template <int OFF>
 __device__ __forceinline__ void pw16(unsigned addr, f32x4_t v) { asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
 template <int OFF>
 __device__ __forceinline__ void pr16(unsigned addr, f32x4_t& v) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void pr8(unsigned addr, u32x2_t& v) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory"); }
+// x + (the value SHR lanes below in the same 16-lane DPP row; 0 from outside the row): three of them leave the sum of 8 consecutive lanes in the last
+template <int SHR>
+__device__ __forceinline__ float dpp_row_shr_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + SHR, 0xf, 0xf, true);
+  return v + __int_as_float(moved);
+}
 // residual rows (fp32 epilogue): 16 bytes per lane at sbase + voff by inline asm, so that the compiler neither counts nor waits for the
 // load (its own wait would be vmcnt(0): every store of the previous step); the epilogue's counted waits cover it
 __device__ __forceinline__ void gl16(f32x4_t& r, unsigned voff, const float* sbase) {
@@ -81,9 +100,13 @@ __device__ __forceinline__ void gl16(f32x4_t& r, unsigned voff, const float* sba
 __device__ __forceinline__ void touch(f32x4_t& r) { asm volatile("; GL16_USE %0" : "+v"(r)); }
 
 // RES: the fp32 epilogue adds residual rows (compile time: a run-time test would put every in-flight residual register behind phi copies)
-template <int EPI, bool BF, bool RES>
+// LN: 0 plain epilogues, 1 LayerNorm-folded consumer (16-bit epilogues), 2 LayerNorm producer (residual epilogue)
+template <int EPI, bool BF, bool RES, int LN = 0>
 __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
   constexpr bool kHalf = EPI <= CS_EPI_BIAS_LEAKY_F16;
+  constexpr bool kLNc = LN == 1, kLNp = LN == 2;
+  static_assert(!kLNc || kHalf, "gemm256: the LayerNorm-folded consumer has a 16-bit output");
+  static_assert(!kLNp || RES, "gemm256: the LayerNorm producer is the residual epilogue");
   static_assert(!RES || EPI == CS_EPI_RESID_F32, "gemm256: residual rows belong to the fp32 epilogue");
   static_assert(kHalf || EPI == CS_EPI_RESID_F32, "gemm256: bias->16-bit and residual fp32 epilogues only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
   // ---- bias vector -> LDS once per block (plain accesses: nothing else is in flight yet) ----
   for (int i = tid * 4; i < min(p.N, G_NMAX); i += 2048) {
     f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + i);
+    if (p.bias && !kLNc) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + i);  // (consumer: `bias` is c[n], applied behind the row scale)
     *reinterpret_cast<f32x4_t*>(smem + G_BIAS + i * 4) = b4;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -222,6 +245,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
   //      these six registers would be spilled around the K loop (which runs at the 256-register limit) ----
   const unsigned lds0 = (unsigned)(size_t)CS_LDS_PTR(smem);
   unsigned pw_addr = 0, pr_addr = 0, bias_addr = 0;
+  [[maybe_unused]] unsigned ln_a = 0, ln_b = 0;  // consumer: this lane's addresses of its rows' (mean, rstd) and its columns' s / c in the patch
   int rrow = 0, rch = 0;
   auto seam_addresses = [&]() {
     int ln = lane;
@@ -231,10 +255,26 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     rrow = ln >> 3; rch = ln & 7;
     pr_addr = patch + rrow * G_PROW + rch * 16;                            // row segments: 8 rows x 8 chunks per read (+ 8 rows: + 8 * G_PROW)
     bias_addr = lds0 + G_BIAS + (wn * 64 + 4 * (ln >> 4)) * 4;
+    if constexpr (kLNc) { ln_a = patch + (ln & 15) * 8; ln_b = patch + 1024 + (ln >> 4) * 16; }
+  };
+  // consumer: rows [m0 + 128 wm, + 128) x (mean, rstd) (1 KiB; ln_part holds whole 256-row tiles), s and c of columns [n0 + 64 wn, + 64)
+  // (256 B each) -> the wave's patch [0, 1024) | [1024, 1280) | [1280, 1536)
+  auto ln_fetch = [&](int m0, int n0) {
+    if constexpr (kLNc) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      char* patch = smem + G_PATCH0 + wv * G_PATCH;
+      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.ln_part + ((size_t)(m0 + wm * 128) + 2 * ln) * 2), CS_LDS_PTR(patch), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.col_s + n0 + wn * 64 + ln), CS_LDS_PTR(patch + 1024), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(CS_GLOBAL_PTR(p.bias + n0 + wn * 64 + ln), CS_LDS_PTR(patch + 1280), 4, 0, 0);
+    }
   };
   auto init_acc = [&](int n0) {  // accumulators start at the bias of their columns (16 j + 4 cq .. + 3 of the wave's 64)
     f32x4_t b4[4];
-    if (p.N <= G_NMAX) {
+    if constexpr (kLNc) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b4[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    } else if (p.N <= G_NMAX) {
       const unsigned a = bias_addr + n0 * 4;
       pr16<0>(a, b4[0]); pr16<64>(a, b4[1]); pr16<128>(a, b4[2]); pr16<192>(a, b4[3]);
       G_LGKM(0);
@@ -294,6 +334,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     tile_of(idx, cm0, cn0);
     seam_addresses();
     init_acc(cn0);
+    ln_fetch(cm0, cn0);
     ktile(IC<0>{}, true, false);
     ktile(IC<1>{}, false, false);
     for (int t = 2; t < T; t += 2) {
@@ -310,11 +351,31 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
     const int row_w = cm0 + wm * 128;       // first row of the wave tile
     const int col_w = cn0 + wn * 64;        // first column
     if constexpr (kHalf) {
+      [[maybe_unused]] f32x4_t s4[4], c4[4];
+      [[maybe_unused]] float rstd[8], nm[8];
+      if constexpr (kLNc) {
+        // (mean, rstd) of this lane's eight rows 16 i + fr and s / c of its sixteen columns 16 j + 4 cq ..: out of the patch before it is reused
+        u32x2_t st8[8];
+        pr8<0>(ln_a, st8[0]); pr8<128>(ln_a, st8[1]); pr8<256>(ln_a, st8[2]); pr8<384>(ln_a, st8[3]);
+        pr8<512>(ln_a, st8[4]); pr8<640>(ln_a, st8[5]); pr8<768>(ln_a, st8[6]); pr8<896>(ln_a, st8[7]);
+        pr16<0>(ln_b, s4[0]); pr16<64>(ln_b, s4[1]); pr16<128>(ln_b, s4[2]); pr16<192>(ln_b, s4[3]);
+        pr16<256>(ln_b, c4[0]); pr16<320>(ln_b, c4[1]); pr16<384>(ln_b, c4[2]); pr16<448>(ln_b, c4[3]);
+        G_LGKM(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          rstd[i] = __uint_as_float(st8[i][1]);
+          nm[i] = -__uint_as_float(st8[i][0]) * rstd[i];
+        }
+      }
       auto put = [&](auto I_) {
         constexpr int i = decltype(I_)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if constexpr (kLNc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd[i], v[r], fmaf(nm[i], s4[j][r], c4[j][r]));
+          }
           if constexpr (EPI == CS_EPI_BIAS_GELU_F16) gelu_erf4(v);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -351,7 +412,12 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
       // step t's rows are needed the younger instructions number G_RCNT(t) below (the DMA pieces issued above are older: they land first).
       // The loads' destination registers are written when the data arrives, not at the asm statement: nothing may touch them in between
       // (tools/asm_audit_gl.py checks the build's .s for that).
-#define G_RCNT(t) ((t) <= 3 ? 6 + 2 * (t) : (t) <= 12 ? 12 : 12 - 2 * ((t) - 12))
+      // With the LayerNorm outputs a step issues 4 stores (fp32 rows, their 16-bit copies) and every second step (nh == 1) 2 more (partial sums):
+      // the same bookkeeping with |S_k| = 4 + 2 (k & 1) instead of 2.
+#define G_SK(k) (kLNp ? 4 + 2 * ((k) & 1) : 2)
+#define G_RCNT(t) ((t) == 0 ? 6 : (t) == 1 ? 6 + G_SK(0) : (t) == 2 ? 6 + G_SK(0) + G_SK(1) : (t) == 3 ? 6 + G_SK(0) + G_SK(1) + G_SK(2) : \
+                   (t) <= 12 ? 6 + G_SK((t) - 3) + G_SK((t) - 2) + G_SK((t) - 1) :                                                          \
+                   (t) == 13 ? 4 + G_SK(10) + G_SK(11) + G_SK(12) : (t) == 14 ? 2 + G_SK(11) + G_SK(12) + G_SK(13) : G_SK(12) + G_SK(13) + G_SK(14))
       [[maybe_unused]] f32x4_t ra0, ra1, rb0, rb1, rc0, rc1, rd0, rd1;
       auto rload = [&](auto S_, f32x4_t& r0, f32x4_t& r1) {
         constexpr int st = decltype(S_)::value;
@@ -369,14 +435,36 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
         pw16<64>(pw_addr, acc[i][2 * nh + 1]);
       };
       f32x4_t seg0, seg1;
+      [[maybe_unused]] float sa0 = 0.f, sb0 = 0.f, sa1 = 0.f, sb1 = 0.f;  // partial (sum, sum of squares) of this lane's columns, rows rrow / rrow + 8
       auto get = [&]() { pr16<0>(pr_addr, seg0); pr16<8 * G_PROW>(pr_addr, seg1); };
       auto out = [&](auto S_, f32x4_t& r0, f32x4_t& r1) {
         constexpr int st = decltype(S_)::value;
         constexpr int i = st >> 1, nh = st & 1;
         if constexpr (RES) { touch(r0); touch(r1); seg0 += r0; seg1 += r1; }
-        float* o = reinterpret_cast<float*>(p.out) + (size_t)(row_w + 16 * i + rrow) * p.ldc + col_w + nh * 32 + rch * 4;
-        if (row_w + 16 * i + rrow < p.M) *reinterpret_cast<f32x4_t*>(o) = seg0;
-        if (row_w + 16 * i + 8 + rrow < p.M) *reinterpret_cast<f32x4_t*>(o + (size_t)8 * p.ldc) = seg1;
+        const int m_a = row_w + 16 * i + rrow, m_b = m_a + 8;
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)m_a * p.ldc + col_w + nh * 32 + rch * 4;
+        if (m_a < p.M) *reinterpret_cast<f32x4_t*>(o) = seg0;
+        if (m_b < p.M) *reinterpret_cast<f32x4_t*>(o + (size_t)8 * p.ldc) = seg1;
+        if constexpr (kLNp) {
+          h16_t* o16 = p.out_f16 + (size_t)m_a * p.ldc + col_w + nh * 32 + rch * 4;
+          if (m_a < p.M) *reinterpret_cast<u32x2_t*>(o16) = u32x2_t{pack_o16x2<BF>(seg0[0], seg0[1]), pack_o16x2<BF>(seg0[2], seg0[3])};
+          if (m_b < p.M) *reinterpret_cast<u32x2_t*>(o16 + (size_t)8 * p.ldc) = u32x2_t{pack_o16x2<BF>(seg1[0], seg1[1]), pack_o16x2<BF>(seg1[2], seg1[3])};
+          const float a0 = (seg0[0] + seg0[1]) + (seg0[2] + seg0[3]), a1 = (seg1[0] + seg1[1]) + (seg1[2] + seg1[3]);
+          const float b0 = fmaf(seg0[0], seg0[0], fmaf(seg0[1], seg0[1], fmaf(seg0[2], seg0[2], seg0[3] * seg0[3])));
+          const float b1 = fmaf(seg1[0], seg1[0], fmaf(seg1[1], seg1[1], fmaf(seg1[2], seg1[2], seg1[3] * seg1[3])));
+          if constexpr (nh == 0) { sa0 = a0; sb0 = b0; sa1 = a1; sb1 = b1; }
+          else {
+            // both 32-column halves of the wave's 64 columns are in: sum over the eight lanes of a row (one DPP row holds two rows' lanes), the
+            // row's last lane (rch == 7) stores slot (column tile) * 4 + wn
+            float t0 = sa0 + a0, u0 = sb0 + b0, t1 = sa1 + a1, u1 = sb1 + b1;
+            t0 = dpp_row_shr_add<1>(t0); u0 = dpp_row_shr_add<1>(u0); t1 = dpp_row_shr_add<1>(t1); u1 = dpp_row_shr_add<1>(u1);
+            t0 = dpp_row_shr_add<2>(t0); u0 = dpp_row_shr_add<2>(u0); t1 = dpp_row_shr_add<2>(t1); u1 = dpp_row_shr_add<2>(u1);
+            t0 = dpp_row_shr_add<4>(t0); u0 = dpp_row_shr_add<4>(u0); t1 = dpp_row_shr_add<4>(t1); u1 = dpp_row_shr_add<4>(u1);
+            const int slot = (cn0 / G_BN) * 4 + wn;
+            if (rch == 7 && m_a < p.M) *reinterpret_cast<float2*>(p.stats_out + ((size_t)m_a * p.stats_sp + slot) * 2) = make_float2(t0, u0);
+            if (rch == 7 && m_b < p.M) *reinterpret_cast<float2*>(p.stats_out + ((size_t)m_b * p.stats_sp + slot) * 2) = make_float2(t1, u1);
+          }
+        }
       };
       const bool full = cm0 + G_BM <= p.M;  // a ragged tile's masked stores make the store count unknown: its waits are vmcnt(0)
       if constexpr (RES) { rload(IC<0>{}, ra0, ra1); rload(IC<1>{}, rb0, rb1); rload(IC<2>{}, rc0, rc1); rload(IC<3>{}, rd0, rd1); }
@@ -395,6 +483,7 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
       if constexpr (RES) { if (full) G_VMCNT(G_RCNT(15)); else G_VMCNT(0); }
       G_SB(); out(IC<15>{}, rd0, rd1);
 #undef G_RCNT
+#undef G_SK
     }
     G_SB();
     if (wm == 1) bar();  // (the last K tile's final barrier of the second half)
@@ -414,13 +503,13 @@ __global__ __launch_bounds__(512, 2) void cs_gemm256_kernel(CsGemmParams p) {
 int g_enabled = 1;
 int g_kmin = 384;  // cs_debug_gemm256_kmin
 
-template <int EPI, bool BF, bool RES = false>
+template <int EPI, bool BF, bool RES = false, int LN = 0>
 hipError_t launch256(const CsGemmParams& p, hipStream_t st) {
   static bool attr_done[16] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm256_kernel<EPI, BF, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_gemm256_kernel<EPI, BF, RES, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;
     attr_done[dev] = true;
   }
@@ -436,7 +525,7 @@ hipError_t launch256(const CsGemmParams& p, hipStream_t st) {
   const int need = ((tiles_m + 7) / 8) * tiles_n * 8;
   if (grid > need) grid = need;
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((cs_gemm256_kernel<EPI, BF, RES>), dim3(grid), dim3(512), G_LDS, st, p);
+  hipLaunchKernelGGL((cs_gemm256_kernel<EPI, BF, RES, LN>), dim3(grid), dim3(512), G_LDS, st, p);
   return hipGetLastError();
 }
 
@@ -457,14 +546,21 @@ void cs_debug_gemm256_kmin(int k) { g_kmin = k > 0 ? k : 384; }
 // K >= 384, the plain epilogues.
 int cs_gemm256_supported(const CsGemmParams* p, int epi) {
   if (!g_enabled) return 0;
-  if (epi > CS_EPI_RESID_F32) return 0;
+  // LayerNorm-folded forms (r5): consumers read FINALISED row statistics (ln_sp == 1: [rows rounded up to 256][2] = mean, rstd; the partial-sum
+  // layout with ln_sp 4 / 8 / 16 belongs to gemm.hip's kernel), the producer writes N / 64 partial slots per row
+  const bool ln_c = (epi == CS_EPI_LN_F16 || epi == CS_EPI_LN_GELU_F16) && p->ln_sp == 1 && p->ln_part && p->col_s && p->bias;
+  const bool ln_p = epi == CS_EPI_RESID_F32_LN && p->resid && p->out_f16 && p->stats_out && p->stats_sp == p->N / 64;
+  if (epi > CS_EPI_RESID_F32 && !ln_c && !ln_p) return 0;
   // K >= 384 (r4; 512 before): at K = 384 the large tile already wins clearly -- ViT-S QKV (32 880 x 1280 x 384) 36.9 us against 52.9 on the
   // 128-row kernel (47.5 at the unpadded 1152 columns), tools/qkv_k384_try.py.  The K loop itself takes any even number >= 4 of K tiles.
   if (p->N % G_BN || p->N > G_NLIM || p->K % (2 * G_BK) || p->K < g_kmin || p->K < 4 * G_BK || p->M < G_BM) return 0;
   if (p->lda % 8 || p->ldw % 8 || p->ldc % 8) return 0;
   if ((long long)p->M * p->lda * 2 >= (1ll << 32) || (long long)p->N * p->ldw * 2 >= (1ll << 32)) return 0;
-  if (epi == CS_EPI_RESID_F32 && p->resid && (p->ldr % 4 || (long long)p->M * p->ldr * 4 >= (1ll << 32))) return 0;
-  if (p->pos || p->pmean || p->out_f16 || p->stats_out || p->ln_part) return 0;
+  if ((epi == CS_EPI_RESID_F32 || ln_p) && p->resid && (p->ldr % 4 || (long long)p->M * p->ldr * 4 >= (1ll << 32))) return 0;
+  if (p->pos || p->pmean) return 0;
+  if (!ln_p && (p->out_f16 || p->stats_out)) return 0;
+  if (!ln_c && p->ln_part) return 0;
+  if (ln_c && p->N > G_NLIM) return 0;
   return 1;
 }
 
@@ -475,6 +571,9 @@ hipError_t cs_gemm256_launch(const CsGemmParams* p, int epi, int bf16, hipStream
     case CS_EPI_RESID_F32:
       if (p->resid) return bf16 ? launch256<CS_EPI_RESID_F32, true, true>(*p, st) : launch256<CS_EPI_RESID_F32, false, true>(*p, st);
       return bf16 ? launch256<CS_EPI_RESID_F32, true, false>(*p, st) : launch256<CS_EPI_RESID_F32, false, false>(*p, st);
+    case CS_EPI_RESID_F32_LN: return bf16 ? launch256<CS_EPI_RESID_F32, true, true, 2>(*p, st) : launch256<CS_EPI_RESID_F32, false, true, 2>(*p, st);
+    case CS_EPI_LN_F16: return bf16 ? launch256<CS_EPI_BIAS_F16, true, false, 1>(*p, st) : launch256<CS_EPI_BIAS_F16, false, false, 1>(*p, st);
+    case CS_EPI_LN_GELU_F16: return bf16 ? launch256<CS_EPI_BIAS_GELU_F16, true, false, 1>(*p, st) : launch256<CS_EPI_BIAS_GELU_F16, false, false, 1>(*p, st);
   }
 #undef G_CASE
   return hipErrorInvalidValue;

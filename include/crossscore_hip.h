@@ -61,8 +61,12 @@ typedef struct cs_config {
   int act;           /* 0 sigmoid (metric.min == 0), 1 tanh (metric.min == -1), model/regression_layer.py:31-38 */
   float pow_p;       /* exponent after the activation; 1 = identity, model/regression_layer.py:40-62 */
   int enc_chunk_images; /* images per encoder pass (0 = library default) */
-  int ln_fold;       /* 1: encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass; opt-in, measured
-                      * slower on MI355X); 0: separate LayerNorm kernels (default) */
+  int ln_fold;       /* encoder LayerNorms (HF modeling_dinov2.py:361-380) folded into the producing / consuming GEMM epilogues:
+                      * 0 (default): by backbone width -- hidden 384: inside the token-panel kernel; hidden 768 / 1024: in the 256-tile GEMM's
+                      *    epilogues for chunks of >= 256 rows (residual epilogues write 16-bit(x) + row partial sums, a row-statistics kernel,
+                      *    QKV / fc1 apply rstd * (acc - mean * s) + c), separate LayerNorm kernels otherwise;
+                      * 1: the 128-row kernel's folded epilogues everywhere (fp16 operands only; slower: A/B and tests);
+                      * 2: separate LayerNorm kernels for the wide backbones */
   int lanes;         /* internal streams that run independent image chunks / batch groups concurrently: 0 = default (2), 1 = serial, up to 4 */
   int pos_interp_legacy; /* encoder position-embedding resize (grids other than 37 x 37, or H != W): 0 = F.interpolate(size=(h, w)), the installed
                        * transformers (>= 4.4x; what the goldens were generated with); 1 = scale_factor ((h + 0.1) / 37, (w + 0.1) / 37) as
@@ -185,6 +189,10 @@ int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int l
                             float* out, cs_stream stream);
 int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
                     uint16_t* out_f16, cs_stream stream);
+/* Row statistics of the LayerNorm folded into the 256-tile GEMM (cs_config.ln_fold = 0 on hidden 768 / 1024): part (M, sp, 2) partial (sum,
+ * sum of squares) of every row's 64-column slices as the CS_EPI_RESID_F32_LN epilogue of that kernel writes them (sp = C / 64) ->
+ * stat (rows_padded, 2) = (mean, 1 / sqrt(var + eps)), rows [M, rows_padded) zero (the consuming epilogue fetches whole 256-row tiles). */
+int cs_op_ln_finalize(const float* part, int M, int rows_padded, int sp, int C, float eps, float* stat, cs_stream stream);
 int cs_op_im2col(const float* x, uint16_t* out, int I, int H, int W, int P, int Kp, cs_stream stream);
 /* The patch embedding exactly as the forward runs it (HF modeling_dinov2.py:141-149: conv patchify = im2col + GEMM, + position rows), with
  * (centred != 0) or without the mean-centred operand form: x (I,3,H,W), w (C,3,P,P), bias (C), pos (1 + Np, C) -> out (I * (1 + Np), C) fp32,

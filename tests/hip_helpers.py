@@ -33,6 +33,16 @@ def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_F16, resid=None, out=None, pos=None,
     return out
 
 
+def ln_finalize(part, Cc, eps=1e-6):
+    """(M, sp, 2) partial sums of the 256-tile GEMM's residual epilogue -> (ceil(M / 256) * 256, 1, 2) finalised (mean, rstd) rows."""
+    lib = _lib.load()
+    M, sp, _ = part.shape
+    Mpad = (M + 255) // 256 * 256
+    stat = torch.full((Mpad, 1, 2), 777.0, dtype=torch.float32, device=part.device)
+    _lib.check(lib.cs_op_ln_finalize(_p(part), M, Mpad, sp, Cc, eps, _p(stat), _stream()))
+    return stat
+
+
 def prescale_q(Q, dh):
     """Q * log2(e)/sqrt(dh) in fp32, rounded to fp16 once: what the forward's Q projections emit (the factor is folded into their weights)."""
     return (Q.float() * (1.4426950408889634 / dh ** 0.5)).to(torch.float16)

@@ -283,6 +283,69 @@ def test_gemm_resid_producer_emits_bf16_rows_and_partials(M, Cc):
     assert (mu - out.mean(1)).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,Cc,K", [(256, 768, 768), (1370, 768, 3072), (300, 1024, 1024), (10960, 768, 768)])
+def test_gemm256_layernorm_folded_chain(M, Cc, K, bf16):
+    """The ViT-B encoder's LayerNorm fold on the 256-tile GEMM (gemm256.hip LN = 2 / 1; HF modeling_dinov2.py:361-380): the residual epilogue
+    (x += A Wo^T + b) also emits 16-bit(x) and per-row partial sums over its 64-column wave slices, cs_op_ln_finalize turns them into
+    (mean, rstd), and the consuming projection computes LN(x) W^T + b as rstd * (16-bit(x) W'^T - mean * s) + c [+ GELU]."""
+    lib = _lib.load()
+    assert lib.cs_debug_set_op_operand_dtype(1 if bf16 else 0) == 0
+    try:
+        rd = (lambda t: t.to(torch.bfloat16).view(torch.float16)) if bf16 else _bf       # fp32 -> the operand type's bits (carried as uint16 / half)
+        fl = (lambda t: t.view(torch.bfloat16).float()) if bf16 else (lambda t: t.float())
+        g = _rng(M + Cc + K + (7 if bf16 else 0))
+        A = rd(_t(g.standard_normal((M, K), dtype=np.float32)))
+        W = rd(_t(g.standard_normal((Cc, K), dtype=np.float32) / math.sqrt(K)))
+        b = _t(g.standard_normal((Cc,), dtype=np.float32))
+        r = _t(3.0 * g.standard_normal((M, Cc), dtype=np.float32) + 0.5)
+        r[:, 5] += 300.0   # DINOv2-style outlier channels in the residual stream
+        r[:, 200] -= 250.0
+        sp = Cc // 64
+        x16 = torch.zeros((M, Cc), dtype=torch.float16, device=DEV)
+        st = torch.full((M, sp, 2), 777.0, device=DEV)
+        x = r.clone()
+        hh.gemm(A, W, b, _lib.EPI_RESID_F32_LN, resid=x, out=x, out_f16=x16, stats_out=st)
+        ref = fl(A) @ fl(W).t() + b + r
+        torch.cuda.synchronize()
+        assert (x - ref).abs().max() < 3e-4 * max(1.0, math.sqrt(K / 768)) * 4   # (|x| up to 300: fp32 half-ulp 1.5e-5, sums of K products)
+        assert torch.equal(x16, rd(x))
+        want = torch.stack([x.view(M, sp, 64).sum(2), (x * x).view(M, sp, 64).sum(2)], dim=2)
+        assert (st - want).abs().max() < 2e-5 * float(want.abs().max())
+        stat = hh.ln_finalize(st, Cc)
+        torch.cuda.synchronize()
+        mu, var = x.double().mean(1), x.double().var(1, unbiased=False)
+        assert (stat[:M, 0, 0].double() - mu).abs().max() < 1e-4
+        assert ((stat[:M, 0, 1].double() * torch.sqrt(var + 1e-6)) - 1).abs().max() < 2e-4   # rstd, relative (E[x^2] - mu^2 in fp32)
+        assert (stat[M:] == 0).all()
+        # consumer: a QKV-like (N = 3 Cc) and an fc1-like (N = 4 Cc, GELU) projection of LN(x)
+        gam = _t(1 + 0.2 * g.standard_normal((Cc,), dtype=np.float32))
+        bet = _t(0.1 * g.standard_normal((Cc,), dtype=np.float32))
+        for N, epi in ((3 * Cc, _lib.EPI_LN_F16), (4 * Cc, _lib.EPI_LN_GELU_F16)):
+            Wf = _t(g.standard_normal((N, Cc), dtype=np.float32) / math.sqrt(Cc))
+            bb = _t(0.1 * g.standard_normal((N,), dtype=np.float32))
+            Wp = rd(Wf * gam[None, :])
+            s = fl(Wp).sum(1)
+            c = bb + Wf @ bet
+            out = hh.gemm(x16, Wp, c, epi, ln_part=stat, col_s=s, ln_eps=1e-6)
+            torch.cuda.synchronize()
+            # (a) the same arithmetic in fp32 from the same rounded operands: summation order only
+            xn = (fl(x16) - stat[:M, 0, 0:1]) * stat[:M, 0, 1:2]
+            same = xn @ fl(Wp).t() + c
+            # (b) the layer's fp32 definition
+            true = orc.layer_norm(x.cpu(), gam.cpu(), bet.cpu(), 1e-6).to(DEV) @ Wf.t() + bb
+            if epi == _lib.EPI_LN_GELU_F16:
+                same, true = orc.gelu_erf(same.cpu()).to(DEV), orc.gelu_erf(true.cpu()).to(DEV)
+            o = fl(out)
+            rel = 4.2e-3 if bf16 else 6e-4   # half an ulp of the 16-bit output
+            err = (o - same).abs()
+            assert (err <= rel * same.abs() + (4e-3 if bf16 else 1.5e-3)).all(), float((err - rel * same.abs()).max())
+            err = (o - true).abs()
+            assert err.mean() < (8e-3 if bf16 else 1.2e-3) and err.max() < (0.2 if bf16 else 3e-2), (float(err.mean()), float(err.max()))
+    finally:
+        lib.cs_debug_set_op_operand_dtype(0)
+
+
 def test_gemm_patch_epilogue_and_im2col():
     """im2col + patch GEMM == conv patchify + cls/pos placement (HF:97-149), rows m -> img*T + 1 + p."""
     I, H, W, P, Cc = 3, 75, 90, 14, 128
