@@ -474,8 +474,10 @@ cs_handle cs_create(const cs_config* cfg) {
 
 void cs_destroy(cs_handle h) {
   if (!h) return;
-  // waits for THIS handle's work only (its last forward's completion event and its lane streams; a forward that failed half-way may have left
-  // lane work that no event covers) -- not for the device: sibling handles of a pipeline keep running while one is torn down
+  // waits explicitly for THIS handle's work (its last forward's completion event and its lane streams; a forward that failed half-way may have
+  // left lane work that no event covers).  The hipFree calls below synchronise the device on top of that in today's runtime -- which is also
+  // what covers caller-stream work of a half-failed forward -- so siblings of a pipeline do stall while one handle is torn down; nothing here
+  // relies on them not stalling, and nothing of this handle is freed before its own streams have drained.
   if (h->ev_done) hipEventSynchronize(h->ev_done);
   for (int l = 0; l < CS_MAX_LANES; ++l) if (h->lane_st[l]) hipStreamSynchronize(h->lane_st[l]);
   for (auto& r : h->retired) hipEventSynchronize(r.ev);

@@ -16,6 +16,7 @@
 // image through ds_read_b64_tr_b16 (hardware transposed read); LDS row strides are chosen bank-conflict free
 // (K: odd number of 16-B slots; V: 192 B so the four rows of a transposed block hit disjoint bank windows).
 #include "cs_common.h"
+#include <atomic>
 #include <math.h>
 
 #ifdef CS_ATTN_STAMP
@@ -318,7 +319,7 @@ hipError_t launch(CsAttnParams p, int batch, hipStream_t stream) {
   dim3 grid(((groups + 7) / 8) * 8 * ((p.Lq + 127) / 128));
   const int lds = 2 * AttnCfg<DH>::STAGE + 64;  // +64: the last rows' transposed reads of a padded d tile may run past the image
   if (lds > 48 * 1024) {  // (dh = 128: 74 KiB)
-    static bool attr_done[16] = {};
+    static std::atomic<bool> attr_done[16];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {

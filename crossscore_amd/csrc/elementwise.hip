@@ -3,6 +3,7 @@
 // position-table resizes (done once per (h,w)), the optional attention-weight materialisation and per-image
 // score means.  All are HBM-bound: 16-byte accesses, one wave per token row, no LDS round trips.
 #include "cs_common.h"
+#include <atomic>
 #include <math.h>
 
 namespace {
@@ -512,7 +513,7 @@ hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, h
   const int gh = H / P, gw = W / P;
   const size_t lds = (size_t)gw * Kp * sizeof(h16_t) + (pmean ? ((size_t)P * gw * P + gw + (size_t)gw * P) * sizeof(float) : 0);
   if (P == 14 && Kp >= 3 * P * P && lds <= 156 * 1024 && (long long)I * gh < (1ll << 31) && gw <= 256) {
-    static bool attr_done[16] = {};  // per device
+    static std::atomic<bool> attr_done[16];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)  // per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
@@ -610,7 +611,7 @@ hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int 
 }
 
 hipError_t cs_spin_launch(unsigned long long ticks, int blocks, int lds_bytes, hipStream_t st) {
-  static bool attr_done[16] = {};
+  static std::atomic<bool> attr_done[16];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (lds_bytes > 48 * 1024 && !attr_done[dev]) {

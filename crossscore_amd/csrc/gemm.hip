@@ -20,6 +20,7 @@
 //   alias with the LDS-DMA ring and drain it) and stores whole 128-byte lines; residual / position addends are read the
 //   same way.  The bias is the accumulator's initial value, LayerScale is folded into the packed weights at finalize.
 #include "cs_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -668,7 +669,7 @@ template <int EPI, int NSUB, int SPL, bool PIPE, bool BF>
 hipError_t launch_nb(const CsGemmParams& p, hipStream_t stream) {
   constexpr int BN = 64 * NSUB;
   constexpr int LDS = GemmCfg<NSUB>::LDS;
-  static bool attr_done[CS_MAX_DEVICES] = {};
+  static std::atomic<bool> attr_done[CS_MAX_DEVICES];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CS_MAX_DEVICES) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {

@@ -38,6 +38,7 @@
 //   fp16(x) instead of fp16(LN(x)) as the MFMA operand: the same RELATIVE rounding step per element (the row's 1/sigma scales value and error
 //   alike), so an outlier channel at 300 in a row of sigma 20 carries 0.125 / 20 = 6e-3 against 3.9e-3 for the rounded normalised value 15.
 #include "cs_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -505,7 +506,7 @@ int g_kmin = 384;  // cs_debug_gemm256_kmin
 
 template <int EPI, bool BF, bool RES = false, int LN = 0>
 hipError_t launch256(const CsGemmParams& p, hipStream_t st) {
-  static bool attr_done[16] = {};
+  static std::atomic<bool> attr_done[16];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {

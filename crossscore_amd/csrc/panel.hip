@@ -27,6 +27,7 @@
 // through a 3-slot ring, two chunks in flight, counted s_waitcnt vmcnt + one raw s_barrier per chunk.  A chunk is one half tick:
 // [12 fragments for the A waves (half the K range of an fc1 slice) | 12 for the B waves (6 of the 12 output tiles of an fc2 slice)].
 #include "cs_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(256) void cs_panel_pack_kernel(const float* __restr
 
 template <bool OUTPROJ, bool BF>
 hipError_t panel_launch_t(const CsPanelParams* p, hipStream_t st) {
-  static bool attr_done[16] = {};
+  static std::atomic<bool> attr_done[16];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {

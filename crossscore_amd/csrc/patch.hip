@@ -20,6 +20,7 @@
 //      token rows (+ bias + position embedding + mean term)
 // C = 384 n (ViT-S: one pass, ViT-B: two); rows past np of the last 16-row tile read whatever follows the A tile and are never stored.
 #include "cs_common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -279,7 +280,7 @@ hipError_t cs_patch_fused_launch(const float* xq, const float* xr, int N, int im
   const int lds = pf_lds(npmax);
   const long long blocks = (long long)I * p.gh * p.nsx;
   if (blocks <= 0 || blocks >= (1ll << 31)) return hipErrorInvalidValue;
-  static bool attr_done[16][2] = {};
+  static std::atomic<bool> attr_done[16][2];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_done[dev][bf ? 1 : 0]) {

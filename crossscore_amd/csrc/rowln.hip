@@ -15,6 +15,7 @@
 // cross_reference.py:45-50).  The normalised rows, rounded to the operand type as a separate GEMM would read them, replace the activation rows
 // in LDS and the K loop runs again.
 #include "cs_common.h"
+#include <atomic>
 
 namespace {
 
@@ -292,7 +293,7 @@ extern "C" hipError_t cs_rowln_launch(const CsRowLnParams* p, int C, int bf16, h
   if (C != 384) return hipErrorInvalidValue;
   constexpr int CC = 384, NW = CC / 96;
   constexpr int lds = 64 * (CC * 2 + 16) + 2 * CC * (64 * 2 + 16) + 2 * NW * 64 * 4;  // activation rows + two weight slices + the row-sum exchange
-  static bool attr_done[16] = {};
+  static std::atomic<bool> attr_done[16];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {

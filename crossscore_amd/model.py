@@ -79,12 +79,11 @@ class CrossScoreNet(torch.nn.Module):
         if not m.do_reference_cross:
             raise NotImplementedError("model.do_reference_cross=False produces no score map in the reference (task/core.py:89); not built")
         # model/positional_encoding.py:61-69 hands the mode to F.interpolate together with align_corners=True, which torch accepts for a 4-D tensor
-        # only with the interpolating modes bilinear and bicubic: every other value raises there too ("align_corners option can only be set with
-        # the interpolating modes ...").  The reference raises at the first forward that has to resize; here the error comes at construction.
-        self._pe_mode = {"bilinear": 0, "bicubic": 1}.get(str(m.pos_enc.multi_view.interpolate_mode))
-        if self._pe_mode is None:
-            raise ValueError(f"model.pos_enc.multi_view.interpolate_mode={m.pos_enc.multi_view.interpolate_mode!r}: align_corners option can only be "
-                             "set with the interpolating modes: linear | bilinear | bicubic | trilinear (4-D input: bilinear | bicubic)")
+        # only with the interpolating modes bilinear and bicubic: every other value raises there ("align_corners option can only be set with
+        # the interpolating modes ...") -- at the first forward whose patch grid differs from the PE's (pe_h, pe_w), not before: a grid that
+        # matches adds the parameter as it is (positional_encoding.py:51-56) whatever the mode says.  Same here: `_check_pe_mode`.
+        self._pe_mode_name = str(m.pos_enc.multi_view.interpolate_mode)
+        self._pe_mode = {"bilinear": 0, "bicubic": 1}.get(self._pe_mode_name, 0)  # (an unsupported name never reaches the resize kernel)
         self.arch = arch_from_cfg(cfg)
         metric = m.predict.metric
         self._act, self._pow = regression_activation(metric.type, metric.min, metric.max, metric.power_factor)
@@ -160,6 +159,13 @@ class CrossScoreNet(torch.nn.Module):
         kern = {k: int(v) for k, v in (kv.split("=") for kv in buf.value.decode().split() if "=" in kv)}
         return {"launches": int(n.value), "host_enqueue_ms": float(ms.value), "kernels": kern}
 
+    def _check_pe_mode(self, H: int, W: int) -> None:
+        """The reference's F.interpolate call (positional_encoding.py:61-69) only runs when the patch grid differs from the PE table's."""
+        P = self.arch.patch
+        if self._pe_mode_name not in ("bilinear", "bicubic") and (H // P, W // P) != (self.arch.pe_h, self.arch.pe_w):
+            raise ValueError(f"model.pos_enc.multi_view.interpolate_mode={self._pe_mode_name!r}: align_corners option can only be "
+                             "set with the interpolating modes: linear | bilinear | bicubic | trilinear (4-D input: bilinear | bicubic)")
+
     def _release(self):
         if self._handle is not None:
             _lib.load().cs_destroy(self._handle)
@@ -233,6 +239,7 @@ class CrossScoreNet(torch.nn.Module):
         N = r.shape[1]
         P = self.arch.patch
         h, w = H // P, W // P
+        self._check_pe_mode(H, W)
         lib = _lib.load()
         handle = self._ensure_handle(dev)
         with torch.cuda.device(dev):
@@ -271,6 +278,7 @@ class CrossScoreNet(torch.nn.Module):
         dev = ref_imgs.device
         x = ref_imgs.to(torch.float32).contiguous()
         R, _, H, W = x.shape
+        self._check_pe_mode(H, W)
         P = self.arch.patch
         handle = self._ensure_handle(dev)
         with torch.cuda.device(dev):
@@ -295,6 +303,7 @@ class CrossScoreNet(torch.nn.Module):
         N = t.shape[1]
         P = self.arch.patch
         h, w = H // P, W // P
+        self._check_pe_mode(H, W)
         if t.shape[2] != h * w or t.shape[3] != self.arch.hidden:
             raise ValueError("ref_tokens do not match the query's patch grid / hidden size")
         handle = self._ensure_handle(dev)

@@ -158,16 +158,29 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
     t_loop = time.perf_counter() - t0
     # finish the outputs and the pools first, then decide about the overflow report together with the other ranks: a rank that raised on its
     # own before the barrier would leave the others waiting in it, and the files written so far are worth keeping either way
+    # A rank whose output stage raises must still take part in the collective below, or the other ranks wait in it forever: the
+    # exception is kept, the failure travels with the overflow count (one max-reduction: value = count + 1e12 for a failed rank) and is
+    # re-raised behind the barrier -- on the failing rank as it was, on the others as a RuntimeError naming the situation.
+    failure: Optional[BaseException] = None
     try:
         if writer is not None:
             writer.finish()
         files += summariser.summarise()
+    except BaseException as exc:  # noqa: BLE001 -- re-raised below, behind the collective
+        failure = exc
     finally:
         prefetch.shutdown()
         pool.shutdown()
     bad = pipe.nonfinite_count()
-    bad_any = int(parallel.max_over_ranks(float(bad), device))  # every rank learns whether ANY rank saw non-finite values
+    FAILED = 1.0e12
+    worst = parallel.max_over_ranks(float(bad) + (FAILED if failure is not None else 0.0), device)  # every rank learns about ANY rank
     parallel.barrier()
+    if failure is not None:
+        raise failure
+    if worst >= FAILED:
+        raise RuntimeError("another rank failed while finishing its outputs (see its traceback); this rank's outputs are under "
+                           f"{cfg.logger.predict.out_dir}")
+    bad_any = int(worst)
     if bad_any:  # an activation left the range of the 16-bit operand type somewhere upstream (fp16: |x| > 65504)
         raise FloatingPointError(f"{bad} non-finite score-map values on this rank (up to {bad_any} on one rank) with {net.operand_dtype} MFMA operands: "
                                  "run with trainer.precision=bf16-mixed (model.backbone.operand_dtype=bf16); the outputs written are under "

@@ -392,8 +392,16 @@ def test_multiview_pe_bicubic_mode_end_to_end():
     assert mae_g < MAE_TOL and mx_g < MAX_TOL, (mae_g, mx_g)
     ref_bil = _oracle(arch, sd, q, r)["score_map_ref_cross"]
     assert float((ref - ref_bil).abs().mean()) > 3 * mae
+    # any other mode: F.interpolate(..., align_corners=True) raises in the reference -- at the first forward that has to resize the PE table, not
+    # at construction, and never for a patch grid equal to the table's 40 x 40 (positional_encoding.py:51-56 adds the parameter as it is)
+    netn, _, _ = _net(TINY, 13, **{"pos_enc.multi_view.interpolate_mode": "nearest"})
     with pytest.raises(ValueError, match="align_corners"):
-        CrossScoreNet(model_config(**{"backbone.from_pretrained": TINY, "pos_enc.multi_view.interpolate_mode": "nearest"}))
+        netn(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)
+    q40, r40 = synth.make_inputs(1, 1, 560, 560, 13)
+    s_near = netn(torch.from_numpy(q40).cuda(), torch.from_numpy(r40).cuda(), False, 0, False)["score_map_ref_cross"]
+    s_bil = _net(TINY, 13)[0](torch.from_numpy(q40).cuda(), torch.from_numpy(r40).cuda(), False, 0, False)["score_map_ref_cross"]
+    torch.cuda.synchronize()
+    assert torch.equal(s_near, s_bil)
 
 
 def test_pos_embed_scale_factor_interpolation_option():
