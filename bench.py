@@ -100,7 +100,7 @@ def roofline_of(dom):
     return r
 
 
-TRAFFIC_PROFILE = "profiles/r04_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r05_hbm_traffic.json"
 
 
 def pmc_traffic(kernel_name):

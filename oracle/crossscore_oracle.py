@@ -183,7 +183,9 @@ def encoder_pos_embed(Wt: Dict[str, Tensor], h: int, w: int, H: int, W: int, leg
     """(1+h*w, C) position table: parameter as is when grid matches and H==W, else bicubic (HF:57-95).
     legacy=True: the interpolation call of the reference's PINNED transformers 4.33.3 (environment.yaml:340), which passed
     scale_factor=((h + 0.1) / G, (w + 0.1) / G) -- torch then maps dst -> (dst + 0.5) * G / (h + 0.1) - 0.5 -- instead of size=(h, w).
-    That release is not installable offline, so this branch is a restatement of its published source, not pinned by a golden."""
+    That release is not installable offline: the branch restates its published call, and is pinned by tests/golden/g6_pos_legacy.npz -- the
+    same F.interpolate(scale_factor=...) call executed by the installed torch on the synthetic tables, and the imported reference model run end
+    to end with its interpolate_pos_encoding replaced by that call (tests/golden/make_golden.py --only g6; tests/test_oracle_golden.py)."""
     pos = Wt["backbone.embeddings.position_embeddings"][0]  # (1+G*G, C)
     G2 = pos.shape[0] - 1
     if h * w == G2 and H == W:

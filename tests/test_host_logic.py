@@ -302,10 +302,10 @@ def test_bench_refuses_more_gpus_than_visible():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r04_bench.json is a verbatim bench.py line: the keys the driver and the judge read must be there."""
+    """profiles/r05_bench.json is a verbatim bench.py line: the keys the driver and the judge read must be there."""
     import json
 
-    path = os.path.join(REPO, "profiles", "r04_bench.json")
+    path = os.path.join(REPO, "profiles", "r05_bench.json")
     r = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
@@ -340,3 +340,7 @@ def test_committed_bench_line_follows_the_contract():
     assert s4["weak_16_per_gpu"]["mode"] == "weak" and s4["weak_16_per_gpu"]["value"] > 0
     f = r["batches_in_flight_measured"]
     assert abs(f["fraction_two_in_flight"] + f["fraction_one_in_flight"] + f["fraction_idle"] - 1.0) < 1e-6 and f["fraction_two_in_flight"] > 0.5
+    # round 5: what a forward costs the rank's CPU thread (cs_forward_stats), in the line and in every rank's record
+    assert 0 < r["host_enqueue_ms_per_forward"] < r["ms_per_step"] and r["launches_per_forward"] == sum(r["launches_by_kernel"].values())
+    assert all("host_enqueue_ms_per_forward" in x and x["launches_per_forward"] > 0 for x in r["ranks_seen"])
+    assert r["roofline"]["traffic_source"].startswith("committed profile profiles/r0")
