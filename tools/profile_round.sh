@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything the round's committed profiles/ come from, in one GPU call (run from the repo root on the GPU box):
-#   tools/profile_round.sh r03     ->  gpurun_out/prof_r03/...   (copy the summaries into profiles/r03_* afterwards: tools/collect_profiles.py)
+#   tools/profile_round.sh r05     ->  gpurun_out/prof_r05/...   (copy the summaries into profiles/r05_* afterwards: tools/collect_profiles.py r05)
 #   bench lines for every BASELINE workload (+ the bf16 operand mode of cfg-2), rocprofv3 kernel stats of the default command and of the
 #   every-kernel-alone command (cfg-2 and cfg-4), the kernel-concurrency timeline of the default command, FETCH_SIZE / WRITE_SIZE PMC
 #   passes (separate runs, --kernel-trace only beside --pmc) of the every-kernel-alone commands, two SQ counter passes over the
