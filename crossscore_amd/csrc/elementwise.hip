@@ -215,6 +215,10 @@ __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __rest
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long long)I * Np) return;
+  // (r5, measured and not adopted: ordering the waves so that those adding the same PE rows run close together -- position-major, or tiles of
+  //  8 positions x all images -- brings the kernel's fetch traffic from 180 to 110-118 MB, i.e. to the algorithmic 103: the 77 MB on top are
+  //  re-fetches of the 2.1-MB PE table, which does not survive 100 MB of streamed rows in a 4-MB L2.  They are served by the Infinity Cache,
+  //  not by HBM, and the reordered kernel is SLOWER, 45-47 us against 41: its waves then read and write 1.5-KB rows of different images.)
   const int img = (int)(row / Np);
   const int pp = (int)(row - (long long)img * Np);
   // N < 0: every image is a reference view (reference-token cache): row goes to mem_bf[(img0+img)*Np + pp]

@@ -82,10 +82,14 @@ __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
 #ifdef CS_PF_EMPTY  // timing only: what the launch itself costs (same registers, same LDS, no work)
   if (p.H > 0) return;
 #endif
+  // block -> (patch row, run, image), image fastest (r5): the workgroups that add the same slice of the position table (the patch row's
+  // 57 KB at 518 px) run next to each other, so the slice is fetched once per XCD instead of once per image (the table is 2.1 MB, a chunk
+  // of 48 images streams 260 MB through the L2s in between: PMC traffic 349 -> see profiles/)
   int b = blockIdx.x;
-  const int sx = b % p.nsx; b /= p.nsx;
-  const int pi = b % p.gh;
-  const int img = b / p.gh;
+  const int n_img = gridDim.x / (p.gh * p.nsx);
+  const int img = b % n_img; b /= n_img;
+  const int sx = b % p.nsx;
+  const int pi = b / p.nsx;
   const int base = p.gw / p.nsx, rem = p.gw - base * p.nsx;
   const int np = base + (sx < rem ? 1 : 0);              // patches of this run
   const int p0 = sx * base + (sx < rem ? sx : rem);      // first patch (column index in the patch row)
