@@ -53,12 +53,17 @@ def test_panel_vs_torch(M, outproj):
     u = hh.encoder_panel(xk, o if outproj else None, img, w["bo"] if outproj else None, w["b1"], w["b2"])
     torch.cuda.synchronize()
     ref_x, ref_u = _reference(x, o, w, outproj, emulate=True)
-    # same fp16 operand roundings as the kernel: what is left is fp32 summation order and the GELU fit (<= 2.1e-4)
+    # same fp16 operand roundings as the kernel: what is left is fp32 summation order and the GELU.  Since round 5 the kernel rounds the fc1
+    # output to half BEFORE the activation and evaluates GELU's correction term in packed half arithmetic (panel.hip, tools/gelu_pk16_fit.py):
+    # per hidden value rms 2.6e-4 / worst 2.1e-3 against the exact GELU (the reference's own 16-mixed arithmetic: rms 2.1e-4), where the fp32
+    # degree-7 fit of rounds 2-4 had <= 2.1e-4 worst.  Through fc2 (1536 terms with weights of rms 1/sqrt(1536) x LayerScale ~ 1) that is
+    # ~3e-4 rms on x: measured mean |d| 2.6e-4, max 1.9e-3 - 2.7e-3 on these shapes (the printed values; r4's kernel with the fp32 GELU: 1.1e-4 / 8e-4).
     assert torch.isfinite(xk).all()
     err = (xk - ref_x).abs().max().item()
-    assert err < 4e-3, err
     mean_err = (xk - ref_x).abs().mean().item()
-    assert mean_err < 3e-4, mean_err
+    print(f"panel M={M} outproj={outproj}: mean |d| {mean_err:.2e} max {err:.2e} (same operand roundings, exact GELU)")
+    assert err < 4e-3, err
+    assert mean_err < 4e-4, mean_err  # (1.5 x measured)
     u_err = (u.float() - ref_u).abs().max().item()
     assert u_err < 6e-3, u_err  # fp16 output of O(1..4) values: half an ulp is up to 2e-3
     # against exact fp32 arithmetic the fp16 operand rounding dominates
