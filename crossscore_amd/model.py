@@ -76,8 +76,10 @@ class CrossScoreNet(torch.nn.Module):
         super().__init__()
         self.cfg = cfg
         m = cfg.model
-        if not m.do_reference_cross:
-            raise NotImplementedError("model.do_reference_cross=False produces no score map in the reference (task/core.py:89); not built")
+        # model.do_reference_cross=False (task/core.py:55,89): the reference builds no CrossReferenceNet (its state dict has no `ref_cross.*`
+        # entries), runs the encoder for nothing and returns an EMPTY result dict.  Same here, minus the wasted encoder pass: the module keeps
+        # the backbone / PE parameters so that such a checkpoint loads strictly, and forward() returns {} after the reference's own input checks.
+        self._do_reference_cross = bool(m.do_reference_cross)
         # model/positional_encoding.py:61-69 hands the mode to F.interpolate together with align_corners=True, which torch accepts for a 4-D tensor
         # only with the interpolating modes bilinear and bicubic: every other value raises there ("align_corners option can only be set with
         # the interpolating modes ...") -- at the first forward whose patch grid differs from the PE's (pe_h, pe_w), not before: a grid that
@@ -89,6 +91,8 @@ class CrossScoreNet(torch.nn.Module):
         self._act, self._pow = regression_activation(metric.type, metric.min, metric.max, metric.power_factor)
         # parameter tree with the checkpoint's key names (all frozen for inference)
         for name, shape, kind, _ in synth.state_dict_spec(self.arch):
+            if not self._do_reference_cross and name.startswith("ref_cross."):
+                continue
             parts = name.split(".")
             node = self
             for p in parts[:-1]:
@@ -178,6 +182,8 @@ class CrossScoreNet(torch.nn.Module):
             pass
 
     def _ensure_handle(self, device: torch.device):
+        if not self._do_reference_cross:
+            raise ValueError("model.do_reference_cross=False: this module has no cross-reference predictor (task/core.py:55) -- nothing to score or cache")
         if self._handle is not None and not self._dirty and self._handle_device == device:
             return self._handle
         lib = _lib.load()
@@ -220,6 +226,15 @@ class CrossScoreNet(torch.nn.Module):
         :param ref_cross_imgs:  (B, N_ref_cross, 3, H, W)
         :param norm_img:        reference flag (task/core.py:76-81), bug-for-bug: the std used is the mean.
         """
+        if not self._do_reference_cross:
+            # task/core.py:84-117 with the flag off: features of the query (and of the references, when given) are computed and dropped, the
+            # result dict stays empty.  The input checks of get_featmaps (:119-138: a 4-D query, references that concatenate with it) still hold.
+            if query_img.dim() != 4 or query_img.shape[1] != 3:
+                raise ValueError("expected query_img (B,3,H,W)")
+            if ref_cross_imgs is not None and (ref_cross_imgs.dim() != 5 or ref_cross_imgs.shape[0] != query_img.shape[0] or
+                                               tuple(ref_cross_imgs.shape[2:]) != tuple(query_img.shape[1:])):
+                raise ValueError("expected ref_cross_imgs (B,N,3,H,W) matching query_img")
+            return {}
         if ref_cross_imgs is None:
             raise ValueError("ref_cross_imgs is required when model.do_reference_cross=True (task/core.py:90)")
         if query_img.dim() != 4 or query_img.shape[1] != 3 or ref_cross_imgs.dim() != 5 or ref_cross_imgs.shape[2] != 3:

@@ -92,6 +92,21 @@ def test_no_self_attn_variant_has_no_self_attn_keys():
     assert not any("self_attn" in k for k in net.state_dict())
 
 
+def test_do_reference_cross_off_returns_an_empty_result_like_the_reference():
+    """model.do_reference_cross=False (task/core.py:55,89): no CrossReferenceNet in the module (no `ref_cross.*` state-dict entries) and an EMPTY
+    result dict from forward -- the reference computes the features and drops them; here nothing is launched (works on CPU tensors too)."""
+    net = CrossScoreNet(model_config(do_reference_cross=False))
+    keys = set(net.state_dict().keys())
+    assert keys and not any(k.startswith("ref_cross.") for k in keys) and "pos_enc_fn.PE" in keys and "backbone.layernorm.weight" in keys
+    full = set(CrossScoreNet(model_config()).state_dict().keys())
+    assert keys == {k for k in full if not k.startswith("ref_cross.")}
+    q = torch.zeros(2, 3, 28, 28)
+    assert net(q, torch.zeros(2, 3, 3, 28, 28), False, 0, False) == {}
+    assert net(q, None, False, 0, False) == {}  # (get_featmaps takes ref_cross_imgs=None: task/core.py:130)
+    with pytest.raises(ValueError):
+        net(q, torch.zeros(2, 3, 3, 28, 42), False, 0, False)  # images that would not concatenate
+
+
 def test_forward_refuses_cpu_tensors():
     net = CrossScoreNet(model_config(**{"backbone.from_pretrained": "synthetic/dinov2-tiny"}))
     q = torch.zeros(1, 3, 70, 70)
