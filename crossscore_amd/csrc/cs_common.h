@@ -165,10 +165,11 @@ struct CsGemmParams {
   // LayerNorm fold (see CS_EPI_LN_*): producer side (RESID_F32_LN, PATCH_F32) ...
   h16_t* out_f16;    // [rows][ldc] fp16 copy of the fp32 rows written (the next GEMM's A operand), or null
   float* stats_out;    // [rows][stats_sp][2] partial (sum, sumsq) per row: slot = column_tile*4 + wave, or null
-  int stats_sp;
+  int stats_sp;        //   128-row kernel (gemm.hip): 4 x its column tiles (192 / 128 wide); 256-tile kernel (gemm256.hip, LN = 2): N / 64
   // ... consumer side (LN_BF16, LN_GELU_BF16); `bias` carries c[n]
-  const float* ln_part;  // [M][ln_sp][2] partial sums of the A rows (fp32 values before fp16 rounding)
-  int ln_sp;             // 4, 8 or 16
+  const float* ln_part;  // 128-row kernel: [M][ln_sp][2] partial sums of the A rows (fp32 values before fp16 rounding), ln_sp in {4, 8, 16};
+  int ln_sp;             // 256-tile kernel (LN = 1): ln_sp == 1 and ln_part = FINALISED rows [ceil(M / 256) * 256][2] = (mean, rstd) from
+                         // cs_ln_finalize_launch -- whole 256-row tiles are fetched, so the buffer must hold the padded row count
   const float* col_s;    // [N] s[n]
   float ln_eps;
   int ablate;         // debug timing builds only (CS_ABLATE); 0 in the product
