@@ -428,7 +428,7 @@ def main():
     # who took part: one record per rank (device identity + that rank's own time for the K steps), gathered over the process group
     # what a forward costs THIS rank's CPU thread (cs_forward_stats of the replica that ran the last timed step: kernel launches of one forward
     # and the wall time of the enqueueing call; nothing is waited for inside it) -- the host-side budget of N ranks on one node
-    fstats = wl.pipe.nets[(wl.pipe._n - 1) % len(wl.pipe.nets)].forward_stats() if getattr(wl.pipe, "nets", None) else wl.net.forward_stats()
+    fstats = wl.pipe.last_replica().forward_stats()
     census = parallel.rank_census(dev, ms_per_step=1e3 * timed_steps.last_rank_seconds / args.steps,
                                   host_enqueue_ms_per_forward=round(fstats["host_enqueue_ms"], 4), launches_per_forward=fstats["launches"])
     # the timed region is short (K steps of a few ms with batches in flight: pipeline fill / drain and clock ramp are inside it), so

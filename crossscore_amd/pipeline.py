@@ -75,6 +75,10 @@ class ForwardPipeline:
         self._n = 0
         self._marks = None  # record_timeline(): [(replica, start event, end event)] of every submit
 
+    def last_replica(self) -> CrossScoreNet:
+        """The module that ran (or is running) the most recently submitted batch -- e.g. to read its forward_stats()."""
+        return self.nets[(self._n - 1) % self.depth] if self._n else self.nets[0]
+
     def _overlapping_streams(self, n: int) -> List[Any]:
         """n streams on which kernels really run side by side.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
         queues and two streams that land on one queue serialise (the replicas would then run one after another: measured 9.0
