@@ -30,7 +30,7 @@ if os.environ.get("CS_ATTN_CHILD"):
 sys.path.insert(0, R)
 from crossscore_amd import build
 variants = [v for v in os.environ.get("CS_ATTN_VARIANTS", "").split(",") if v]
-srcs = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip", "patch.hip"]
+srcs = build.SOURCES
 for var in [None] + variants:
     if var is None:
         pkgroot = R
