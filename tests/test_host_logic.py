@@ -250,7 +250,12 @@ def test_bench_names_the_failing_rank_on_stderr():
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode != 0
     lines = [ln for ln in res.stderr.splitlines() if ln.startswith("bench.py FAILED")]
-    assert len(lines) == 1 and "rank=1 local_rank=1 world=2" in lines[0] and "rehearsed failure" in lines[0] and "plumbing_test" in lines[0], res.stderr[-2000:]
+    mine = [ln for ln in lines if "rank=1 local_rank=1 world=2" in ln]
+    assert len(mine) == 1 and "rehearsed failure" in mine[0] and "plumbing_test" in mine[0], res.stderr[-2000:]
+    # rank 0 is either ended by the launcher (no line) or sees its peer's connection close inside the next collective and says so itself:
+    # at most one line per rank, and the only other rank is 0
+    others = [ln for ln in lines if ln not in mine]
+    assert len(others) <= 1 and all("rank=0 local_rank=0 world=2" in ln and "rehearsed failure" not in ln for ln in others), res.stderr[-2000:]
 
 
 def test_predict_config_defaults_to_the_reference_environments_pos_embed_resize():
