@@ -77,7 +77,7 @@ def kernel_table(net):
     return rows
 
 
-def roofline_of(dom):
+def roofline_of(dom, traffic_profile="default"):
     """Roofline entry of the dominant kernel family.  Its bound follows from its arithmetic intensity (algorithmic FLOPs over
     algorithmic HBM bytes per launch, both recorded by the library next to the HIP-event timings) against the ridge point
     peak_flops / peak_bandwidth = 312.5 FLOP/B: below it the kernel is HBM-bound and `achieved` is algorithmic bytes over the
@@ -89,7 +89,7 @@ def roofline_of(dom):
          "achieved": dom["gbytes_per_s"] if hbm else dom["tflops"], "peak": PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS,
          "unit": "GB/s" if hbm else "TFLOP/s"}
     r["frac"] = r["achieved"] / r["peak"]
-    traffic, traffic_source = pmc_traffic(dom["kernel"])
+    traffic, traffic_source = pmc_traffic(dom["kernel"]) if traffic_profile else (None, "no PMC pass committed for this workload (cfg-2 and cfg-4 have one: profiles/)")
     r.update({"traffic": traffic, "traffic_source": traffic_source,
               "measured": "HIP events around each launch on its stream, kernel alone on the GPU (1 lane, whole batch per chunk)",
               "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
@@ -100,7 +100,7 @@ def roofline_of(dom):
     return r
 
 
-TRAFFIC_PROFILE = "profiles/r05_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r05_hbm_traffic.json"  # (replaced by the round's own pass when tools/collect_profiles.py has run)
 
 
 def pmc_traffic(kernel_name):
@@ -178,26 +178,68 @@ def cpu_baseline(arch, sd, H, W, N, hip_score_item0, seed, max_seconds=25.0):
     return cb, mae, ref[0]
 
 
+def _fused_torch_ops(orc):
+    """The eager legs run what the reference's MODULES execute, not the oracle's explicit arithmetic: nn.LayerNorm -> F.layer_norm (one
+    fused kernel; model/customised_transformer/transformer.py:68-80, HF Dinov2Layer's norm1 / norm2), nn.Linear -> F.linear (addmm with the
+    bias inside), ACT2FN["gelu"] -> F.gelu (HF modeling_dinov2.py:293-297), SDPA attention.  The oracle's own forms (9 elementwise / reduction
+    kernels per LayerNorm, 5 per GELU) stay the PARITY definition; timing them would handicap the baseline.
+    Returns (patch dict, names) for eager_baseline to install and to report."""
+    F = torch.nn.functional
+    return {"layer_norm": lambda x, g, b, eps: F.layer_norm(x, (x.shape[-1],), g, b, eps),
+            "gelu_erf": lambda x: F.gelu(x),
+            "linear": lambda x, w, b, rnd: F.linear(rnd(x), rnd(w), b)}
+
+
 def eager_baseline(arch, sd, tq, tr, dev, steps=3, variants=("fp32_sdpa", "fp16_autocast_sdpa", "bf16_autocast_sdpa")):
-    """The 'PyTorch-ROCm eager reference' of the north-star target: the fp32 restatement (plain torch ops: nn.Linear-shaped
-    matmuls, LayerNorm, SDPA) run on the GPU, in fp32 and under bf16 autocast (trainer.precision=16-mixed,
-    config/default_predict.yaml:25).  `*_sdpa` use F.scaled_dot_product_attention -- what the reference's modules execute on a
-    GPU; the explicit-softmax variants materialise the attention matrix.  Reported next to `value`; never part of it."""
+    """The 'PyTorch-ROCm eager reference' of the north-star target: the fp32 restatement run on the GPU with the fused torch ops the
+    reference's modules execute (F.layer_norm, F.linear, F.gelu, F.scaled_dot_product_attention -- _fused_torch_ops), in fp32 and under
+    fp16 / bf16 autocast (trainer.precision=16-mixed, config/default_predict.yaml:25).  `*_sdpa` use SDPA -- what the reference's modules
+    execute on a GPU; the explicit-softmax variants materialise the attention matrix; `*_unfused` variants time the oracle's explicit
+    LayerNorm / GELU / matmul+bias arithmetic (what rounds 1-5 reported).  Reported next to `value`; never part of it."""
     from oracle import crossscore_oracle as orc
 
     Wt = {k: v.to(dev) for k, v in orc.to_torch(sd).items()}
     cfg = dict(enc_heads=arch.enc_heads)
     out = {}
-    explicit_attention = orc.attention
-    table = {"fp32": (lambda: torch.autocast("cuda", enabled=False), explicit_attention),
-             "bf16_autocast": (lambda: torch.autocast("cuda", dtype=torch.bfloat16), explicit_attention),
-             "fp32_sdpa": (lambda: torch.autocast("cuda", enabled=False), _sdpa_attention),
-             "bf16_autocast_sdpa": (lambda: torch.autocast("cuda", dtype=torch.bfloat16), _sdpa_attention),
+    explicit = {k: getattr(orc, k) for k in ("attention", "layer_norm", "gelu_erf", "linear")}
+    fused = _fused_torch_ops(orc)
+    no_ac = lambda: torch.autocast("cuda", enabled=False)  # noqa: E731
+    table = {"fp32": (no_ac, explicit["attention"], True),
+             "bf16_autocast": (lambda: torch.autocast("cuda", dtype=torch.bfloat16), explicit["attention"], True),
+             "fp32_sdpa": (no_ac, _sdpa_attention, True),
+             "bf16_autocast_sdpa": (lambda: torch.autocast("cuda", dtype=torch.bfloat16), _sdpa_attention, True),
              # trainer.precision = "16-mixed" is fp16 autocast in Lightning: the reference's shipped GPU mode
-             "fp16_autocast_sdpa": (lambda: torch.autocast("cuda", dtype=torch.float16), _sdpa_attention)}
-    for name in variants:
-        ctx, attn_fn = table[name]
+             "fp16_autocast_sdpa": (lambda: torch.autocast("cuda", dtype=torch.float16), _sdpa_attention, True),
+             "fp32_sdpa_unfused": (no_ac, _sdpa_attention, False),
+             "fp16_autocast_sdpa_unfused": (lambda: torch.autocast("cuda", dtype=torch.float16), _sdpa_attention, False)}
+
+    def install(attn_fn, use_fused):
         orc.attention = attn_fn
+        for k in ("layer_norm", "gelu_erf", "linear"):
+            setattr(orc, k, fused[k] if use_fused else explicit[k])
+
+    def restore():
+        for k, v in explicit.items():
+            setattr(orc, k, v)
+
+    try:
+        # what the substitution changes, on batch item 0 in fp32: fused ops + SDPA against the oracle's explicit arithmetic (the parity form)
+        with torch.no_grad(), no_ac():
+            restore()
+            ref0 = orc.forward(Wt, cfg, tq[:1], tr[:1])["score_map_ref_cross"]
+            install(_sdpa_attention, True)
+            got0 = orc.forward(Wt, cfg, tq[:1], tr[:1])["score_map_ref_cross"]
+        out["_fused_ops"] = dict(ops="F.layer_norm, F.linear, F.gelu, F.scaled_dot_product_attention (what nn.LayerNorm / nn.Linear / ACT2FN['gelu'] / "
+                                     "the reference's attention modules execute)",
+                                 fp32_max_abs_diff_vs_explicit_oracle=float((got0 - ref0).abs().max()),
+                                 fp32_mean_abs_diff_vs_explicit_oracle=float((got0 - ref0).abs().mean()))
+    except Exception as e:  # noqa: BLE001
+        out["_fused_ops"] = dict(error=str(e)[:200])
+    finally:
+        restore()
+    for name in variants:
+        ctx, attn_fn, use_fused = table[name]
+        install(attn_fn, use_fused)
         try:
             with torch.no_grad(), ctx():
                 orc.forward(Wt, cfg, tq, tr)
@@ -206,12 +248,78 @@ def eager_baseline(arch, sd, tq, tr, dev, steps=3, variants=("fp32_sdpa", "fp16_
                 for _ in range(steps):
                     orc.forward(Wt, cfg, tq, tr)
                 torch.cuda.synchronize(dev)
-            out[name] = dict(value=tq.shape[0] * steps / (time.perf_counter() - t0), unit="query-images/sec", batch=int(tq.shape[0]))
+            out[name] = dict(value=tq.shape[0] * steps / (time.perf_counter() - t0), unit="query-images/sec", batch=int(tq.shape[0]),
+                             ops="fused torch ops" if use_fused else "the oracle's explicit LayerNorm / GELU / matmul + bias")
         except Exception as e:  # e.g. out of memory for the materialised attention at large batch
             out[name] = dict(error=str(e)[:200])
         finally:
-            orc.attention = explicit_attention
+            restore()
     return out
+
+
+def profile_kernels(wl, prof_steps=3):
+    """Per-kernel HIP-event timing of one workload (a separate pass, so the events do not perturb a timed region): every kernel alone on
+    the GPU -- one lane, the whole batch as one encoder chunk (a timed region overlaps lanes and batches, where a kernel's wall duration also
+    contains its neighbour's work); `bench.py --lanes 1 --chunk <images>` under rocprofv3 reproduces exactly these launches (profiles/).
+    Returns (rows, dominant MFMA-kernel row)."""
+    net = wl.net
+    saved = (net.lanes, net.enc_chunk_images)
+    net.lanes, net.enc_chunk_images = 1, wl.micro * (1 + wl.N)
+    net._mark_dirty()
+    wl.direct()  # rebuilds the handle with the new lane / chunk settings
+    net.profile_enable(True)
+    for _ in range(prof_steps):
+        wl.direct()
+    rows = kernel_table(net)
+    net.profile_enable(False)
+    net.lanes, net.enc_chunk_images = saved
+    net._mark_dirty()
+    for rrow in rows:
+        rrow["launches_per_step"] = rrow["launches"] // prof_steps
+    dom = max((x for x in rows if x["tflops"]), key=lambda x: x["total_ms"])
+    return rows, dom
+
+
+GOLDEN_OF = {"cfg2": "g1_vits_518_n5.npz", "cfg3": "g2_vitb_518_n10.npz", "cfg5": "g3_vits_1036_n5.npz"}
+
+
+def golden_mae(name, score_item0):
+    """Score-map MAE of batch item 0 against the COMMITTED golden of the reference itself (tests/golden/g1 / g2 / g3: generated by importing
+    /root/reference in the build container, same seed, same item): mean |diff| over the golden's four full rows and over its per-patch
+    means.  No oracle run, nothing read outside the repository."""
+    import numpy as np
+    g = np.load(os.path.join(REPO, "tests", "golden", GOLDEN_OF[name]))
+    s = score_item0.detach().float().cpu().numpy()
+    P = 14
+    grid = s.reshape(s.shape[0] // P, P, s.shape[1] // P, P).mean(axis=(1, 3), dtype=np.float64)
+    return {"rows": float(np.abs(s[g["rows_idx"], :] - g["rows"][0]).mean()), "patch_means": float(np.abs(grid - g["patch_mean"][0]).mean()),
+            "golden": "tests/golden/" + GOLDEN_OF[name], "note": "item 0 of the seeded batch = the reference's own output for that item"}
+
+
+def config_leg(name, rank, world, dev, sync, args, steps=3):
+    """One more BASELINE.json configuration timed in the same run: `steps` timed steps behind one warm-up step with the same
+    batches in flight as the headline, its own roofline object (dominant kernel, every kernel alone) and the score-map MAE of item 0 against
+    the committed golden of the reference.  Seed = the golden's seed, so item 0 is the golden's item."""
+    import numpy as np
+    seed = int(np.load(os.path.join(REPO, "tests", "golden", GOLDEN_OF[name]))["seed"])
+    w = Workload(name, rank, dev, inflight=args.inflight, dtype=args.dtype, seed=seed).start_pipeline()
+    e, tk = timed_steps(w.step, sync, steps, 1, dev)
+    score0 = w.pipe.result(tk)["score_map_ref_cross"][0].clone()
+    v = world * w.B * steps / e
+    fq = w.flops_per_query()
+    leg = {"metric": w.metric(), "value": v, "unit": "query-images/sec", "steps": steps, "warmup": 1, "ms_per_step": 1e3 * e / steps,
+           "workload": w.describe(world), "batches_in_flight": w.inflight, "gflop_per_query": fq / 1e9,
+           "whole_path_tflops_per_gpu": v * fq / 1e12 / world, "frac_of_mfma_peak": v * fq / 1e12 / world / PEAK_BF16_TFLOPS,
+           "nonfinite_score_values": w.pipe.nonfinite_count(), "dtype": args.dtype}
+    if rank == 0:
+        leg["score_map_mae_vs_reference_golden"] = golden_mae(name, score0)
+        rows, dom = profile_kernels(w, prof_steps=2)
+        leg["roofline"] = roofline_of(dom, traffic_profile=None)
+        leg["kernels"] = [{k: (round(x[k], 3) if isinstance(x[k], float) else x[k]) for k in ("kernel", "launches_per_step", "avg_us", "tflops", "gbytes_per_s")}
+                          for x in sorted(rows, key=lambda x: -x["total_ms"])[:6]]
+    del w
+    torch.cuda.empty_cache()
+    return leg
 
 
 def self_launch(args) -> int:
@@ -383,6 +491,8 @@ def main():
                     "default of the path (score-map MAE 1e-4); bf16 is BASELINE.json's wording for cfg-2 (MAE 8e-4, fp32's range)")
     ap.add_argument("--global-batch", type=int, default=128, help="fixed global batch of the strong-scaling leg (BASELINE.json configs[3]: ViT-B/14, 5 refs, "
                     "global bs=128 batch-sharded over the ranks); reported as scaling_cfg4 with mode 'strong'")
+    ap.add_argument("--rowln", type=int, default=1, choices=(0, 1, 2), help=argparse.SUPPRESS)  # cs_debug_rowln_enable (A/B runs; was the CS_NO_ROWLN environment read)
+    ap.add_argument("--no-more-configs", action="store_true", help="skip the short legs of BASELINE configs[2] (ViT-B, 10 refs, bs 8) and configs[4] (1036 x 1036, bs 2)")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16-operand leg of the headline workload (dtype_legs)")
     ap.add_argument("--no-repeats", action="store_true", help="skip the four extra K-step regions behind the timed one (value_median_of_5)")
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo rehearsal of the rank plumbing
@@ -405,9 +515,9 @@ def main():
 
     if args.inflight < 0:
         raise SystemExit("--inflight must be >= 0")
-    if os.environ.get("CS_NO_ROWLN"):  # A/B runs (process-wide debug switch): 1 = the decoder's sub-block closings as GEMM + LayerNorm + GEMM
-        from crossscore_amd import _lib  # launches again; 2 = linear + LayerNorm in one launch, the next linear as a GEMM of its own
-        _lib.load().cs_debug_rowln_enable(2 if os.environ["CS_NO_ROWLN"] == "2" else 0)
+    if args.rowln != 1:  # A/B runs (process-wide debug switch): 0 = the decoder's sub-block closings as GEMM + LayerNorm + GEMM launches again;
+        from crossscore_amd import _lib  # 2 = linear + LayerNorm in one launch, the next linear as a GEMM of its own
+        _lib.load().cs_debug_rowln_enable(args.rowln)
     wl = Workload(args.workload, rank, dev, args.lanes, args.chunk, inflight=args.inflight, dtype=args.dtype)
     net, arch, B, N, H, W = wl.net, wl.arch, wl.B, wl.N, wl.H, wl.W
     # ---- the same workload with ONE batch at a time (no pipeline; the library's two encoder lanes inside the forward): reported beside
@@ -490,27 +600,18 @@ def main():
         del ws
         torch.cuda.empty_cache()
 
+    # ---- BASELINE.json configs[2] and configs[4] (ViT-B with 10 refs; the 1036 x 1036 query) in the same line: short legs with their own roofline
+    #      and golden MAE ----
+    more_legs = {}
+    if not args.no_more_configs:
+        for nm in ("cfg3", "cfg5"):
+            if nm != args.workload:
+                more_legs[nm] = config_leg(nm, rank, world, dev, sync, args)
+
     # ---- per-kernel HIP-event timing (separate pass so the events do not perturb the timed region) ----
     result = None
     if rank == 0:
-        # every kernel alone on the GPU: one lane, the whole batch as one encoder chunk (the timed region above overlaps two lanes,
-        # where a kernel's wall duration also contains its neighbour's work); `bench.py --lanes 1 --chunk <images>` under rocprofv3
-        # reproduces exactly these launches (profiles/)
-        saved = (net.lanes, net.enc_chunk_images)
-        net.lanes, net.enc_chunk_images = 1, B * (1 + N)
-        net._mark_dirty()
-        wl.direct()  # rebuilds the handle with the new lane / chunk settings
-        net.profile_enable(True)
-        prof_steps = 3
-        for _ in range(prof_steps):
-            wl.direct()
-        rows = kernel_table(net)
-        net.profile_enable(False)
-        net.lanes, net.enc_chunk_images = saved
-        net._mark_dirty()
-        for rrow in rows:
-            rrow["launches_per_step"] = rrow["launches"] // prof_steps
-        dom = max((x for x in rows if x["tflops"]), key=lambda x: x["total_ms"])
+        rows, dom = profile_kernels(wl)
         flops_q = wl.flops_per_query()
         value = world * B * args.steps / elapsed
         result = {
@@ -535,10 +636,16 @@ def main():
             "roofline": roofline_of(dom),
             "kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in x.items() if k not in ("flops", "bytes")} for x in rows],
         }
+        if args.workload in GOLDEN_OF:
+            import numpy as np
+            if int(np.load(os.path.join(REPO, "tests", "golden", GOLDEN_OF[args.workload]))["seed"]) == wl.seed:
+                result["score_map_mae_vs_reference_golden"] = golden_mae(args.workload, score[0])
         if single is not None:
             result["one_batch_at_a_time"] = single
         if cfg4 is not None:
             result["scaling_cfg4"] = cfg4
+        for nm, leg in more_legs.items():
+            result["config_" + nm] = leg
         if args.kernels:
             for x in rows:
                 print(x, file=sys.stderr)
@@ -579,13 +686,14 @@ def main():
         if world == 1 and not args.no_eager:
             # the north-star target: >= 10x the PyTorch-ROCm eager reference.  The reference's GPU mode is 16-mixed autocast with
             # SDPA attention (config/default_predict.yaml:25); its fp32 forward is the parity target.
-            variants = ("fp32_sdpa", "fp16_autocast_sdpa", "bf16_autocast_sdpa") + (("fp32", "bf16_autocast") if args.eager else ())
+            variants = ("fp32_sdpa", "fp16_autocast_sdpa", "bf16_autocast_sdpa", "fp32_sdpa_unfused", "fp16_autocast_sdpa_unfused") + (("fp32", "bf16_autocast") if args.eager else ())
             eb = eager_baseline(arch, wl.sd, wl.tq, wl.tr, dev, variants=variants)
             result["eager_baseline"] = eb
             for k, v in eb.items():
                 if "value" in v:
                     result[f"speedup_vs_eager_{k}"] = value / v["value"]
-            result["target_10x_met"] = {k: (value / v["value"] >= 10.0) for k, v in eb.items() if "value" in v}
+            # the target is judged against the fused-op legs only (the `_unfused` ones are the handicapped baseline of rounds 1-5, kept for the record)
+            result["target_10x_met"] = {k: (value / v["value"] >= 10.0) for k, v in eb.items() if "value" in v and not k.endswith("_unfused")}
         legs = {args.dtype: {"value": value, "ms_per_step": 1e3 * elapsed / args.steps, "score_map_mae": None}}
         if other is not None:
             legs[other["dtype"]] = {"value": other["value"], "ms_per_step": other["ms_per_step"], "score_map_mae": None,

@@ -61,6 +61,7 @@ SYMBOLS = {
     "cs_debug_patch_fused_enable": (None, [_i]),
     "cs_set_lanes": (_i, [_vp, _i]),
     "cs_redraw_lane_streams": (_i, [_vp]),
+    "cs_debug_stream_probe_log": (None, [_i]),
     "cs_op_pos_bicubic": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pos_bicubic_ex": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_pe_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -70,6 +70,7 @@ hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_
 namespace {
 
 thread_local std::string g_err;
+int g_debug_stream_log = 0;  // cs_debug_stream_probe_log: one stderr line per lane-stream candidate of the overlap probe
 int g_rowln_off = 0;  // cs_debug_rowln_enable(0): the decoder goes back to GEMM + LayerNorm launches (A/B runs and tests; process-wide)
 int g_rowln_no_next = 0;  // cs_debug_rowln_enable(2): linear + LayerNorm in one launch, the following linear as a GEMM of its own (round 4's first form)
 int fail(int code, const char* fmt, ...) {
@@ -821,7 +822,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
           for (int attempt = 0; attempt < 8; ++attempt) {
             bool ok = false;
             if (int r = streams_overlap(h->lane_st[l - 1], h->lane_st[l], &ok)) return r;
-            if (getenv("CS_DEBUG_STREAMS")) fprintf(stderr, "[crossscore_hip] lane %d stream candidate %d: %s\n", l, attempt, ok ? "overlaps" : "serialises");
+            if (g_debug_stream_log) fprintf(stderr, "[crossscore_hip] lane %d stream candidate %d: %s\n", l, attempt, ok ? "overlaps" : "serialises");
             if (ok) break;
             rejected.push_back(h->lane_st[l]);
             h->lane_st[l] = nullptr;
@@ -892,6 +893,25 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       if (h->capture && !L.rc)
         L.rc = tap_copy(h, "enc_layer_" + std::to_string(l), x, (size_t)i0 * p.T * C * 4, (size_t)Mc * C * 4, (size_t)p.I * p.T * C * 4, 0, {p.I, p.T, C}, s);
     };
+    // The LayerNorm-folded epilogues (statistics layouts: consumer ln_sp == 1, producer stats_sp == N / 64) exist only in the 256-tile kernel:
+    // a chunk takes that branch only if the kernel accepts ALL THREE of its folded shapes -- the same answer for every layer of the chunk, since a
+    // layer's producer feeds the next layer's consumer.  Whatever makes it decline (cs_debug_gemm256_enable(0), cs_debug_gemm256_kmin above C, a
+    // chunk below 256 rows or beyond the kernel's 32-bit byte offsets) sends the chunk to the plain path below, which is correct for a fold256
+    // handle (LayerNorm launches with ones / zeros, gamma in the packed weights, beta in the c vectors).
+    bool fold256_chunk = false;
+    if (h->fold256 && Mc >= 256) {
+      const EncLayer& E0 = h->enc[0];
+      CsGemmParams cq = gp(u, C, E0.Wqkv, C, Mc, h->qkv_n, C, E0.c_qkv, r1, h->qkv_n);
+      cq.col_s = E0.s_qkv; cq.ln_part = p.lnstat[slot]; cq.ln_sp = 1;
+      CsGemmParams c1 = gp(u, C, E0.W1, C, Mc, F, C, E0.c_1, r1, F);
+      c1.col_s = E0.s_1; c1.ln_part = p.lnstat[slot]; c1.ln_sp = 1;
+      CsGemmParams po = gp(p.ob[slot], C, E0.Wo, C, Mc, C, C, E0.bo, x, C);
+      po.resid = x; po.ldr = C; po.out_f16 = u; po.stats_out = p.stats[slot]; po.stats_sp = C / 64;
+      CsGemmParams p2 = gp(r1, F, E0.W2, F, Mc, C, F, E0.b2, x, C);
+      p2.resid = x; p2.ldr = C; p2.out_f16 = u; p2.stats_out = p.stats[slot]; p2.stats_sp = C / 64;
+      fold256_chunk = cs_gemm256_supported(&cq, CS_EPI_LN_F16) && cs_gemm256_supported(&c1, CS_EPI_LN_GELU_F16) &&
+                      cs_gemm256_supported(&po, CS_EPI_RESID_F32_LN) && cs_gemm256_supported(&p2, CS_EPI_RESID_F32_LN);
+    }
     for (int l = 0; l < c.enc_layers; ++l) {
       if (l != stage) continue;
       const EncLayer& E = h->enc[l];
@@ -918,7 +938,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         tap_layer(l);
         continue;
       }
-      if (h->fold256 && Mc >= 256) {
+      if (fold256_chunk) {
         // Wide backbones (r5): LayerNorm folded into the 256-tile GEMM's epilogues.  The residual epilogues (out-projection, fc2) also write
         // u = 16-bit(x) and per-row partial sums, a row-statistics kernel (one thread per row) turns them into (mean, rstd), and the consuming
         // projection (QKV, fc1) applies rstd * (acc - mean * s[n]) + c[n].  No LayerNorm pass over the fp32 stream except layer 0's norm1
@@ -1355,6 +1375,7 @@ int cs_nonfinite_count(cs_handle h, long long* count) {
 // single-op entry points
 // ---------------------------------------------------------------------------------------------------------
 static int g_op_bf16 = 0;  // operand type of the cs_op_* entry points below (a handle carries its own: cs_config.operand_dtype)
+void cs_debug_stream_probe_log(int on) { g_debug_stream_log = on; }
 void cs_debug_rowln_enable(int on) { g_rowln_off = on == 0 ? 1 : 0; g_rowln_no_next = on == 2 ? 1 : 0; }
 
 // out_f32 / out_f16 (M, C) = LayerNorm(resid + A (M, C) W (C, C)^T + bias): the decoder's sub-block closing as the forward runs it (C = 384)

@@ -25,13 +25,23 @@ def shard_bounds(global_batch: int, world_size: int, rank: int) -> Tuple[int, in
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+# Collectives are skipped when the group has one rank (nothing to exchange).  Tests set this to True to push the very same calls through
+# the backend on a world-size-1 group (tests/test_rccl_single_rank.py: RCCL on the one GPU a test box has).
+COLLECTIVES_AT_WORLD_1 = False
+
+
+def _single() -> bool:
+    return not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not COLLECTIVES_AT_WORLD_1)
+
+
+def init_from_env(backend: str | None = None, single_rank_group: bool = False) -> Tuple[int, int, int]:
     """(rank, local_rank, world_size) from the torchrun environment; initialises the process group when
-    WORLD_SIZE > 1.  backend defaults to nccl (= RCCL on ROCm) when a GPU is present, else gloo."""
+    WORLD_SIZE > 1 (or, with single_rank_group, also for WORLD_SIZE = 1: the RCCL rehearsal on one GPU).
+    backend defaults to nccl (= RCCL on ROCm) when a GPU is present, else gloo."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -48,7 +58,7 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
 def gather_means(local_means: torch.Tensor, global_batch: int) -> torch.Tensor:
     """All ranks receive the (global_batch,) per-image mean scores in item order.  Shards may be ragged, so each
     rank pads to the largest shard before the all_gather."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return local_means
     world = dist.get_world_size()
     sizes = [shard_bounds(global_batch, world, r) for r in range(world)]
@@ -61,7 +71,7 @@ def gather_means(local_means: torch.Tensor, global_batch: int) -> torch.Tensor:
 
 
 def max_over_ranks(value: float, device: torch.device | str = "cpu") -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -83,7 +93,7 @@ def rank_census(device: torch.device | str = "cpu", **extra) -> List[dict]:
         rec.update(device_name=pr.name, pci_bus_id=f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}",
                    uuid=str(getattr(pr, "uuid", "")))
     rec.update(extra)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return [rec]
     out: List[dict] = [None] * dist.get_world_size()  # type: ignore[list-item]
     dist.all_gather_object(out, rec)
@@ -107,7 +117,7 @@ def backend_info() -> dict:
 
 
 def barrier() -> None:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if not _single():
         dist.barrier()
 
 

@@ -134,6 +134,10 @@ size_t cs_workspace_bytes(cs_handle h, int B, int N, int H, int W);
  * two streams that passed the overlap probe can still end up serialised when other queues were created in between. */
 int cs_set_lanes(cs_handle h, int lanes);
 int cs_redraw_lane_streams(cs_handle h);
+/* debug switch, process-wide (see cs_debug_* below): 1 = one stderr line per lane-stream candidate of the overlap probe (which streams a handle drew
+ * and whether they dispatch side by side); default 0.  Replaces the CS_DEBUG_STREAMS environment read of rounds 3-5: the product path reads no
+ * environment variable. */
+void cs_debug_stream_probe_log(int on);
 
 /* Launch census of the last cs_forward / cs_forward_cached / cs_encode_references on this handle: kernel launches, host wall time of the
  * call (all work is enqueued, nothing is waited for: this is what a rank's CPU thread pays per forward -- bench.py reports it per rank, the
@@ -252,7 +256,9 @@ int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, c
                         uint16_t* u_out, int M, float eps, cs_stream stream);
 /* debug switch, process-wide (see cs_debug_* above).  Kernel selection of cs_op_gemm / the forward's linears: 1 (default) = shapes with K >= 384, N a multiple of
  * 256 and M >= 256 run on the 256 x 256 x 64-tile kernel (csrc/gemm256.hip), everything else on the 128-row kernel (csrc/gemm.hip);
- * 0 = the 128-row kernel for every shape.  The two kernels add the same products in the same order: their results are bit-identical (tested). */
+ * 0 = the 128-row kernel for every shape (a wide backbone's LayerNorm-folded chunks, whose epilogues exist only in the 256-tile kernel, then run
+ * LayerNorm launches + the 128-row kernel's plain epilogues: cs_forward asks cs_gemm256_supported per chunk).  The two kernels add the same products
+ * in the same order: their results are bit-identical (tested). */
 void cs_debug_gemm256_enable(int on);
 /* debug switch, process-wide: the smallest K the 256-tile kernel takes (default 384; tools/qkv_k384_try.py compares 384 with 512) */
 void cs_debug_gemm256_kmin(int k);

@@ -346,6 +346,47 @@ def test_gemm256_layernorm_folded_chain(M, Cc, K, bf16):
         lib.cs_debug_set_op_operand_dtype(0)
 
 
+@pytest.mark.parametrize("offset", [8.0, 30.0])
+def test_gemm256_layernorm_fold_with_a_row_offset(offset):
+    """the folded LayerNorm takes its variance as E[x^2] - mu^2 from fp32 sums and multiplies 16-bit(x), the UN-normalised rows.
+    Both lose accuracy when a row's mean is large against its spread.  Rows x = offset * sigma + N(0, sigma), sigma = 1, C = 768, fp16 operands:
+      * statistics: the fp32 sums carry ~6e-8 * C * offset^2 of absolute error -> rstd relative error <= 1e-4 at offset 30;
+      * consumer: the half-precision step of x is 2^-7 at |x| in [8, 16) and 2^-6 in [16, 32): rounding noise 2.3e-3 / 4.5e-3 rms per element
+        against sigma = 1, which a projection with unit-norm rows passes on 1:1 -- the supported range is |mu| <~ 30 sigma at about 5e-3 of LN output
+        error; beyond it ln_fold = 2 (LayerNorm launches on the fp32 stream) is the setting.  A DINOv2 residual row has |mu| << sigma (sigma is set
+        by its outlier channels), which the +-300 channels of test_gemm256_layernorm_folded_chain model."""
+    M, Cc, K = 512, 768, 768
+    g = _rng(int(offset) + 901)
+    A = _bf(_t(g.standard_normal((M, K), dtype=np.float32)))
+    W = _bf(_t(g.standard_normal((Cc, K), dtype=np.float32) / math.sqrt(K) * 0.5))
+    b = _t(0.1 * g.standard_normal((Cc,), dtype=np.float32))
+    r = _t(g.standard_normal((M, Cc), dtype=np.float32) * 0.85 + offset)
+    sp = Cc // 64
+    x16 = torch.zeros((M, Cc), dtype=torch.float16, device=DEV)
+    st = torch.zeros((M, sp, 2), device=DEV)
+    x = r.clone()
+    hh.gemm(A, W, b, _lib.EPI_RESID_F32_LN, resid=x, out=x, out_f16=x16, stats_out=st)
+    stat = hh.ln_finalize(st, Cc)
+    torch.cuda.synchronize()
+    mu, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    e_mu = float((stat[:M, 0, 0].double() - mu).abs().max())
+    e_rs = float(((stat[:M, 0, 1].double() * torch.sqrt(var + 1e-6)) - 1).abs().max())
+    gam = _t(1 + 0.2 * g.standard_normal((Cc,), dtype=np.float32))
+    bet = _t(0.1 * g.standard_normal((Cc,), dtype=np.float32))
+    N = 3 * Cc
+    Wf = _t(g.standard_normal((N, Cc), dtype=np.float32) / math.sqrt(Cc))
+    bb = _t(0.1 * g.standard_normal((N,), dtype=np.float32))
+    Wp = _bf(Wf * gam[None, :])
+    out = hh.gemm(x16, Wp, bb + Wf @ bet, _lib.EPI_LN_F16, ln_part=stat, col_s=Wp.float().sum(1), ln_eps=1e-6)
+    torch.cuda.synchronize()
+    true = orc.layer_norm(x.cpu(), gam.cpu(), bet.cpu(), 1e-6).to(DEV) @ Wf.t() + bb
+    err = (out.float() - true).abs()
+    print(f"row offset {offset} sigma: mean err {e_mu:.2e}, rstd rel err {e_rs:.2e}, consumer err mean {float(err.mean()):.2e} max {float(err.max()):.2e}")
+    assert e_mu < 2e-4 and e_rs < 3e-4, (e_mu, e_rs)
+    step = 2.0 ** -7 if offset < 16 else 2.0 ** -6
+    assert float(err.mean()) < 3 * step / math.sqrt(12) + 1e-3 and float(err.max()) < 12 * step + 1e-2, (float(err.mean()), float(err.max()))
+
+
 def test_gemm_patch_epilogue_and_im2col():
     """im2col + patch GEMM == conv patchify + cls/pos placement (HF:97-149), rows m -> img*T + 1 + p."""
     I, H, W, P, Cc = 3, 75, 90, 14, 128

@@ -249,22 +249,43 @@ def test_vits_width_stages_match_the_references_intermediates(dtype, variant):
     assert float(aw.max()) < (2.4e-2 if dtype == "bf16" else 3.1e-3), float(aw.max())
 
 
+@pytest.mark.parametrize("routing", ["folded", "ln_launches", "gemm256_off"])
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-def test_vitb_width_stages_match_the_oracle_taps(dtype):
-    """C = 768 (two encoder layers; B = 2, N = 3, 98 x 112): the 256-tile GEMM with its residual / GELU epilogues at K = 768 / 3072, LayerNorm
-    launches, attention at dh 64 / 96 -- against the oracle's same-named taps (fp32 CPU; the oracle is pinned by the reference's goldens)."""
-    net, sd = _wide_net(BASE2, 9, dtype)
+def test_vitb_width_stages_match_the_oracle_taps(dtype, routing):
+    """C = 768 (two encoder layers; B = 2, N = 3, 98 x 112: 456 encoder rows in one chunk) against the oracle's same-named taps (fp32 CPU; the
+    oracle is pinned by the reference's goldens), in the three routings a wide backbone can take -- and WHICH one ran is asserted from
+    cs_forward_stats, so that a silent fall-back cannot pass for the default:
+      folded       (default, ln_fold = 0) the 256-tile GEMM with LayerNorm folded into its epilogues: residual epilogues write 16-bit(x) + row sums,
+                   ln_stats turns them into (mean, rstd), QKV / fc1 apply them; ONE LayerNorm launch in the encoder (layer 0's norm1)
+      ln_launches  (ln_fold = 2) LayerNorm kernels + the 256-tile GEMM's plain epilogues
+      gemm256_off  (cs_debug_gemm256_enable(0) on a folded handle) the chunk must fall to LayerNorm launches + the 128-row kernel, whose
+                   folded statistics layouts differ (ADVICE r5 #1: this used to fail inside cs_gemm_check)."""
+    from crossscore_amd import _lib
+    lib = _lib.load()
+    over = {"ln_fold": 2} if routing == "ln_launches" else {}
+    net, sd = _wide_net(BASE2, 9, dtype, **over)
     q, r = synth.make_inputs(2, 3, 98, 112, 9)
     taps = {}
     ref = orc.forward(orc.to_torch(sd), dict(enc_heads=net.arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), taps=taps)
-    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)
-    torch.cuda.synchronize()
+    lib.cs_debug_gemm256_enable(0 if routing == "gemm256_off" else 1)
+    try:
+        out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)
+        torch.cuda.synchronize()
+    finally:
+        lib.cs_debug_gemm256_enable(1)
     k = net.forward_stats()["kernels"]
     print("kernels:", k)
-    assert "panel" not in k and "rowln" not in k and k.get("attn64") == 2 and k.get("attn96") == 4 and k.get("gemm256", 0) >= 9, k
+    assert "panel" not in k and "rowln" not in k and k.get("attn64") == 2 and k.get("attn96") == 4, k
+    if routing == "folded":
+        # two layers: statistics behind out-projection x 2 and behind layer 0's fc2 (the last layer's fc2 feeds the final LayerNorm)
+        assert k.get("ln_stats") == 3 and k.get("ln1") == 1 and "ln2" not in k and k.get("gemm256", 0) >= 9, k
+    elif routing == "ln_launches":
+        assert "ln_stats" not in k and k.get("ln1") == 2 and k.get("ln2") == 2 and k.get("gemm256", 0) >= 9, k
+    else:
+        assert "ln_stats" not in k and "gemm256" not in k and k.get("ln1") == 2 and k.get("ln2") == 2, k
     _wide_stages(net, {k: v.numpy() for k, v in taps.items() if isinstance(v, torch.Tensor)}, 8.0 if dtype == "bf16" else 1.0)
     d = (out["score_map_ref_cross"].cpu() - ref["score_map_ref_cross"]).abs()
-    print(f"score map vs the oracle: MAE {float(d.mean()):.2e} max {float(d.max()):.2e}")
+    print(f"score map vs the oracle ({routing}): MAE {float(d.mean()):.2e} max {float(d.max()):.2e}")
     assert float(d.mean()) < (1e-3 if dtype == "bf16" else 2e-4)
 
 

@@ -17,21 +17,6 @@ if os.environ.get("CS_ATTN_CHILD"):
     for _ in range(3): hh.attention(Q, K, V, H, dh)
     torch.cuda.synchronize()
     lib = _lib.load()
-    if os.environ.get("CS_ATTN8", "0") != "0":  # the eight-wave form (tools/experiments/attn_eight_wave_and_mfma_rowsum.patch applied): groups A (waves 0-3) and B (waves 4-7)
-        buf = (ctypes.c_ulonglong * (64 * 8 * 8))()
-        lib.cs_attn8_debug_read.argtypes = [ctypes.c_void_p]
-        assert lib.cs_attn8_debug_read(buf) == 0
-        d = np.frombuffer(buf, dtype=np.uint64).reshape(64, 8, 8).astype(np.float64)
-        nwg = B * H * ((Lq + 255) // 256)
-        d = d[: min(64, (nwg + 24) // 25)]
-        nit = (Lk + 63) // 64 + 1
-        print(f"eight-wave form: iterations {nit}; cycles per iteration per wave: total {d[..., 6].mean() / nit:.0f}")
-        for gname, sl in (("group A (waves 0-3)", slice(0, 4)), ("group B (waves 4-7)", slice(4, 8))):
-            per = d[:, sl, :4].mean((0, 1)) / nit
-            print(f"  {gname}: staging {per[0]:.0f}  MFMA segment {per[1]:.0f}  VALU segment {per[2]:.0f}  barriers (2 per iteration) {per[3]:.0f}")
-        us = d[..., 7].mean() / 100.0
-        print(f"  loop wall time per workgroup {us:.1f} us -> in-kernel clock {d[..., 6].mean() / us / 1e3:.2f} GHz; workgroups {nwg}")
-        sys.exit(0)
     buf = (ctypes.c_ulonglong * (64 * 4 * 8))()
     lib.cs_attn_debug_read.argtypes = [ctypes.c_void_p]
     assert lib.cs_attn_debug_read(buf) == 0
