@@ -75,6 +75,7 @@ SYMBOLS = {
     "cs_gemm_column_tiles": (_i, [_i]),
     "cs_debug_gemm256_enable": (None, [_i]),
     "cs_debug_gemm256_kmin": (None, [_i]),
+    "cs_debug_panel_impl": (None, [_i]),
     "cs_panel_supported": (_i, [_i, _i]),
     "cs_panel_image_bytes": (_sz, [_i]),
     "cs_op_panel_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -8,12 +8,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrossscore_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip", "patch.hip", "rowln.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "panel.hip", "panel4.hip", "patch.hip", "rowln.hip"]
 
 
 # panel.hip: its GELU arithmetic shares one wave's issue stream with the MFMAs; SLP-packed v_pk_fma_f32 (dependent-issue nops)
 # costs more there than scalar fma chains
-EXTRA_FLAGS = {"panel.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"panel.hip": ["-fno-slp-vectorize"], "panel4.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -55,7 +55,7 @@ hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hi
 hipError_t cs_score_gray16_launch(const float* score, size_t n, int signed_range, uint16_t* out, hipStream_t stream);
 hipError_t cs_score_rgb_launch(const float* score, size_t n, float vmin, float vmax, const uint8_t* lut, uint8_t* out, hipStream_t stream);
 int cs_panel_supported(int C, int mlp_ratio);
-size_t cs_panel_image_bytes(int with_outproj);
+size_t cs_panel8_image_bytes(int with_outproj);
 hipError_t cs_panel_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
                                 h16_t* img, int bf16, hipStream_t st);
 const char* cs_panel_check(const CsPanelParams* p);
@@ -63,6 +63,11 @@ int cs_rowln_supported(int C);
 const char* cs_rowln_check(const CsRowLnParams* p, int C);
 hipError_t cs_rowln_launch(const CsRowLnParams* p, int C, int bf16, hipStream_t st);
 hipError_t cs_panel_launch(const CsPanelParams* p, hipStream_t st);
+// panel4.hip: the four-wave form of the same kernel (its own weight image)
+size_t cs_panel4_image_bytes(int with_outproj);
+hipError_t cs_panel4_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
+                                 h16_t* img, int bf16, hipStream_t st);
+hipError_t cs_panel4_launch(const CsPanelParams* p, hipStream_t st);
 hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int oh,
                                 int ow, const float* mean, const float* stdv, float* out, float* scratch, hipStream_t stream);
 }
@@ -71,6 +76,7 @@ namespace {
 
 thread_local std::string g_err;
 int g_debug_stream_log = 0;  // cs_debug_stream_probe_log: one stderr line per lane-stream candidate of the overlap probe
+int g_panel_impl = 0;  // cs_debug_panel_impl: which token-panel kernel new handles and the cs_op_panel_* entry points use: 0 = panel.hip (8 waves), 1 = panel4.hip (4 waves)
 int g_rowln_off = 0;  // cs_debug_rowln_enable(0): the decoder goes back to GEMM + LayerNorm launches (A/B runs and tests; process-wide)
 int g_rowln_no_next = 0;  // cs_debug_rowln_enable(2): linear + LayerNorm in one launch, the following linear as a GEMM of its own (round 4's first form)
 int fail(int code, const char* fmt, ...) {
@@ -122,6 +128,7 @@ struct cs_model {
   // launch census of the last forward (cs_forward_stats): kernel launches by kernel, and the host time the call spent enqueueing them
   std::map<std::string, int> census;
   double host_enqueue_ms = 0.0;
+  int panel_impl = 0;   // which panel kernel the images of this handle were packed for (g_panel_impl at cs_finalize)
   bool panel = false;   // encoder layers run as QKV GEMM + attention + ONE token-panel kernel (panel.hip; hidden == 384 only)
   float *ones = nullptr, *zeros = nullptr;  // [C]: layer 0's norm1 without gamma/beta (they are folded into its QKV projection)
   bool lnfold = false;  // encoder LayerNorms folded into the QKV / fc1 projections (no separate LN pass)
@@ -325,9 +332,9 @@ struct Launcher {
     const double M = q.M, C = m->cfg.hidden, F = (double)m->cfg.mlp_ratio * C;
     // algorithmic bytes: x read + written (fp32), attention output read, u written (fp16), the weight stream once
     begin(40, 2.0 * M * C * C * (q.attn_o ? 1 : 0) + 4.0 * M * C * F,
-          M * C * (8.0 + (q.attn_o ? 2.0 : 0.0) + (q.u_out ? 2.0 : 0.0)) + (double)cs_panel_image_bytes(q.attn_o ? 1 : 0));
-    m->census["panel"]++;
-    hipError_t e = cs_panel_launch(&q, st);
+          M * C * (8.0 + (q.attn_o ? 2.0 : 0.0) + (q.u_out ? 2.0 : 0.0)) + (double)(2 * (q.attn_o ? 1 : 0) + 16) * C * C);
+    m->census[m->panel_impl ? "panel4" : "panel"]++;
+    hipError_t e = m->panel_impl ? cs_panel4_launch(&q, st) : cs_panel_launch(&q, st);
     end();
     if (e != hipSuccess) { rc = fail(CS_ERR_HIP, "panel launch: %s", hipGetErrorString(e)); return false; }
     return true;
@@ -468,6 +475,7 @@ cs_handle cs_create(const cs_config* cfg) {
   m->lnfold = c.ln_fold == 1 && (m->ln_sp == 4 || m->ln_sp == 8 || m->ln_sp == 16);
   // default for ViT-S: out-proj + norm2 + MLP + next norm1 in one launch per layer, the 4C hidden never leaves the registers
   m->panel = c.enc_fused != 1 && !m->lnfold && cs_panel_supported(c.hidden, c.mlp_ratio);
+  m->panel_impl = g_panel_impl;
   // wide backbones (r5): the encoder's LayerNorms ride in the 256-tile GEMM's epilogues; ln_fold = 2 keeps the separate LayerNorm launches
   m->fold256 = c.ln_fold == 0 && !m->panel && c.hidden >= 512 && c.hidden % 256 == 0 && (c.mlp_ratio * c.hidden) % 256 == 0;
   return m;
@@ -636,8 +644,9 @@ int cs_finalize(cs_handle h) {
     L.s_qkv = L.c_qkv = L.s_1 = L.c_1 = nullptr;
     L.panel_img = nullptr;
     if (h->panel) {
-      ALLOC_BF(img, cs_panel_image_bytes(1) / sizeof(h16_t))
-      HIPCHK(cs_panel_pack_launch(ow->d, l1->d, f1w->d, n2w->d, f2w->d, l2->d, img, c.operand_dtype, st));
+      ALLOC_BF(img, (h->panel_impl ? cs_panel4_image_bytes(1) : cs_panel8_image_bytes(1)) / sizeof(h16_t))
+      if (h->panel_impl) HIPCHK(cs_panel4_pack_launch(ow->d, l1->d, f1w->d, n2w->d, f2w->d, l2->d, img, c.operand_dtype, st));
+      else HIPCHK(cs_panel_pack_launch(ow->d, l1->d, f1w->d, n2w->d, f2w->d, l2->d, img, c.operand_dtype, st));
       L.panel_img = img;
     }
     if (fold) {
@@ -1587,9 +1596,13 @@ int cs_op_pack_f16(const float* w, int rows, int K, uint16_t* out, int ldo, cons
 int cs_op_panel_pack(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
                      uint16_t* img, cs_stream stream) {
   if (!w1 || !w2 || !img) return fail(CS_ERR_BAD_ARG, "panel_pack: null argument");
-  HIPCHK(cs_panel_pack_launch(wo, ls1, w1, g2, w2, ls2, img, g_op_bf16, (hipStream_t)stream));
+  if (g_panel_impl) HIPCHK(cs_panel4_pack_launch(wo, ls1, w1, g2, w2, ls2, img, g_op_bf16, (hipStream_t)stream));
+  else HIPCHK(cs_panel_pack_launch(wo, ls1, w1, g2, w2, ls2, img, g_op_bf16, (hipStream_t)stream));
   return 0;
 }
+
+size_t cs_panel_image_bytes(int with_outproj) { return g_panel_impl ? cs_panel4_image_bytes(with_outproj) : cs_panel8_image_bytes(with_outproj); }
+void cs_debug_panel_impl(int impl) { g_panel_impl = impl ? 1 : 0; }
 
 int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, const float* bo, const float* b1, const float* b2,
                         uint16_t* u_out, int M, float eps, cs_stream stream) {
@@ -1597,7 +1610,8 @@ int cs_op_encoder_panel(float* x, const uint16_t* attn_o, const uint16_t* img, c
   q.x = x; q.attn_o = attn_o; q.img = img; q.bo = bo; q.b1 = b1; q.b2 = b2; q.u_out = u_out; q.M = M; q.eps = eps;
   q.bf16 = g_op_bf16;
   if (const char* e = cs_panel_check(&q)) return fail(CS_ERR_BAD_ARG, "%s", e);
-  HIPCHK(cs_panel_launch(&q, (hipStream_t)stream));
+  if (g_panel_impl) HIPCHK(cs_panel4_launch(&q, (hipStream_t)stream));
+  else HIPCHK(cs_panel_launch(&q, (hipStream_t)stream));
   return 0;
 }
 

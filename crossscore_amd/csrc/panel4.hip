@@ -1,0 +1,481 @@
+// Encoder token-panel kernel, second structure (round 6): FOUR waves, one per SIMD, each with the whole 512-register file.
+// Same contract as panel.hip (ViT-S: C = 384, MLP 4C = 1536), in ONE launch per encoder layer, for 128-row panels of the residual stream:
+//
+//   x   += attn_o Wo'^T + bo'                       Dinov2SelfOutput + layer_scale1 + residual   (HF modeling_dinov2.py:249-252,365-370)
+//   x   += GELU(LN2(x) W1'^T + b1') W2'^T + b2'     norm2 + Dinov2MLP + layer_scale2 + residual  (HF:373-378, 293-297)
+//   u    = f16((x - mean(x)) * rstd(x))             norm1 of the next layer (its gamma/beta live in that layer's packed Wqkv / bias)
+//
+// Why a second structure.  panel.hip gives every SIMD a pair of waves that share 32 rows: each weight fragment read from LDS feeds ONE MFMA
+// (54 fragment reads, 48 one-KiB LDS-DMA pieces and two 8-wave rendezvous per 48 MFMAs and SIMD), and the rendezvous of eight skewed waves
+// cost a quarter of every tick (profiles/r05_panel_ablate.txt).  Here the output COLUMNS of the two residual products are split over the waves
+// instead of the rows:
+//   * wave w owns columns 96 w .. 96 w + 95 of all 128 rows: 4 row blocks x 3 column tiles = 12 accumulator tiles of 32 x 32 (192 registers),
+//     which are in turn the residual rows, the out-projection accumulators and the fc2 accumulators.  Its weight fragments (Wo', W2') are
+//     PRIVATE -- nobody else reads them -- so they never touch LDS: plain 1-KiB global loads straight into registers, one tick ahead, each
+//     fragment feeding FOUR MFMAs (the four row blocks);
+//   * fc1 is split by rows: wave w keeps norm2(x) of row block w as 24 B fragments in registers (96) and multiplies a 64-wide hidden slice per
+//     tick (48 MFMAs); only W1' is shared by the four waves and streams L2 -> LDS by LDS-DMA (48 KiB per tick, two slots);
+//   * the activated slice crosses the waves through LDS as ready-made B fragments (4 written, 16 read per wave and tick) behind ONE 4-wave
+//     barrier per tick of 96 MFMAs per SIMD.
+// Per 96 MFMAs a wave issues 64 LDS fragment reads (panel.hip: 108 per SIMD), 12 LDS-DMA pieces + 12 global loads (24), and meets one barrier
+// of four waves running the same program (four rendezvous of eight).  The price: one instruction stream per SIMD, so every latency is covered
+// by software pipelining inside the wave (fragment pools filled 6-8 MFMAs ahead, weights a whole phase ahead).
+//
+// MFMA v_mfma_f32_32x32x16_f16 / _bf16 with the WEIGHT fragment as the A operand and the activation fragment as the B operand, exactly as in
+// panel.hip: D[feature][row]; lane (j = lane & 31, h = lane >> 5) holds, for token row j of the tile, features 32 T + 16 h + r in register r
+// (the packed weights carry the row permutation that makes it so), and registers 8 s .. 8 s + 7 of a D tile ARE the B fragment of k-step
+// 2 T + s of the next product (contraction order 32 T + 16 h + 8 s + e).
+#include "cs_common.h"
+#include "panel_shared.h"
+#include <atomic>
+
+namespace {
+
+constexpr int PC = 384;               // hidden size
+constexpr int PF = 1536;              // MLP hidden
+constexpr int KS = PC / 16;           // 24 k-steps over C
+constexpr int FRAG = 1024;            // bytes of one MFMA operand fragment (64 lanes x 16 B)
+constexpr int ROWS = 128;             // rows per workgroup
+constexpr int HT = 64;                // hidden columns per tick
+constexpr int NTICK = PF / HT;        // 24
+constexpr int PAD_TICKS = 3;          // zero ticks behind the image: the fetches of S2 run unconditionally (W2 one tick, W1 three ticks ahead)
+constexpr size_t IMG_WO = (size_t)4 * KS * 3 * FRAG;  // out-projection section: [wave][k-step][column tile]   (288 KiB)
+constexpr size_t IMG_W1 = 48 * FRAG;                   // per tick: W1 [hidden tile 0..1][k-step 0..23]            (48 KiB, shared: LDS-DMA)
+constexpr size_t IMG_TICK = IMG_W1 + 48 * FRAG;        //           W2 [wave][fc2 k-step 0..3][column tile 0..2]   (48 KiB, private: registers)
+// LDS map
+constexpr int L_A = 0;                 // 96 KiB: attention-output fragments [row block][k-step] -> norm2(x) fragments -> W1 ring (2 x 48 KiB)
+constexpr int L_HB = 96 * 1024;        // 32 KiB: activated slices, 2 buffers x [fc2 k-step 0..3][row block 0..3]
+constexpr int L_RED = 128 * 1024;      // 4 KiB: LayerNorm partial sums [pass][wave][row]
+constexpr int L_B1 = L_RED + 4096;     // 6 KiB: fc1 bias (fp32)
+constexpr int LDS4_BYTES = L_B1 + PF * 4;  // 138 KiB
+
+__device__ __forceinline__ int panel4_perm(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+
+template <bool OUTPROJ, bool BF>
+__global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int row_base = blockIdx.x * ROWS;
+  const unsigned lds0 = (unsigned)(size_t)CS_LDS_PTR(smem);
+  const unsigned lane16 = lane * 16;
+  const char* img = reinterpret_cast<const char*>(p.img);
+  const char* img_mlp = img + (OUTPROJ ? IMG_WO : 0);
+
+  // ---- fc1 bias -> LDS (plain stores: nothing is in flight yet) ----
+  for (int i = tid; i < PF / 4; i += 256)
+    reinterpret_cast<f32x4_t*>(smem + L_B1)[i] = reinterpret_cast<const f32x4_t*>(p.b1)[i];
+
+  // ---- attention-output rows -> LDS as B fragments [row block][k-step] (natural contraction order 16 ks + 8 h + e): wave w copies row block w ----
+  if constexpr (OUTPROJ) {
+    const size_t rowa = (size_t)min(row_base + wv * 32 + j, p.M - 1);
+    const char* so = reinterpret_cast<const char*>(p.attn_o) + rowa * (PC * 2) + 16 * h;
+    const unsigned dst = lds0 + L_A + wv * KS * FRAG;
+    sfor<KS>([&](auto K_) {
+      constexpr int K = decltype(K_)::value;
+      dma_piece<0>(so + K * 32, dst + K * FRAG);
+    });
+  }
+
+  // ---- residual rows -> accumulators: acc[rb][ct][r] = x[row_base + 32 rb + j][96 w + 32 ct + 16 h + r]  (+ out-projection bias) ----
+  f32x16_t acc[4][3];
+  {
+    const float* bsrc = p.bo + 96 * wv + 16 * h;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+      f32x4_t bq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = OUTPROJ ? *reinterpret_cast<const f32x4_t*>(bsrc + 32 * ct + 4 * q) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const size_t row = (size_t)min(row_base + rb * 32 + j, p.M - 1);
+        const float* xr = p.x + row * PC + 96 * wv + 32 * ct + 16 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4_t v = *reinterpret_cast<const f32x4_t*>(xr + 4 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[rb][ct][4 * q + i] = v[i] + (OUTPROJ ? bq[q][i] : 0.f);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- attention output projection: per k-step 3 private weight fragments (global -> registers) x 4 row-block fragments (LDS) = 12 MFMAs ----
+  if constexpr (OUTPROJ) {
+    const char* wsrc = img + (size_t)wv * (KS * 3 * FRAG) + lane16;
+    const char* bfr = smem + L_A + lane16;
+#pragma unroll 6
+    for (int ks = 0; ks < KS; ++ks) {
+      h16x8_t wf[3], bf[4];
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) wf[ct] = *reinterpret_cast<const h16x8_t*>(wsrc + (ks * 3 + ct) * FRAG);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) bf[rb] = *reinterpret_cast<const h16x8_t*>(bfr + (rb * KS + ks) * FRAG);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) acc[rb][ct] = mfma_32x32x16<BF>(wf[ct], bf[rb], acc[rb][ct]);
+    }
+  }
+
+  // ---- LayerNorm statistics of complete rows: a row's 384 columns live in lanes j / j + 32 of all four waves.  Two passes (mean, then
+  //      squared deviations), each: 48 values in the lane + the other half of the wave + the other three waves through LDS, summed in a fixed order ----
+  float* red = reinterpret_cast<float*>(smem + L_RED);
+  auto row_stats = [&](float (&mean)[4], float (&rstd)[4]) {
+    float s[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      float t = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) t += (acc[rb][ct][r] + acc[rb][ct][r + 1]) + (acc[rb][ct][r + 2] + acc[rb][ct][r + 3]);
+      s[rb] = add_other_half(t);
+      if (h == 0) red[wv * ROWS + rb * 32 + j] = s[rb];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const float* r0 = red + rb * 32 + j;
+      mean[rb] = ((r0[0] + r0[ROWS]) + (r0[2 * ROWS] + r0[3 * ROWS])) * (1.0f / PC);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      float q = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[rb][ct][r] - mean[rb];
+          q = fmaf(d, d, q);
+        }
+      q = add_other_half(q);
+      if (h == 0) red[4 * ROWS + wv * ROWS + rb * 32 + j] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const float* r0 = red + 4 * ROWS + rb * 32 + j;
+      const float q = (r0[0] + r0[ROWS]) + (r0[2 * ROWS] + r0[3 * ROWS]);
+      rstd[rb] = 1.0f / sqrtf(q * (1.0f / PC) + p.eps);
+    }
+    __syncthreads();  // (the scratch may be rewritten by the next call)
+  };
+
+  // ---- norm2(x) -> B fragments of fc1: k-step 2 T + s of row block rb = registers 8 s .. 8 s + 7 of tile (rb, T = 3 w + ct) ----
+  h16x8_t xf[KS];
+  {
+    float mean[4], rstd[4];
+    row_stats(mean, rstd);  // (its barriers also order the out-projection's reads of L_A before the writes below)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const float nb = -mean[rb] * rstd[rb];
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(acc[rb][ct][8 * s + e], rstd[rb], nb);
+          *reinterpret_cast<u32x4_t*>(smem + L_A + (rb * KS + 2 * (3 * wv + ct) + s) * FRAG + lane16) = pack8<BF>(v);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const h16x8_t*>(smem + L_A + (wv * KS + ks) * FRAG + lane16);
+    __syncthreads();  // every wave holds its fragments: L_A becomes the W1 ring
+  }
+  // the fc2 accumulators start at residual + bias: the residual add and the bias add are free
+  {
+    const float* bsrc = p.b2 + 96 * wv + 16 * h;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bsrc + 32 * ct + 4 * q);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[rb][ct][4 * q + i] += b4[i];
+      }
+  }
+
+  // =========================================================================================================================
+  // MLP: 24 ticks of 64 hidden columns.
+  //   S1(t): fc1 of tick t + 1 (48 MFMAs: hidden tile ht, k-step ks; W1 fragment ht * 24 + ks from ring slot (t + 1) & 1, one LDS read per MFMA,
+  //          eight ahead) with the GELU of tick t in the gaps (one block of the packed-half GELU per gap), then the activated slice of row block
+  //          w leaves as 4 B fragments into buffer t & 1; vmcnt(0) (everything S2(t - 1) fetched has landed); barrier.
+  //   S2(t): fc2 of tick t (48 MFMAs: k-step kk, row block rb, column tile ct; W2 fragments in registers, B fragment (kk, rb) from LDS once per
+  //          3 MFMAs) -- and the fetches: W2 of tick t + 1 into the registers just used (global loads), W1 of tick t + 3 into ring slot
+  //          (t + 1) & 1, free since the barrier (12 LDS-DMA pieces per wave).
+  // =========================================================================================================================
+  h16x8_t w2r[12];       // this wave's W2 fragments of the current tick: [kk][ct]
+  h16x8_t wp[8];         // rolling pool of W1 fragments
+  f32x16_t hA[2], hB[2]; // fc1 accumulators of even / odd ticks: [hidden tile]
+  unsigned xp[16];       // the previous tick's pre-activations as packed halves: xp[4 (2 ht + s) + q] = (r = 8 s + 2 q, + 1) of tile ht
+  PkGelu pg;
+  const PkGeluK kk_ = pk_gelu_consts();
+  const unsigned ring = lds0 + L_A + lane16;
+  const unsigned hbw = lds0 + L_HB + wv * FRAG + lane16;   // + (buf * 16 + 4 kkf) * FRAG: this wave's row block
+  const unsigned hbr = lds0 + L_HB + lane16;               // + (buf * 16 + 4 kkf + rb) * FRAG
+  const unsigned b1g = lds0 + L_B1 + 4 * panel4_perm(j);  // + (64 t + 32 ht) * 4: the bias of the hidden unit in MFMA row j of a tile
+  // B fragment of the bias k-step: 1.0 in contraction slots 0 and 1 (lane half 0, elements 0 and 1), 0 elsewhere
+  const h16x8_t ones = __builtin_bit_cast(h16x8_t, u32x4_t{h == 0 ? (BF ? 0x3F803F80u : 0x3C003C00u) : 0u, 0u, 0u, 0u});
+
+  auto w1_issue = [&](int t) {  // this wave's 12 pieces of tick t's W1 slice, all at once (prologue)
+    const unsigned dst = lds0 + L_A + (t & 1) * (48 * FRAG) + wv * 12 * FRAG;
+    const char* s = img_mlp + (size_t)t * IMG_TICK + wv * 12 * FRAG + lane16;
+    // (the instruction's immediate offset is 13-bit signed: pieces in groups of four, the group's base in the addresses)
+    sfor<12>([&](auto K_) { constexpr int K = decltype(K_)::value; dma_piece<(K & 3) * FRAG>(s + (K & ~3) * FRAG, dst + (K & ~3) * FRAG); });
+  };
+  auto w2_load = [&](int t) {
+    const char* s = img_mlp + (size_t)t * IMG_TICK + IMG_W1 + wv * 12 * FRAG + lane16;
+#pragma unroll
+    for (int f = 0; f < 12; ++f) w2r[f] = *reinterpret_cast<const h16x8_t*>(s + f * FRAG);
+  };
+  // fc1 of tick t into hn (from ring slot t & 1), GELU blocks on xp (pre-activations `ha` of the previous tick, fp32, for the bf16 form)
+  auto s1 = [&](auto GELU_, auto FC1_, f32x16_t (&hn)[2], const f32x16_t (&ha)[2], int t) {
+    constexpr bool GELU = decltype(GELU_)::value, FC1 = decltype(FC1_)::value;
+    const unsigned cur = ring + (t & 1) * (48 * FRAG);
+    if constexpr (FC1) {
+      // fc1 bias through the matrix pipe: one more k-step per tile whose weight fragment carries b1 (split hi + lo: exact to 2^-22 / 2^-16) in
+      // contraction slots 0 and 1 and whose activation fragment is 1 there -- the accumulators start from the inline constant 0, nothing is
+      // written into them by the vector unit (the MFMA results live in accumulator registers: 32 v_accvgpr_write per tick otherwise)
+      float bv[2];
+      asm volatile("ds_read_b32 %0, %1" : "=&v"(bv[0]) : "v"(b1g + t * (HT * 4)) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:128" : "=&v"(bv[1]) : "v"(b1g + t * (HT * 4)) : "memory");
+      sfor<8>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(cur, wp[decltype(F_)::value]); });
+      CS_LGKM(8);
+#pragma unroll
+      for (int ht = 0; ht < 2; ++ht) {
+        const unsigned hi = BF ? (unsigned)f2bf(bv[ht]) : (unsigned)f2h(bv[ht]);
+        const float rest = bv[ht] - (BF ? bf2f((h16_t)hi) : h2f((h16_t)hi));
+        const unsigned lo = BF ? (unsigned)f2bf(rest) : (unsigned)f2h(rest);
+        const unsigned r0 = h == 0 ? (hi | (lo << 16)) : 0u;
+        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        hn[ht] = mfma_32x32x16<BF>(__builtin_bit_cast(h16x8_t, u32x4_t{r0, 0u, 0u, 0u}), ones, zero);
+      }
+    }
+    sfor<48>([&](auto M_) {
+      constexpr int M = decltype(M_)::value;
+      if constexpr (FC1) {
+        constexpr int ht = M / 24, ks = M % 24;
+        // fragment M is complete when at most (the reads issued behind it) are outstanding: 7 in the steady state, fewer at the tail
+        constexpr int BEHIND = (M + 8 <= 48) ? 7 : 47 - M;
+        CS_LGKM(BEHIND);
+        hn[ht] = mfma_32x32x16<BF>(wp[M % 8], xf[ks], hn[ht]);
+        if constexpr (M + 8 < 48) lds_read1<(M + 8) * FRAG>(cur, wp[M % 8]);
+      }
+      if constexpr (GELU) {
+        constexpr int G = M / 6, B = M % 6;       // group G = packed registers 2 G, 2 G + 1; block B of its six
+        constexpr int ht = G / 4, r0 = 8 * ((G / 2) & 1) + 4 * (G & 1);
+        pk_gelu_block<B, BF>(pg, xp[2 * G], xp[2 * G + 1], kk_, ha[ht][r0], ha[ht][r0 + 1], ha[ht][r0 + 2], ha[ht][r0 + 3]);
+      }
+      CS_SB();
+    });
+  };
+  auto hb_write = [&](int buf) {
+    const unsigned a = hbw + buf * (16 * FRAG);
+    sfor<4>([&](auto K_) {
+      constexpr int K = decltype(K_)::value;
+      lds_write16<K * 4 * FRAG>(a, u32x4_t{xp[4 * K], xp[4 * K + 1], xp[4 * K + 2], xp[4 * K + 3]});
+    });
+  };
+  auto pack_xp = [&](const f32x16_t (&ha)[2]) {
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xp[4 * (2 * ht + s) + q] = pack_h16x2(ha[ht][8 * s + 2 * q], ha[ht][8 * s + 2 * q + 1]);
+  };
+  // fc2 of tick t (buffer t & 1) and the fetches for later ticks
+  auto s2 = [&](int t) {
+    const unsigned hr = hbr + (t & 1) * (16 * FRAG);
+    const char* w2s = img_mlp + (size_t)(t + 1) * IMG_TICK + IMG_W1 + wv * 12 * FRAG + lane16;
+    const char* w1s = img_mlp + (size_t)(t + 3) * IMG_TICK + wv * 12 * FRAG + lane16;
+    const unsigned w1d = lds0 + L_A + ((t + 1) & 1) * (48 * FRAG) + wv * 12 * FRAG;
+    h16x8_t hb[4];  // rolling pool of B fragments: fragment g = 4 kk + rb lives in hb[g % 4], three groups ahead
+    sfor<3>([&](auto G_) { constexpr int G = decltype(G_)::value; lds_read1<G * FRAG>(hr, hb[G]); });
+    sfor<16>([&](auto G_) {
+      constexpr int G = decltype(G_)::value;
+      constexpr int kk = G / 4, rb = G % 4;
+      if constexpr (G + 3 < 16) lds_read1<(G + 3) * FRAG>(hr, hb[(G + 3) % 4]);
+      constexpr int BEHIND = (G + 3 < 16) ? 3 : 15 - G;
+      CS_LGKM(BEHIND);
+      sfor<3>([&](auto C_) {
+        constexpr int ct = decltype(C_)::value;
+        acc[rb][ct] = mfma_32x32x16<BF>(w2r[kk * 3 + ct], hb[G % 4], acc[rb][ct]);
+        if constexpr (rb == 3) {  // the last use of this weight fragment: refill it with the next tick's (lands during the next S1)
+          w2r[kk * 3 + ct] = *reinterpret_cast<const h16x8_t*>(w2s + (kk * 3 + ct) * FRAG);
+        } else if constexpr (ct == 1) {  // 12 gaps (kk, rb < 3, ct = 1): one W1 piece each
+          constexpr int K = kk * 3 + rb;
+          dma_piece<(K & 3) * FRAG>(w1s + (K & ~3) * FRAG, w1d + (K & ~3) * FRAG);
+        }
+        CS_SB();
+      });
+    });
+  };
+
+  // prologue: W1 of ticks 0 and 1, W2 of tick 0; fc1 of tick 0; then W1 of tick 2 into slot 0
+  w1_issue(0);
+  w1_issue(1);
+  w2_load(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  s1(std::false_type{}, std::true_type{}, hA, hA, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  w1_issue(2);
+  auto iter = [&](f32x16_t (&hcur)[2], f32x16_t (&hnext)[2], int t) {  // hcur = fc1 of tick t (complete)
+    pack_xp(hcur);
+    if (t + 1 < NTICK) s1(std::true_type{}, std::true_type{}, hnext, hcur, t + 1);
+    else s1(std::true_type{}, std::false_type{}, hnext, hcur, t + 1);
+    hb_write(t & 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    CS_SB();
+    s2(t);
+  };
+  // (fp16 mode: the GELU works on the packed halves alone, so fc1 of the next tick may overwrite the accumulators it was packed from; the bf16
+  //  form's relu reads the fp32 pre-activations: two buffers)
+  for (int t = 0; t < NTICK; t += 2) {
+    if constexpr (BF) { iter(hA, hB, t); iter(hB, hA, t + 1); }
+    else { iter(hA, hA, t); iter(hA, hA, t + 1); }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  // ---- epilogue: x rows back to memory, the next layer's normalised rows ----
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) {
+    const int row = row_base + rb * 32 + j;
+    if (row < p.M) {
+      float* xr = p.x + (size_t)row * PC + 96 * wv + 16 * h;
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4_t*>(xr + 32 * ct + 4 * q) = f32x4_t{acc[rb][ct][4 * q], acc[rb][ct][4 * q + 1], acc[rb][ct][4 * q + 2], acc[rb][ct][4 * q + 3]};
+    }
+  }
+  if (p.u_out) {
+    __syncthreads();
+    float mean[4], rstd[4];
+    row_stats(mean, rstd);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int row = row_base + rb * 32 + j;
+      const float nb = -mean[rb] * rstd[rb];
+      if (row < p.M) {
+        h16_t* ur = p.u_out + (size_t)row * PC + 96 * wv + 16 * h;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(acc[rb][ct][8 * s + e], rstd[rb], nb);
+            *reinterpret_cast<u32x4_t*>(ur + 32 * ct + 8 * s) = pack8<BF>(v);
+          }
+      }
+    }
+  }
+}
+
+// ---- weight image.  One thread per 16-byte fragment element (8 halves): [fragment][lane 0..63].  Lane (i = lane & 31, h = lane >> 5) of an
+//      A-operand fragment holds MFMA row i of its 32-feature tile -- output feature perm(i) of the tile, so that D register r of lane half h is
+//      feature 16 h + r -- and 8 contraction indices of its 16-wide k-step:
+//        natural  16 ks + 8 h + e                        (out-projection: B fragments come from memory)
+//        tiled    32 (ks >> 1) + 16 h + 8 (ks & 1) + e   (fc1 / fc2: B fragments are accumulator tiles)
+//      Sections: [out-projection: wave w, k-step ks, column tile ct -> output tile T = 3 w + ct]
+//                [24 ticks: W1 fragment ht * 24 + ks = hidden tile 2 t + ht, k-step ks | W2: wave w, fc2 k-step kk, column tile ct =
+//                 output tile 3 w + ct, hidden k-step 4 t + kk] ----
+template <bool BF>
+__global__ __launch_bounds__(256) void cs_panel4_pack_kernel(const float* __restrict__ wo, const float* __restrict__ ls1,
+                                                             const float* __restrict__ w1, const float* __restrict__ g2,
+                                                             const float* __restrict__ w2, const float* __restrict__ ls2,
+                                                             h16_t* __restrict__ img) {
+  const long long n_out16 = wo ? (long long)(IMG_WO / 16) : 0;
+  const long long total16 = n_out16 + (long long)(NTICK + PAD_TICKS) * (IMG_TICK / 16);
+  const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= total16) return;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int lane = (int)(gi & 63), i = lane & 31, h = lane >> 5;
+  if (gi < n_out16) {
+    const int f = (int)(gi >> 6);  // (w * 24 + ks) * 3 + ct
+    const int ct = f % 3, ks = (f / 3) % KS, w = f / (3 * KS);
+    const int rowi = 32 * (3 * w + ct) + panel4_perm(i);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = wo[(size_t)rowi * PC + 16 * ks + 8 * h + e] * (ls1 ? ls1[rowi] : 1.f);
+  } else {
+    const long long g2i = gi - n_out16;
+    const int t = (int)(g2i / (IMG_TICK / 16));
+    const int f = (int)((g2i - (long long)t * (IMG_TICK / 16)) >> 6);  // 0..95
+    if (t >= NTICK) {
+      // padding: zeros
+    } else if (f < 48) {
+      const int ht = f / KS, ks = f % KS;
+      const int rowi = HT * t + 32 * ht + panel4_perm(i);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + e;
+        v[e] = w1[(size_t)rowi * PC + col] * (g2 ? g2[col] : 1.f);
+      }
+    } else {
+      const int fp = f - 48;  // w * 12 + kk * 3 + ct
+      const int ct = fp % 3, kk = (fp / 3) % 4, w = fp / 12;
+      const int rowi = 32 * (3 * w + ct) + panel4_perm(i);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = HT * t + 32 * (kk >> 1) + 16 * h + 8 * (kk & 1) + e;
+        v[e] = w2[(size_t)rowi * PF + col] * (ls2 ? ls2[rowi] : 1.f);
+      }
+    }
+  }
+  const uint4 o = {pack_o16x2<BF>(v[0], v[1]), pack_o16x2<BF>(v[2], v[3]), pack_o16x2<BF>(v[4], v[5]), pack_o16x2<BF>(v[6], v[7])};
+  reinterpret_cast<uint4*>(img)[gi] = o;
+}
+
+template <bool OUTPROJ, bool BF>
+hipError_t panel4_launch_t(const CsPanelParams* p, hipStream_t st) {
+  static std::atomic<bool> attr_done[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_panel4_kernel<OUTPROJ, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  const int grid = (p->M + ROWS - 1) / ROWS;
+  hipLaunchKernelGGL((cs_panel4_kernel<OUTPROJ, BF>), dim3(grid), dim3(256), LDS4_BYTES, st, *p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cs_panel4_image_bytes(int with_outproj) { return (with_outproj ? IMG_WO : 0) + (size_t)(NTICK + PAD_TICKS) * IMG_TICK; }
+
+hipError_t cs_panel4_pack_launch(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,
+                                 h16_t* img, int bf16, hipStream_t st) {
+  const int total = (int)(cs_panel4_image_bytes(wo ? 1 : 0) / 16);
+  if (bf16) hipLaunchKernelGGL(cs_panel4_pack_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, st, wo, ls1, w1, g2, w2, ls2, img);
+  else hipLaunchKernelGGL(cs_panel4_pack_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, st, wo, ls1, w1, g2, w2, ls2, img);
+  return hipGetLastError();
+}
+
+hipError_t cs_panel4_launch(const CsPanelParams* p, hipStream_t st) {
+  if (p->attn_o) return p->bf16 ? panel4_launch_t<true, true>(p, st) : panel4_launch_t<true, false>(p, st);
+  return p->bf16 ? panel4_launch_t<false, true>(p, st) : panel4_launch_t<false, false>(p, st);
+}
+
+}  // extern "C"

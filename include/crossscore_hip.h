@@ -248,6 +248,10 @@ int cs_op_ln_fold_consts(const uint16_t* w_packed, int ldp, const float* w, cons
  * cs_panel_image_bytes(wo != NULL) bytes.  cs_op_encoder_panel then computes, in place on x (M,C) fp32,
  *   x += attn_o Wo'^T + bo   (skipped when attn_o is NULL);   x += GELU(norm(x) W1'^T + b1) W2'^T + b2;
  *   u_out = fp16(norm(x))    (skipped when NULL), norm = LayerNorm without gamma/beta (HF modeling_dinov2.py:361-380). */
+/* debug switch, process-wide (see cs_debug_* above): which of the two token-panel kernels handles created from now on (their weight images are
+ * packed in cs_finalize) and the cs_op_panel_* entry points use: 0 = csrc/panel.hip (8 waves in role-split pairs, rounds 2-5), 1 = csrc/panel4.hip
+ * (4 waves, one per SIMD, column-split residual products; round 6).  The images differ: pack and launch under the same setting. */
+void cs_debug_panel_impl(int impl);
 int cs_panel_supported(int hidden, int mlp_ratio);
 size_t cs_panel_image_bytes(int with_outproj);
 int cs_op_panel_pack(const float* wo, const float* ls1, const float* w1, const float* g2, const float* w2, const float* ls2,

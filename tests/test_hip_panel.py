@@ -9,6 +9,18 @@ pytestmark = pytest.mark.gpu
 C, F = 384, 1536
 
 
+@pytest.fixture(params=[0, 1], ids=["panel8", "panel4"], autouse=True)
+def panel_impl(request):
+    """Both token-panel kernels through every test of this file: csrc/panel.hip (8 waves in role-split pairs) and csrc/panel4.hip (4 waves, one per
+    SIMD, column-split residual products).  cs_debug_panel_impl selects the weight image cs_op_panel_pack builds and the kernel
+    cs_op_encoder_panel launches."""
+    from crossscore_amd import _lib
+    lib = _lib.load()
+    lib.cs_debug_panel_impl(request.param)
+    yield request.param
+    lib.cs_debug_panel_impl(0)
+
+
 def _bf(t):
     return t.to(torch.float16).to(torch.float32)
 
