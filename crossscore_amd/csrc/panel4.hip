@@ -40,7 +40,7 @@ constexpr int HT = 64;                // hidden columns per tick
 constexpr int NTICK = PF / HT;        // 24
 constexpr int PAD_TICKS = 3;          // zero ticks behind the image: the fetches of S2 run unconditionally (W2 one tick, W1 three ticks ahead)
 constexpr size_t IMG_WO = (size_t)4 * KS * 3 * FRAG;  // out-projection section: [wave][k-step][column tile]   (288 KiB)
-constexpr size_t IMG_W1 = 48 * FRAG;                   // per tick: W1 [hidden tile 0..1][k-step 0..23]            (48 KiB, shared: LDS-DMA)
+constexpr size_t IMG_W1 = 48 * FRAG;                   // per tick: W1 [k-step 0..23][hidden tile 0..1]            (48 KiB, shared: LDS-DMA)
 constexpr size_t IMG_TICK = IMG_W1 + 48 * FRAG;        //           W2 [wave][fc2 k-step 0..3][column tile 0..2]   (48 KiB, private: registers)
 // LDS map
 constexpr int L_A = 0;                 // 96 KiB: attention-output fragments [row block][k-step] -> norm2(x) fragments -> W1 ring (2 x 48 KiB)
@@ -48,6 +48,26 @@ constexpr int L_HB = 96 * 1024;        // 32 KiB: activated slices, 2 buffers x 
 constexpr int L_RED = 128 * 1024;      // 4 KiB: LayerNorm partial sums [pass][wave][row]
 constexpr int L_B1 = L_RED + 4096;     // 6 KiB: fc1 bias (fp32)
 constexpr int LDS4_BYTES = L_B1 + PF * 4;  // 138 KiB
+
+#ifndef CS_P4_ABL
+#define CS_P4_ABL 0   // timing-only ablations of diagnostic builds (results wrong by design): 1 no GELU arithmetic, 2 no W1 fragment reads, 4 no fc1 MFMAs, 8 no counted LDS waits in S1
+#endif
+#ifdef CS_P4_STAMP
+// diagnostic builds only (tools/panel4_phases.py): per (block < 64, wave) phase stamps and per-tick sums; read by cs_panel4_debug_read
+__device__ unsigned long long g_p4_dbg[64 * 4 * 16];
+__device__ unsigned long long g_p4_dbg2[64 * 4 * 8];
+#define P4_NOW(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define P4_STAMP(k) do { unsigned long long t_; P4_NOW(t_); if (blockIdx.x < 64 && lane == 0) g_p4_dbg[(blockIdx.x * 4 + wv) * 16 + (k)] = t_; } while (0)
+#ifdef CS_P4_STAMPL
+#define P4_NOWL(v) P4_NOW(v)
+#else
+#define P4_NOWL(v) do { v = 0; } while (0)
+#endif
+#else
+#define P4_NOW(v) do { } while (0)
+#define P4_NOWL(v) do { } while (0)
+#define P4_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ int panel4_perm(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 
@@ -64,6 +84,7 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   const char* img = reinterpret_cast<const char*>(p.img);
   const char* img_mlp = img + (OUTPROJ ? IMG_WO : 0);
 
+  P4_STAMP(0);
   // ---- fc1 bias -> LDS (plain stores: nothing is in flight yet) ----
   for (int i = tid; i < PF / 4; i += 256)
     reinterpret_cast<f32x4_t*>(smem + L_B1)[i] = reinterpret_cast<const f32x4_t*>(p.b1)[i];
@@ -105,6 +126,7 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
+  P4_STAMP(1);
   // ---- attention output projection: per k-step 3 private weight fragments (global -> registers) x 4 row-block fragments (LDS) = 12 MFMAs ----
   if constexpr (OUTPROJ) {
     const char* wsrc = img + (size_t)wv * (KS * 3 * FRAG) + lane16;
@@ -123,10 +145,11 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
     }
   }
 
+  P4_STAMP(2);
   // ---- LayerNorm statistics of complete rows: a row's 384 columns live in lanes j / j + 32 of all four waves.  Two passes (mean, then
   //      squared deviations), each: 48 values in the lane + the other half of the wave + the other three waves through LDS, summed in a fixed order ----
   float* red = reinterpret_cast<float*>(smem + L_RED);
-  auto row_stats = [&](float (&mean)[4], float (&rstd)[4]) {
+  auto row_stats = [&](float (&mean)[4], float (&rstd)[4], int j, int h) {
     float s[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
@@ -171,7 +194,7 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   h16x8_t xf[KS];
   {
     float mean[4], rstd[4];
-    row_stats(mean, rstd);  // (its barriers also order the out-projection's reads of L_A before the writes below)
+    row_stats(mean, rstd, j, h);  // (its barriers also order the out-projection's reads of L_A before the writes below)
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       const float nb = -mean[rb] * rstd[rb];
@@ -190,19 +213,23 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
     for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const h16x8_t*>(smem + L_A + (wv * KS + ks) * FRAG + lane16);
     __syncthreads();  // every wave holds its fragments: L_A becomes the W1 ring
   }
-  // the fc2 accumulators start at residual + bias: the residual add and the bias add are free
+  // the fc2 accumulators start at residual + bias.  The bias enters through the matrix pipe (one MFMA per tile: b2 split hi + lo in contraction
+  // slots 0 / 1 against a fragment of ones): a vector add on the accumulators here, with norm2(x) live beside them, overflowed the arch
+  // VGPRs and hipcc spilled 22 accumulator registers around the prologue
   {
-    const float* bsrc = p.b2 + 96 * wv + 16 * h;
+    const unsigned lb = fresh_lane();
+    const int jb = lb & 31, hb_ = lb >> 5;
+    const h16x8_t ones_b = __builtin_bit_cast(h16x8_t, u32x4_t{hb_ == 0 ? (BF ? 0x3F803F80u : 0x3C003C00u) : 0u, 0u, 0u, 0u});
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
+    for (int ct = 0; ct < 3; ++ct) {
+      const float bv = p.b2[96 * wv + 32 * ct + panel4_perm(jb)];
+      const unsigned hi = BF ? (unsigned)f2bf(bv) : (unsigned)f2h(bv);
+      const float rest = bv - (BF ? bf2f((h16_t)hi) : h2f((h16_t)hi));
+      const unsigned lo = BF ? (unsigned)f2bf(rest) : (unsigned)f2h(rest);
+      const h16x8_t bfrag = __builtin_bit_cast(h16x8_t, u32x4_t{hb_ == 0 ? (hi | (lo << 16)) : 0u, 0u, 0u, 0u});
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bsrc + 32 * ct + 4 * q);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[rb][ct][4 * q + i] += b4[i];
-      }
+      for (int rb = 0; rb < 4; ++rb) acc[rb][ct] = mfma_32x32x16<BF>(bfrag, ones_b, acc[rb][ct]);
+    }
   }
 
   // =========================================================================================================================
@@ -220,21 +247,27 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   unsigned xp[16];       // the previous tick's pre-activations as packed halves: xp[4 (2 ht + s) + q] = (r = 8 s + 2 q, + 1) of tile ht
   PkGelu pg;
   const PkGeluK kk_ = pk_gelu_consts();
-  const unsigned ring = lds0 + L_A + lane16;
-  const unsigned hbw = lds0 + L_HB + wv * FRAG + lane16;   // + (buf * 16 + 4 kkf) * FRAG: this wave's row block
-  const unsigned hbr = lds0 + L_HB + lane16;               // + (buf * 16 + 4 kkf + rb) * FRAG
-  const unsigned b1g = lds0 + L_B1 + 4 * panel4_perm(j);  // + (64 t + 32 ht) * 4: the bias of the hidden unit in MFMA row j of a tile
+  // lane-derived values of the MLP phase are formed from a fresh lane id (opaque to the compiler), those of the epilogue likewise: nothing
+  // lane-derived has to stay in a register -- or in scratch -- across the loop, which runs at the 512-register limit.  (A kernel with a
+  // private segment ran the SAME loop instructions at half the speed: tools/panel4_phases.py, EXPERIMENTS.md round 6.)
+  const unsigned lm = fresh_lane();
+  const unsigned lm16 = lm * 16;
+  const int hm = lm >> 5;
+  const unsigned ring = lds0 + L_A + lm16;
+  const unsigned hbw = lds0 + L_HB + wv * FRAG + lm16;   // + (buf * 16 + 4 kkf) * FRAG: this wave's row block
+  const unsigned hbr = lds0 + L_HB + lm16;               // + (buf * 16 + 4 kkf + rb) * FRAG
+  const unsigned b1g = lds0 + L_B1 + 4 * panel4_perm(lm & 31);  // + (64 t + 32 ht) * 4: the bias of the hidden unit in MFMA row j of a tile
   // B fragment of the bias k-step: 1.0 in contraction slots 0 and 1 (lane half 0, elements 0 and 1), 0 elsewhere
-  const h16x8_t ones = __builtin_bit_cast(h16x8_t, u32x4_t{h == 0 ? (BF ? 0x3F803F80u : 0x3C003C00u) : 0u, 0u, 0u, 0u});
+  const h16x8_t ones = __builtin_bit_cast(h16x8_t, u32x4_t{hm == 0 ? (BF ? 0x3F803F80u : 0x3C003C00u) : 0u, 0u, 0u, 0u});
 
   auto w1_issue = [&](int t) {  // this wave's 12 pieces of tick t's W1 slice, all at once (prologue)
     const unsigned dst = lds0 + L_A + (t & 1) * (48 * FRAG) + wv * 12 * FRAG;
-    const char* s = img_mlp + (size_t)t * IMG_TICK + wv * 12 * FRAG + lane16;
+    const char* s = img_mlp + (size_t)t * IMG_TICK + wv * 12 * FRAG + lm16;
     // (the instruction's immediate offset is 13-bit signed: pieces in groups of four, the group's base in the addresses)
     sfor<12>([&](auto K_) { constexpr int K = decltype(K_)::value; dma_piece<(K & 3) * FRAG>(s + (K & ~3) * FRAG, dst + (K & ~3) * FRAG); });
   };
   auto w2_load = [&](int t) {
-    const char* s = img_mlp + (size_t)t * IMG_TICK + IMG_W1 + wv * 12 * FRAG + lane16;
+    const char* s = img_mlp + (size_t)t * IMG_TICK + IMG_W1 + wv * 12 * FRAG + lm16;
 #pragma unroll
     for (int f = 0; f < 12; ++f) w2r[f] = *reinterpret_cast<const h16x8_t*>(s + f * FRAG);
   };
@@ -256,22 +289,31 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
         const unsigned hi = BF ? (unsigned)f2bf(bv[ht]) : (unsigned)f2h(bv[ht]);
         const float rest = bv[ht] - (BF ? bf2f((h16_t)hi) : h2f((h16_t)hi));
         const unsigned lo = BF ? (unsigned)f2bf(rest) : (unsigned)f2h(rest);
-        const unsigned r0 = h == 0 ? (hi | (lo << 16)) : 0u;
+        const unsigned r0 = hm == 0 ? (hi | (lo << 16)) : 0u;
         const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         hn[ht] = mfma_32x32x16<BF>(__builtin_bit_cast(h16x8_t, u32x4_t{r0, 0u, 0u, 0u}), ones, zero);
       }
     }
     sfor<48>([&](auto M_) {
       constexpr int M = decltype(M_)::value;
+#ifdef CS_P4_STAMP2
+      if constexpr (GELU && FC1 && (M % 8 == 0)) { unsigned long long t_; P4_NOW(t_); if (t == 7 && blockIdx.x < 64 && lane == 0) g_p4_dbg2[(blockIdx.x * 4 + wv) * 8 + M / 8] = t_; }
+#endif
       if constexpr (FC1) {
-        constexpr int ht = M / 24, ks = M % 24;
+        // consumption order: the two hidden tiles alternate (two independent accumulation chains); fragment M of the tick's W1 slice (in this
+        // order in the image) = tile ht, k-step ks
+        constexpr int ht = M % 2, ks = M / 2;
         // fragment M is complete when at most (the reads issued behind it) are outstanding: 7 in the steady state, fewer at the tail
         constexpr int BEHIND = (M + 8 <= 48) ? 7 : 47 - M;
-        CS_LGKM(BEHIND);
-        hn[ht] = mfma_32x32x16<BF>(wp[M % 8], xf[ks], hn[ht]);
-        if constexpr (M + 8 < 48) lds_read1<(M + 8) * FRAG>(cur, wp[M % 8]);
+        if constexpr (!(CS_P4_ABL & 8)) CS_LGKM(BEHIND);
+        if constexpr (CS_P4_ABL & 32) hn[ht] = mfma_32x32x16<BF>(ones, xf[ks], hn[ht]);
+        else if constexpr (CS_P4_ABL & 64) hn[ht] = mfma_32x32x16<BF>(wp[M % 8], ones, hn[ht]);
+        else if constexpr (CS_P4_ABL & 8192) hn[ht] = mfma_32x32x16<BF>(wp[M % 8], xf[0], hn[ht]);                       // H1: one B fragment, 23 dead
+        else if constexpr (CS_P4_ABL & 16384) { asm volatile("" :: "v"(xf[ks])); hn[ht] = mfma_32x32x16<BF>(wp[M % 8], ones, hn[ht]); }  // H2: all live, unused
+        else if constexpr (!(CS_P4_ABL & 4)) hn[ht] = mfma_32x32x16<BF>(wp[M % 8], xf[ks], hn[ht]);
+        if constexpr (M + 8 < 48 && !(CS_P4_ABL & 2)) lds_read1<(M + 8) * FRAG>(cur, wp[M % 8]);
       }
-      if constexpr (GELU) {
+      if constexpr (GELU && !(CS_P4_ABL & 1)) {
         constexpr int G = M / 6, B = M % 6;       // group G = packed registers 2 G, 2 G + 1; block B of its six
         constexpr int ht = G / 4, r0 = 8 * ((G / 2) & 1) + 4 * (G & 1);
         pk_gelu_block<B, BF>(pg, xp[2 * G], xp[2 * G + 1], kk_, ha[ht][r0], ha[ht][r0 + 1], ha[ht][r0 + 2], ha[ht][r0 + 3]);
@@ -297,35 +339,36 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   // fc2 of tick t (buffer t & 1) and the fetches for later ticks
   auto s2 = [&](int t) {
     const unsigned hr = hbr + (t & 1) * (16 * FRAG);
-    const char* w2s = img_mlp + (size_t)(t + 1) * IMG_TICK + IMG_W1 + wv * 12 * FRAG + lane16;
-    const char* w1s = img_mlp + (size_t)(t + 3) * IMG_TICK + wv * 12 * FRAG + lane16;
+    const char* w2s = img_mlp + (size_t)(t + 1) * IMG_TICK + IMG_W1 + wv * 12 * FRAG + lm16;
+    const char* w1s = img_mlp + (size_t)(t + 3) * IMG_TICK + wv * 12 * FRAG + lm16;
     const unsigned w1d = lds0 + L_A + ((t + 1) & 1) * (48 * FRAG) + wv * 12 * FRAG;
     h16x8_t hb[4];  // rolling pool of B fragments: fragment g = 4 kk + rb lives in hb[g % 4], three groups ahead
-    sfor<3>([&](auto G_) { constexpr int G = decltype(G_)::value; lds_read1<G * FRAG>(hr, hb[G]); });
+    if constexpr (!(CS_P4_ABL & 4096)) sfor<3>([&](auto G_) { constexpr int G = decltype(G_)::value; lds_read1<G * FRAG>(hr, hb[G]); });
     sfor<16>([&](auto G_) {
       constexpr int G = decltype(G_)::value;
       constexpr int kk = G / 4, rb = G % 4;
-      if constexpr (G + 3 < 16) lds_read1<(G + 3) * FRAG>(hr, hb[(G + 3) % 4]);
+      if constexpr (G + 3 < 16 && !(CS_P4_ABL & 4096)) lds_read1<(G + 3) * FRAG>(hr, hb[(G + 3) % 4]);
       constexpr int BEHIND = (G + 3 < 16) ? 3 : 15 - G;
-      CS_LGKM(BEHIND);
+      if constexpr (!(CS_P4_ABL & 4096)) CS_LGKM(BEHIND);
       sfor<3>([&](auto C_) {
         constexpr int ct = decltype(C_)::value;
-        acc[rb][ct] = mfma_32x32x16<BF>(w2r[kk * 3 + ct], hb[G % 4], acc[rb][ct]);
+        if constexpr (!(CS_P4_ABL & 2048)) acc[rb][ct] = mfma_32x32x16<BF>(w2r[kk * 3 + ct], hb[G % 4], acc[rb][ct]);
         if constexpr (rb == 3) {  // the last use of this weight fragment: refill it with the next tick's (lands during the next S1)
-          w2r[kk * 3 + ct] = *reinterpret_cast<const h16x8_t*>(w2s + (kk * 3 + ct) * FRAG);
+          if constexpr (!(CS_P4_ABL & (16 | 4096))) w2r[kk * 3 + ct] = *reinterpret_cast<const h16x8_t*>(w2s + (kk * 3 + ct) * FRAG);
         } else if constexpr (ct == 1) {  // 12 gaps (kk, rb < 3, ct = 1): one W1 piece each
           constexpr int K = kk * 3 + rb;
-          dma_piece<(K & 3) * FRAG>(w1s + (K & ~3) * FRAG, w1d + (K & ~3) * FRAG);
+          if constexpr (!(CS_P4_ABL & (16 | 4096))) dma_piece<(K & 3) * FRAG>(w1s + (K & ~3) * FRAG, w1d + (K & ~3) * FRAG);
         }
         CS_SB();
       });
     });
   };
 
-  // prologue: W1 of ticks 0 and 1, W2 of tick 0; fc1 of tick 0; then W1 of tick 2 into slot 0
+  // prologue: W1 of ticks 0 and 1; fc1 of tick 0; then W1 of tick 2 into slot 0 and W2 of tick 0 into its registers
+  P4_STAMP(3);
+  [[maybe_unused]] unsigned long long ts1 = 0, tvm = 0, tbar = 0, ts2 = 0;
   w1_issue(0);
   w1_issue(1);
-  w2_load(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -334,16 +377,31 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   w1_issue(2);
+  w2_load(0);  // (lands under the first S1: its closing vmcnt(0) covers it)
+  P4_STAMP(4);
   auto iter = [&](f32x16_t (&hcur)[2], f32x16_t (&hnext)[2], int t) {  // hcur = fc1 of tick t (complete)
-    pack_xp(hcur);
+    [[maybe_unused]] unsigned long long ta, tb0, tb, tc, td;
+    P4_NOWL(ta);
+    if constexpr (!(CS_P4_ABL & 1024)) pack_xp(hcur);
     if (t + 1 < NTICK) s1(std::true_type{}, std::true_type{}, hnext, hcur, t + 1);
     else s1(std::true_type{}, std::false_type{}, hnext, hcur, t + 1);
-    hb_write(t & 1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+#ifdef CS_P4_STAMP2
+    { unsigned long long t_; P4_NOW(t_); if (t == 6 && blockIdx.x < 64 && lane == 0) { g_p4_dbg2[(blockIdx.x * 4 + wv) * 8 + 6] = t_; g_p4_dbg2[(blockIdx.x * 4 + wv) * 8 + 7] = ta; } }
+#endif
+    if constexpr (!(CS_P4_ABL & 512)) hb_write(t & 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    P4_NOWL(tb0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P4_NOWL(tb);
+    if constexpr (!(CS_P4_ABL & 256)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    P4_NOWL(tc);
     CS_SB();
-    s2(t);
+    if constexpr (!(CS_P4_ABL & 128)) s2(t);
+    P4_NOWL(td);
+#ifdef CS_P4_STAMP
+    ts1 += tb0 - ta; tvm += tb - tb0; tbar += tc - tb; ts2 += td - tc;
+#endif
   };
   // (fp16 mode: the GELU works on the packed halves alone, so fc1 of the next tick may overwrite the accumulators it was packed from; the bf16
   //  form's relu reads the fp32 pre-activations: two buffers)
@@ -352,13 +410,19 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
     else { iter(hA, hA, t); iter(hA, hA, t + 1); }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  P4_STAMP(5);
+#ifdef CS_P4_STAMP
+  if (blockIdx.x < 64 && lane == 0) { unsigned long long* d = g_p4_dbg + (blockIdx.x * 4 + wv) * 16; d[8] = ts1; d[9] = tvm; d[10] = tbar; d[11] = ts2; }
+#endif
 
   // ---- epilogue: x rows back to memory, the next layer's normalised rows ----
+  const unsigned le = fresh_lane();
+  const int je = le & 31, he = le >> 5;
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb) {
-    const int row = row_base + rb * 32 + j;
+    const int row = row_base + rb * 32 + je;
     if (row < p.M) {
-      float* xr = p.x + (size_t)row * PC + 96 * wv + 16 * h;
+      float* xr = p.x + (size_t)row * PC + 96 * wv + 16 * he;
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
@@ -366,16 +430,17 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
           *reinterpret_cast<f32x4_t*>(xr + 32 * ct + 4 * q) = f32x4_t{acc[rb][ct][4 * q], acc[rb][ct][4 * q + 1], acc[rb][ct][4 * q + 2], acc[rb][ct][4 * q + 3]};
     }
   }
+  P4_STAMP(6);
   if (p.u_out) {
     __syncthreads();
     float mean[4], rstd[4];
-    row_stats(mean, rstd);
+    row_stats(mean, rstd, je, he);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      const int row = row_base + rb * 32 + j;
+      const int row = row_base + rb * 32 + je;
       const float nb = -mean[rb] * rstd[rb];
       if (row < p.M) {
-        h16_t* ur = p.u_out + (size_t)row * PC + 96 * wv + 16 * h;
+        h16_t* ur = p.u_out + (size_t)row * PC + 96 * wv + 16 * he;
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
@@ -388,6 +453,11 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
       }
     }
   }
+#ifdef CS_P4_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  P4_STAMP(7);
+  if (blockIdx.x < 64 && lane == 0) g_p4_dbg[(blockIdx.x * 4 + wv) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---- weight image.  One thread per 16-byte fragment element (8 halves): [fragment][lane 0..63].  Lane (i = lane & 31, h = lane >> 5) of an
@@ -396,7 +466,7 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
 //        natural  16 ks + 8 h + e                        (out-projection: B fragments come from memory)
 //        tiled    32 (ks >> 1) + 16 h + 8 (ks & 1) + e   (fc1 / fc2: B fragments are accumulator tiles)
 //      Sections: [out-projection: wave w, k-step ks, column tile ct -> output tile T = 3 w + ct]
-//                [24 ticks: W1 fragment ht * 24 + ks = hidden tile 2 t + ht, k-step ks | W2: wave w, fc2 k-step kk, column tile ct =
+//                [24 ticks: W1 fragment 2 ks + ht = hidden tile 2 t + ht, k-step ks | W2: wave w, fc2 k-step kk, column tile ct =
 //                 output tile 3 w + ct, hidden k-step 4 t + kk] ----
 template <bool BF>
 __global__ __launch_bounds__(256) void cs_panel4_pack_kernel(const float* __restrict__ wo, const float* __restrict__ ls1,
@@ -422,7 +492,7 @@ __global__ __launch_bounds__(256) void cs_panel4_pack_kernel(const float* __rest
     if (t >= NTICK) {
       // padding: zeros
     } else if (f < 48) {
-      const int ht = f / KS, ks = f % KS;
+      const int ht = f % 2, ks = f / 2;
       const int rowi = HT * t + 32 * ht + panel4_perm(i);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -462,6 +532,11 @@ hipError_t panel4_launch_t(const CsPanelParams* p, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+#ifdef CS_P4_STAMP
+int cs_panel4_debug_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_p4_dbg), sizeof(g_p4_dbg)); }
+int cs_panel4_debug_read2(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_p4_dbg2), sizeof(g_p4_dbg2)); }
+#endif
 
 size_t cs_panel4_image_bytes(int with_outproj) { return (with_outproj ? IMG_WO : 0) + (size_t)(NTICK + PAD_TICKS) * IMG_TICK; }
 
