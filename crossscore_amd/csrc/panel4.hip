@@ -233,16 +233,12 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   }
 
   // =========================================================================================================================
-  // MLP: 24 ticks of 64 hidden columns.
-  //   S1(t): fc1 of tick t + 1 (48 MFMAs: hidden tile ht, k-step ks; W1 fragment ht * 24 + ks from ring slot (t + 1) & 1, one LDS read per MFMA,
-  //          eight ahead) with the GELU of tick t in the gaps (one block of the packed-half GELU per gap), then the activated slice of row block
-  //          w leaves as 4 B fragments into buffer t & 1; vmcnt(0) (everything S2(t - 1) fetched has landed); barrier.
-  //   S2(t): fc2 of tick t (48 MFMAs: k-step kk, row block rb, column tile ct; W2 fragments in registers, B fragment (kk, rb) from LDS once per
-  //          3 MFMAs) -- and the fetches: W2 of tick t + 1 into the registers just used (global loads), W1 of tick t + 3 into ring slot
-  //          (t + 1) & 1, free since the barrier (12 LDS-DMA pieces per wave).
+  // MLP: 24 ticks of 64 hidden columns, software-pipelined over three ticks (see `tick` below): per iteration fc1 of tick t + 1, the GELU of
+  // tick t and fc2 of tick t - 1, one barrier.
   // =========================================================================================================================
   h16x8_t w2r[12];       // this wave's W2 fragments of the current tick: [kk][ct]
-  h16x8_t wp[8];         // rolling pool of W1 fragments
+  constexpr int WPN = BF ? 6 : 8;  // (the bf16 form keeps two fc1 accumulator buffers: a smaller pool keeps it out of scratch)
+  h16x8_t wp[WPN];       // rolling pool of W1 fragments: fragment M in wp[M % WPN], WPN MFMAs ahead
   f32x16_t hA[2], hB[2]; // fc1 accumulators of even / odd ticks: [hidden tile]
   unsigned xp[16];       // the previous tick's pre-activations as packed halves: xp[4 (2 ht + s) + q] = (r = 8 s + 2 q, + 1) of tile ht
   PkGelu pg;
@@ -260,30 +256,65 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   // B fragment of the bias k-step: 1.0 in contraction slots 0 and 1 (lane half 0, elements 0 and 1), 0 elsewhere
   const h16x8_t ones = __builtin_bit_cast(h16x8_t, u32x4_t{hm == 0 ? (BF ? 0x3F803F80u : 0x3C003C00u) : 0u, 0u, 0u, 0u});
 
+  // The MLP section of the image through a buffer descriptor: a fetch is (descriptor, this lane's 32-bit offset, a scalar offset, an immediate
+  // < 4 KiB) -- no 64-bit address pair per lane has to be formed or kept (the flat forms cost 6 VGPRs and a v_add_co / v_addc pair per fetch;
+  // in the bf16 form one such pair was spilled into the loop).  LDS-DMA piece K of a 12-piece run: groups of four share a scalar offset.
+  const __amdgpu_buffer_rsrc_t rs_mlp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img_mlp), 0, (int)((NTICK + PAD_TICKS) * IMG_TICK), 0x00020000);
+  auto dma_w1 = [&](auto K_, unsigned soff, unsigned dst) {  // piece K of this wave's 12: image offset soff + K KiB -> LDS dst + K KiB
+    constexpr int K = decltype(K_)::value;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_mlp, (__attribute__((address_space(3))) void*)(size_t)(dst + (K & ~3) * FRAG), 16, lm16,
+                                             soff + (K & ~3) * FRAG, (K & 3) * FRAG, 0);
+  };
   auto w1_issue = [&](int t) {  // this wave's 12 pieces of tick t's W1 slice, all at once (prologue)
     const unsigned dst = lds0 + L_A + (t & 1) * (48 * FRAG) + wv * 12 * FRAG;
-    const char* s = img_mlp + (size_t)t * IMG_TICK + wv * 12 * FRAG + lm16;
-    // (the instruction's immediate offset is 13-bit signed: pieces in groups of four, the group's base in the addresses)
-    sfor<12>([&](auto K_) { constexpr int K = decltype(K_)::value; dma_piece<(K & 3) * FRAG>(s + (K & ~3) * FRAG, dst + (K & ~3) * FRAG); });
+    const unsigned soff = t * (unsigned)IMG_TICK + wv * 12 * FRAG;
+    sfor<12>([&](auto K_) { dma_w1(K_, soff, dst); });
   };
-  auto w2_load = [&](int t) {
-    const char* s = img_mlp + (size_t)t * IMG_TICK + IMG_W1 + wv * 12 * FRAG + lm16;
+  auto pack_xp = [&](const f32x16_t (&ha)[2]) {
 #pragma unroll
-    for (int f = 0; f < 12; ++f) w2r[f] = *reinterpret_cast<const h16x8_t*>(s + f * FRAG);
+    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xp[4 * (2 * ht + s) + q] = pack_h16x2(ha[ht][8 * s + 2 * q], ha[ht][8 * s + 2 * q + 1]);
   };
-  // fc1 of tick t into hn (from ring slot t & 1), GELU blocks on xp (pre-activations `ha` of the previous tick, fp32, for the bf16 form)
-  auto s1 = [&](auto GELU_, auto FC1_, f32x16_t (&hn)[2], const f32x16_t (&ha)[2], int t) {
-    constexpr bool GELU = decltype(GELU_)::value, FC1 = decltype(FC1_)::value;
-    const unsigned cur = ring + (t & 1) * (48 * FRAG);
-    if constexpr (FC1) {
+  // GELU block B (0..47) of the tick: group B / 6 = packed registers 2 G, 2 G + 1, block B % 6 of its six
+  auto gelu_block = [&](auto B_, const f32x16_t (&ha)[2]) {
+    constexpr int B = decltype(B_)::value;
+    constexpr int G = B / 6, ht = G / 4, r0 = 8 * ((G / 2) & 1) + 4 * (G & 1);
+    if constexpr (!(CS_P4_ABL & 1))
+      pk_gelu_block<B % 6, BF>(pg, xp[2 * G], xp[2 * G + 1], kk_, ha[ht][r0], ha[ht][r0 + 1], ha[ht][r0 + 2], ha[ht][r0 + 3]);
+  };
+  // One iteration = 98 MFMA gaps and ONE barrier.  Iteration t:
+  //   F1  fc1 of tick t + 1 into hn (W1 from ring slot (t + 1) & 1: one LDS read per MFMA, eight ahead; the bias through one more k-step per
+  //       tile) -- gaps 0..49;
+  //   G   GELU of tick t (its pre-activations `ha`, packed to halves first) -- one block of the packed-half GELU every second gap of the whole
+  //       iteration; the activated slice of this wave's row block leaves as 4 B fragments into hand-off buffer t & 1 at the end;
+  //   F2  fc2 of tick t - 1 from buffer (t - 1) & 1 (written before the previous barrier): k-step kk, row block rb, column tile ct; W2 fragments
+  //       in registers, B fragment (kk, rb) from LDS once per 3 MFMAs -- gaps 50..97;
+  //   fetches: W1 of tick t + 2 into ring slot t & 1 (free since the previous barrier; 12 LDS-DMA pieces in the F1 phase, so they have half an
+  //       iteration to land before the closing wait), W2 of tick t into the registers F2 has just used (global loads, consumed an iteration on).
+  //       The closing wait leaves exactly those 12 register loads in flight (vmcnt counts in issue order).  (All 24 fetches in the F1 phase:
+  //       measured slower, 4 890 against 4 475 cycles per iteration -- that phase already carries the fragment reads.)
+  auto tick = [&](auto F1_, auto G_, auto F2_, f32x16_t (&hn)[2], const f32x16_t (&ha)[2], int t) {
+    constexpr bool F1 = decltype(F1_)::value, G = decltype(G_)::value, F2 = decltype(F2_)::value;
+    const unsigned cur = ring + ((t + 1) & 1) * (48 * FRAG);
+    const unsigned hr = hbr + ((t + 1) & 1) * (16 * FRAG);
+    const unsigned w1s = (unsigned)(t + 2) * (unsigned)IMG_TICK + wv * 12 * FRAG;            // scalar offsets into the MLP section
+    const unsigned w1d = lds0 + L_A + (t & 1) * (48 * FRAG) + wv * 12 * FRAG;
+    const unsigned w2s = (unsigned)t * (unsigned)IMG_TICK + (unsigned)IMG_W1 + wv * 12 * FRAG;
+    constexpr int HBN = BF ? 3 : 4;  // (bf16 form: one register quad less, see WPN)
+    h16x8_t hb[HBN];  // rolling pool of B fragments of fc2: fragment g = 4 kk + rb lives in hb[g % HBN], HBN - 1 groups ahead
+    if constexpr (G) pack_xp(ha);
+    if constexpr (F1) {
       // fc1 bias through the matrix pipe: one more k-step per tile whose weight fragment carries b1 (split hi + lo: exact to 2^-22 / 2^-16) in
       // contraction slots 0 and 1 and whose activation fragment is 1 there -- the accumulators start from the inline constant 0, nothing is
       // written into them by the vector unit (the MFMA results live in accumulator registers: 32 v_accvgpr_write per tick otherwise)
       float bv[2];
-      asm volatile("ds_read_b32 %0, %1" : "=&v"(bv[0]) : "v"(b1g + t * (HT * 4)) : "memory");
-      asm volatile("ds_read_b32 %0, %1 offset:128" : "=&v"(bv[1]) : "v"(b1g + t * (HT * 4)) : "memory");
-      sfor<8>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(cur, wp[decltype(F_)::value]); });
-      CS_LGKM(8);
+      asm volatile("ds_read_b32 %0, %1" : "=&v"(bv[0]) : "v"(b1g + (t + 1) * (HT * 4)) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:128" : "=&v"(bv[1]) : "v"(b1g + (t + 1) * (HT * 4)) : "memory");
+      sfor<WPN>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(cur, wp[decltype(F_)::value]); });
+      CS_LGKM(WPN);
 #pragma unroll
       for (int ht = 0; ht < 2; ++ht) {
         const unsigned hi = BF ? (unsigned)f2bf(bv[ht]) : (unsigned)f2h(bv[ht]);
@@ -296,124 +327,95 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
     }
     sfor<48>([&](auto M_) {
       constexpr int M = decltype(M_)::value;
-#ifdef CS_P4_STAMP2
-      if constexpr (GELU && FC1 && (M % 8 == 0)) { unsigned long long t_; P4_NOW(t_); if (t == 7 && blockIdx.x < 64 && lane == 0) g_p4_dbg2[(blockIdx.x * 4 + wv) * 8 + M / 8] = t_; }
-#endif
-      if constexpr (FC1) {
-        // consumption order: the two hidden tiles alternate (two independent accumulation chains); fragment M of the tick's W1 slice (in this
-        // order in the image) = tile ht, k-step ks
+      if constexpr (F1) {
+        // consumption order: the two hidden tiles alternate; fragment M of the tick's W1 slice (in this order in the image) = tile ht, k-step ks.
+        // Fragment M is complete when at most (the LDS operations issued behind it) are outstanding: WPN - 1 reads in the steady state; at the
+        // tail fewer, plus the first three fc2 fragments, which are read behind fragment 47
         constexpr int ht = M % 2, ks = M / 2;
-        // fragment M is complete when at most (the reads issued behind it) are outstanding: 7 in the steady state, fewer at the tail
-        constexpr int BEHIND = (M + 8 <= 48) ? 7 : 47 - M;
+        constexpr int BEHIND = (M + WPN <= 48) ? WPN - 1 : 47 - M + (F2 ? HBN - 1 : 0);
         if constexpr (!(CS_P4_ABL & 8)) CS_LGKM(BEHIND);
-        if constexpr (CS_P4_ABL & 32) hn[ht] = mfma_32x32x16<BF>(ones, xf[ks], hn[ht]);
-        else if constexpr (CS_P4_ABL & 64) hn[ht] = mfma_32x32x16<BF>(wp[M % 8], ones, hn[ht]);
-        else if constexpr (CS_P4_ABL & 8192) hn[ht] = mfma_32x32x16<BF>(wp[M % 8], xf[0], hn[ht]);                       // H1: one B fragment, 23 dead
-        else if constexpr (CS_P4_ABL & 16384) { asm volatile("" :: "v"(xf[ks])); hn[ht] = mfma_32x32x16<BF>(wp[M % 8], ones, hn[ht]); }  // H2: all live, unused
-        else if constexpr (!(CS_P4_ABL & 4)) hn[ht] = mfma_32x32x16<BF>(wp[M % 8], xf[ks], hn[ht]);
-        if constexpr (M + 8 < 48 && !(CS_P4_ABL & 2)) lds_read1<(M + 8) * FRAG>(cur, wp[M % 8]);
+        hn[ht] = mfma_32x32x16<BF>(wp[M % WPN], xf[ks], hn[ht]);
+        if constexpr (M + WPN < 48 && !(CS_P4_ABL & 2)) lds_read1<(M + WPN) * FRAG>(cur, wp[M % WPN]);
+        if constexpr (M == 47 - WPN && F2) sfor<HBN - 1>([&](auto G_) { constexpr int Gi = decltype(G_)::value; lds_read1<Gi * FRAG>(hr, hb[Gi]); });
+        if constexpr (M % 4 == 1 && !(CS_P4_ABL & 16)) {
+          dma_w1(IC<M / 4>{}, w1s, w1d);
+        }
       }
-      if constexpr (GELU && !(CS_P4_ABL & 1)) {
-        constexpr int G = M / 6, B = M % 6;       // group G = packed registers 2 G, 2 G + 1; block B of its six
-        constexpr int ht = G / 4, r0 = 8 * ((G / 2) & 1) + 4 * (G & 1);
-        pk_gelu_block<B, BF>(pg, xp[2 * G], xp[2 * G + 1], kk_, ha[ht][r0], ha[ht][r0 + 1], ha[ht][r0 + 2], ha[ht][r0 + 3]);
-      }
+
+      if constexpr (G && M % 2 == 0) gelu_block(IC<M / 2>{}, ha);
       CS_SB();
     });
-  };
-  auto hb_write = [&](int buf) {
-    const unsigned a = hbw + buf * (16 * FRAG);
-    sfor<4>([&](auto K_) {
-      constexpr int K = decltype(K_)::value;
-      lds_write16<K * 4 * FRAG>(a, u32x4_t{xp[4 * K], xp[4 * K + 1], xp[4 * K + 2], xp[4 * K + 3]});
-    });
-  };
-  auto pack_xp = [&](const f32x16_t (&ha)[2]) {
-#pragma unroll
-    for (int ht = 0; ht < 2; ++ht)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xp[4 * (2 * ht + s) + q] = pack_h16x2(ha[ht][8 * s + 2 * q], ha[ht][8 * s + 2 * q + 1]);
-  };
-  // fc2 of tick t (buffer t & 1) and the fetches for later ticks
-  auto s2 = [&](int t) {
-    const unsigned hr = hbr + (t & 1) * (16 * FRAG);
-    const char* w2s = img_mlp + (size_t)(t + 1) * IMG_TICK + IMG_W1 + wv * 12 * FRAG + lm16;
-    const char* w1s = img_mlp + (size_t)(t + 3) * IMG_TICK + wv * 12 * FRAG + lm16;
-    const unsigned w1d = lds0 + L_A + ((t + 1) & 1) * (48 * FRAG) + wv * 12 * FRAG;
-    h16x8_t hb[4];  // rolling pool of B fragments: fragment g = 4 kk + rb lives in hb[g % 4], three groups ahead
-    if constexpr (!(CS_P4_ABL & 4096)) sfor<3>([&](auto G_) { constexpr int G = decltype(G_)::value; lds_read1<G * FRAG>(hr, hb[G]); });
+    if constexpr (F2 && !F1) sfor<HBN - 1>([&](auto G_) { constexpr int Gi = decltype(G_)::value; lds_read1<Gi * FRAG>(hr, hb[Gi]); });
     sfor<16>([&](auto G_) {
-      constexpr int G = decltype(G_)::value;
-      constexpr int kk = G / 4, rb = G % 4;
-      if constexpr (G + 3 < 16 && !(CS_P4_ABL & 4096)) lds_read1<(G + 3) * FRAG>(hr, hb[(G + 3) % 4]);
-      constexpr int BEHIND = (G + 3 < 16) ? 3 : 15 - G;
-      if constexpr (!(CS_P4_ABL & 4096)) CS_LGKM(BEHIND);
+      constexpr int Gi = decltype(G_)::value;
+      constexpr int kk = Gi / 4, rb = Gi % 4;
+      if constexpr (F2) {
+        if constexpr (Gi + HBN - 1 < 16 && !(CS_P4_ABL & 2)) lds_read1<(Gi + HBN - 1) * FRAG>(hr, hb[(Gi + HBN - 1) % HBN]);
+        constexpr int BEHIND = (Gi + HBN - 1 < 16) ? HBN - 1 : 15 - Gi;
+        if constexpr (!(CS_P4_ABL & 8)) CS_LGKM(BEHIND);
+      }
       sfor<3>([&](auto C_) {
         constexpr int ct = decltype(C_)::value;
-        if constexpr (!(CS_P4_ABL & 2048)) acc[rb][ct] = mfma_32x32x16<BF>(w2r[kk * 3 + ct], hb[G % 4], acc[rb][ct]);
-        if constexpr (rb == 3) {  // the last use of this weight fragment: refill it with the next tick's (lands during the next S1)
-          if constexpr (!(CS_P4_ABL & (16 | 4096))) w2r[kk * 3 + ct] = *reinterpret_cast<const h16x8_t*>(w2s + (kk * 3 + ct) * FRAG);
-        } else if constexpr (ct == 1) {  // 12 gaps (kk, rb < 3, ct = 1): one W1 piece each
-          constexpr int K = kk * 3 + rb;
-          if constexpr (!(CS_P4_ABL & (16 | 4096))) dma_piece<(K & 3) * FRAG>(w1s + (K & ~3) * FRAG, w1d + (K & ~3) * FRAG);
-        }
+        constexpr int M2 = Gi * 3 + ct;
+        if constexpr (F2) acc[rb][ct] = mfma_32x32x16<BF>(w2r[kk * 3 + ct], hb[Gi % HBN], acc[rb][ct]);
+        // behind the last use of this weight fragment: refill it with tick t's (consumed by the fc2 phase of the next iteration; iteration 0,
+        // which has no fc2 phase of its own, fetches tick 0's here as well)
+        if constexpr ((F2 || G) && rb == 3 && !(CS_P4_ABL & 16)) w2r[kk * 3 + ct] = __builtin_bit_cast(h16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_mlp, lm16 + ((kk * 3 + ct) & 3) * FRAG, w2s + ((kk * 3 + ct) & ~3) * FRAG, 0));
+        if constexpr (G && M2 % 2 == 0) gelu_block(IC<24 + M2 / 2>{}, ha);
         CS_SB();
       });
     });
-  };
-
-  // prologue: W1 of ticks 0 and 1; fc1 of tick 0; then W1 of tick 2 into slot 0 and W2 of tick 0 into its registers
-  P4_STAMP(3);
-  [[maybe_unused]] unsigned long long ts1 = 0, tvm = 0, tbar = 0, ts2 = 0;
-  w1_issue(0);
-  w1_issue(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  s1(std::false_type{}, std::true_type{}, hA, hA, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  w1_issue(2);
-  w2_load(0);  // (lands under the first S1: its closing vmcnt(0) covers it)
-  P4_STAMP(4);
-  auto iter = [&](f32x16_t (&hcur)[2], f32x16_t (&hnext)[2], int t) {  // hcur = fc1 of tick t (complete)
-    [[maybe_unused]] unsigned long long ta, tb0, tb, tc, td;
-    P4_NOWL(ta);
-    if constexpr (!(CS_P4_ABL & 1024)) pack_xp(hcur);
-    if (t + 1 < NTICK) s1(std::true_type{}, std::true_type{}, hnext, hcur, t + 1);
-    else s1(std::true_type{}, std::false_type{}, hnext, hcur, t + 1);
-#ifdef CS_P4_STAMP2
-    { unsigned long long t_; P4_NOW(t_); if (t == 6 && blockIdx.x < 64 && lane == 0) { g_p4_dbg2[(blockIdx.x * 4 + wv) * 8 + 6] = t_; g_p4_dbg2[(blockIdx.x * 4 + wv) * 8 + 7] = ta; } }
-#endif
-    if constexpr (!(CS_P4_ABL & 512)) hb_write(t & 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    P4_NOWL(tb0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    P4_NOWL(tb);
-    if constexpr (!(CS_P4_ABL & 256)) __builtin_amdgcn_s_barrier();
+    if constexpr (G) {
+      const unsigned a = hbw + (t & 1) * (16 * FRAG);
+      sfor<4>([&](auto K_) {
+        constexpr int K = decltype(K_)::value;
+        lds_write16<K * 4 * FRAG>(a, u32x4_t{xp[4 * K], xp[4 * K + 1], xp[4 * K + 2], xp[4 * K + 3]});
+      });
+    }
+    // everything but the 12 register loads of this iteration's fc2 phase has landed: the LDS-DMA pieces of the ring slot the next iteration
+    // reads, and (older) the previous iteration's register loads (vmcnt counts in issue order)
+    if constexpr (F2 || G) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    P4_NOWL(tc);
     CS_SB();
-    if constexpr (!(CS_P4_ABL & 128)) s2(t);
-    P4_NOWL(td);
-#ifdef CS_P4_STAMP
-    ts1 += tb0 - ta; tvm += tb - tb0; tbar += tc - tb; ts2 += td - tc;
-#endif
   };
-  // (fp16 mode: the GELU works on the packed halves alone, so fc1 of the next tick may overwrite the accumulators it was packed from; the bf16
-  //  form's relu reads the fp32 pre-activations: two buffers)
-  for (int t = 0; t < NTICK; t += 2) {
-    if constexpr (BF) { iter(hA, hB, t); iter(hB, hA, t + 1); }
-    else { iter(hA, hA, t); iter(hA, hA, t + 1); }
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
+  // prologue: W1 of tick 0; "iteration -1" = fc1 of tick 0 (and the fetch of W1 of tick 1)
+  P4_STAMP(3);
+  // iteration 0 runs the full body: its fc2 phase ("tick -1") multiplies zero weight fragments with a zeroed hand-off buffer -- 48 MFMAs that
+  // add exact zeros -- instead of being one more instance of the body (whose register allocation spilled in the bf16 form)
+  {
+    const u32x4_t z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4_t*>(smem + L_HB + 16 * FRAG + (q * 256 + tid) * 16) = z4;
+#pragma unroll
+    for (int f = 0; f < 12; ++f) w2r[f] = __builtin_bit_cast(h16x8_t, z4);
   }
+  w1_issue(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  tick(T_{}, F_{}, F_{}, hA, hA, -1);
+  P4_STAMP(4);
+  // (fp16 mode: the GELU works on the packed halves alone, so fc1 of the next tick may overwrite the accumulators it was packed from; the bf16
+  //  form's relu reads the fp32 pre-activations: two buffers, alternating)
+  if constexpr (BF) {
+    for (int t = 0; t < NTICK - 2; t += 2) {
+      tick(T_{}, T_{}, T_{}, hB, hA, t);
+      tick(T_{}, T_{}, T_{}, hA, hB, t + 1);
+    }
+    tick(T_{}, T_{}, T_{}, hB, hA, NTICK - 2);
+    tick(F_{}, T_{}, T_{}, hA, hB, NTICK - 1);
+  } else {
+    for (int t = 0; t < NTICK - 1; ++t) tick(T_{}, T_{}, T_{}, hA, hA, t);
+    tick(F_{}, T_{}, T_{}, hA, hA, NTICK - 1);
+  }
+  tick(F_{}, F_{}, T_{}, hA, hA, NTICK);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   P4_STAMP(5);
-#ifdef CS_P4_STAMP
-  if (blockIdx.x < 64 && lane == 0) { unsigned long long* d = g_p4_dbg + (blockIdx.x * 4 + wv) * 16; d[8] = ts1; d[9] = tvm; d[10] = tbar; d[11] = ts2; }
-#endif
 
   // ---- epilogue: x rows back to memory, the next layer's normalised rows ----
   const unsigned le = fresh_lane();
