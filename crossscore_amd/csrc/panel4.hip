@@ -85,67 +85,114 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   const char* img_mlp = img + (OUTPROJ ? IMG_WO : 0);
 
   P4_STAMP(0);
-  // ---- fc1 bias -> LDS (plain stores: nothing is in flight yet) ----
-  for (int i = tid; i < PF / 4; i += 256)
-    reinterpret_cast<f32x4_t*>(smem + L_B1)[i] = reinterpret_cast<const f32x4_t*>(p.b1)[i];
 
-  // ---- attention-output rows -> LDS as B fragments [row block][k-step] (natural contraction order 16 ks + 8 h + e): wave w copies row block w ----
+  // ---- attention-output rows -> LDS, whole 128-byte lines: six planes [128-byte segment s of a row][row 0..127][128 B].  One LDS-DMA piece =
+  //      8 rows x 128 B of one plane (8 full lines; the fragment-shaped copy of round 6's first version fetched 64 separate 16-byte pieces per
+  //      instruction).  Lane l of a piece writes row 8 g + l / 8, 16-byte position l % 8, and FETCHES chunk (l % 8) ^ ((row >> 1) & 7) of the
+  //      segment: with the same XOR on the read side a B-fragment read (32 rows x one chunk per lane half) is conflict-free.  Wave w copies
+  //      its own row block (row groups 4 w .. 4 w + 3). ----
   if constexpr (OUTPROJ) {
-    const size_t rowa = (size_t)min(row_base + wv * 32 + j, p.M - 1);
-    const char* so = reinterpret_cast<const char*>(p.attn_o) + rowa * (PC * 2) + 16 * h;
-    const unsigned dst = lds0 + L_A + wv * KS * FRAG;
-    sfor<KS>([&](auto K_) {
-      constexpr int K = decltype(K_)::value;
-      dma_piece<0>(so + K * 32, dst + K * FRAG);
-    });
-  }
-
-  // ---- residual rows -> accumulators: acc[rb][ct][r] = x[row_base + 32 rb + j][96 w + 32 ct + 16 h + r]  (+ out-projection bias) ----
-  f32x16_t acc[4][3];
-  {
-    const float* bsrc = p.bo + 96 * wv + 16 * h;
+    const int rl = lane >> 3, cp = lane & 7;
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
-      f32x4_t bq[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bq[q] = OUTPROJ ? *reinterpret_cast<const f32x4_t*>(bsrc + 32 * ct + 4 * q) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const size_t row = (size_t)min(row_base + rb * 32 + j, p.M - 1);
-        const float* xr = p.x + row * PC + 96 * wv + 32 * ct + 16 * h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4_t v = *reinterpret_cast<const f32x4_t*>(xr + 4 * q);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[rb][ct][4 * q + i] = v[i] + (OUTPROJ ? bq[q][i] : 0.f);
-        }
-      }
+    for (int gq = 0; gq < 4; ++gq) {
+      const int r = 32 * wv + 8 * gq + rl;                       // row of the panel
+      const int c = cp ^ ((r >> 1) & 7);
+      const char* so = reinterpret_cast<const char*>(p.attn_o) + (size_t)min(row_base + r, p.M - 1) * (PC * 2) + c * 16;
+      const unsigned dst = lds0 + L_A + (32 * wv + 8 * gq) * 128;
+      sfor<6>([&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        dma_piece<0>(so + S * 128, dst + S * 16384);
+      });
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
 
-  P4_STAMP(1);
-  // ---- attention output projection: per k-step 3 private weight fragments (global -> registers) x 4 row-block fragments (LDS) = 12 MFMAs ----
-  if constexpr (OUTPROJ) {
-    const char* wsrc = img + (size_t)wv * (KS * 3 * FRAG) + lane16;
-    const char* bfr = smem + L_A + lane16;
-#pragma unroll 6
-    for (int ks = 0; ks < KS; ++ks) {
-      h16x8_t wf[3], bf[4];
+  // ---- residual rows: xt[rb][ct][q] = 4 floats of x[row_base + 32 rb + j][96 w + 32 ct + 16 h + 4 q ..].  With the out-projection they are
+  //      fetched BEHIND the attention-output pieces and only waited for after it (the projection needs the attention output and the weights;
+  //      the 192 KiB of residual rows -- two thirds of the workgroup's input bytes, from HBM -- arrive under its 288 MFMAs) ----
+  f32x16_t acc[4][3];
+  {
+    f32x4_t xt[4][3][4];
 #pragma unroll
-      for (int ct = 0; ct < 3; ++ct) wf[ct] = *reinterpret_cast<const h16x8_t*>(wsrc + (ks * 3 + ct) * FRAG);
+    for (int rb = 0; rb < 4; ++rb) {
+      const size_t row = (size_t)min(row_base + rb * 32 + j, p.M - 1);
+      const float* xr = p.x + row * PC + 96 * wv + 16 * h;
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) bf[rb] = *reinterpret_cast<const h16x8_t*>(bfr + (rb * KS + ks) * FRAG);
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xt[rb][ct][q] = *reinterpret_cast<const f32x4_t*>(xr + 32 * ct + 4 * q);
+    }
+    if constexpr (OUTPROJ) {
+      // every LDS-DMA piece of this wave has landed (the 48 residual loads behind them may still be in flight); then everybody's
+      asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      P4_STAMP(1);
+      // ---- attention output projection: per k-step 3 private weight fragments (global -> registers) x 4 row-block fragments (LDS) = 12 MFMAs ----
+      // The weight fragments are private to the wave: buffer loads straight into registers, PD k-steps ahead (left to itself hipcc issues each
+      // load right in front of its use: one L2 round trip per k-step, 23 k cycles for 288 MFMAs); the B fragments one k-step ahead.
+      const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, (int)IMG_WO, 0x00020000);
+      const unsigned wo_s = wv * (KS * 3 * FRAG);
+      unsigned boff[4];  // this lane's byte offset of its chunk of k-step (ks % 4) inside a row-block plane
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) boff[kq] = j * 128 + (((kq * 2 + h) ^ ((j >> 1) & 7)) * 16);
+      const char* bpl = smem + L_A;
+      constexpr int PD = 6;
+      h16x8_t wq[PD][3], bq[2][4];
+      auto wload = [&](auto KS_) {
+        constexpr int K = decltype(KS_)::value;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+          wq[K % PD][ct] = __builtin_bit_cast(h16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_wo, lane16 + ct * FRAG, wo_s + K * 3 * FRAG, 0));
+      };
+      auto bload = [&](auto KS_) {
+        constexpr int K = decltype(KS_)::value;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) bq[K & 1][rb] = *reinterpret_cast<const h16x8_t*>(bpl + (K / 4) * 16384 + rb * 4096 + boff[K % 4]);
+      };
+      sfor<PD>([&](auto K_) { wload(K_); });
+      bload(IC<0>{});
+      CS_SB();
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      sfor<KS>([&](auto K_) {
+        constexpr int K = decltype(K_)::value;
+        if constexpr (K + 1 < KS) bload(IC<K + 1>{});
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) acc[rb][ct] = mfma_32x32x16<BF>(wq[K % PD][ct], bq[K & 1][rb], K == 0 ? zero : acc[rb][ct]);
+        if constexpr (K + PD < KS) wload(IC<K + PD>{});
+        CS_SB();
+      });
+      P4_STAMP(2);
+      // x + (projection + bias): the residual rows have arrived meanwhile
+      const float* bsrc = p.bo + 96 * wv + 16 * h;
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bsrc + 32 * ct + 4 * q);
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[rb][ct][4 * q + i] += xt[rb][ct][q][i] + b4[i];
+        }
+    } else {
+      P4_STAMP(1);
+      P4_STAMP(2);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) acc[rb][ct] = mfma_32x32x16<BF>(wf[ct], bf[rb], acc[rb][ct]);
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[rb][ct][4 * q + i] = xt[rb][ct][q][i];
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // (the fc1 bias is in LDS)
+      asm volatile("" ::: "memory");
     }
   }
 
-  P4_STAMP(2);
   // ---- LayerNorm statistics of complete rows: a row's 384 columns live in lanes j / j + 32 of all four waves.  Two passes (mean, then
   //      squared deviations), each: 48 values in the lane + the other half of the wave + the other three waves through LDS, summed in a fixed order ----
   float* red = reinterpret_cast<float*>(smem + L_RED);
@@ -213,6 +260,10 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
     for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const h16x8_t*>(smem + L_A + (wv * KS + ks) * FRAG + lane16);
     __syncthreads();  // every wave holds its fragments: L_A becomes the W1 ring
   }
+  // ---- fc1 bias -> LDS (plain accesses: no LDS-DMA is in flight here; kept out of the kernel's first instructions, where its vmcnt(0)
+  //      would wait for the attention-output pieces and the residual rows) ----
+  for (int i = tid; i < PF / 4; i += 256)
+    reinterpret_cast<f32x4_t*>(smem + L_B1)[i] = reinterpret_cast<const f32x4_t*>(p.b1)[i];
   // the fc2 accumulators start at residual + bias.  The bias enters through the matrix pipe (one MFMA per tile: b2 split hi + lo in contraction
   // slots 0 / 1 against a fragment of ones): a vector add on the accumulators here, with norm2(x) live beside them, overflowed the arch
   // VGPRs and hipcc spilled 22 accumulator registers around the prologue
@@ -417,41 +468,62 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   P4_STAMP(5);
 
-  // ---- epilogue: x rows back to memory, the next layer's normalised rows ----
+  // ---- epilogue: x rows back to memory, the next layer's normalised rows.  A lane holds 64 B of a row per tile: stored directly, every store
+  //      instruction would touch 64 separate 16-byte pieces in 32 rows (measured: 29 k cycles for the 48 stores of a wave).  Each 32 x 32 tile
+  //      goes through a wave-private LDS patch instead (rows padded to 144 B: conflict-free 16-byte writes of a lane's row, row-contiguous reads)
+  //      and leaves as whole 128-byte lines, 8 rows per store instruction.  Wave-private: no barrier, the LDS queue keeps a wave's accesses in order. ----
   const unsigned le = fresh_lane();
   const int je = le & 31, he = le >> 5;
+  {
+    char* patch = smem + L_A + wv * (16 * 1024);                  // two patches of 32 x 144 B per wave (the ring is idle: last barrier passed)
+    char* pw = patch + je * 144 + he * 64;                        // this lane's 64 bytes of row je
+    const char* pr = patch + (le >> 3) * 144 + (le & 7) * 16;     // row le / 8 (+ 8 per pass), 16-byte piece le % 8
+    char* xg = reinterpret_cast<char*>(p.x) + ((size_t)row_base * PC + 96 * wv) * 4 + (size_t)(le >> 3) * (PC * 4) + (le & 7) * 16;
+    const int r0 = row_base + (le >> 3);
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb) {
-    const int row = row_base + rb * 32 + je;
-    if (row < p.M) {
-      float* xr = p.x + (size_t)row * PC + 96 * wv + 16 * he;
+    for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int ct = 0; ct < 3; ++ct)
+      for (int ct = 0; ct < 3; ++ct) {
+        const int pb = ((rb * 3 + ct) & 1) * (32 * 144);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<f32x4_t*>(xr + 32 * ct + 4 * q) = f32x4_t{acc[rb][ct][4 * q], acc[rb][ct][4 * q + 1], acc[rb][ct][4 * q + 2], acc[rb][ct][4 * q + 3]};
-    }
+          *reinterpret_cast<f32x4_t*>(pw + pb + 16 * q) = f32x4_t{acc[rb][ct][4 * q], acc[rb][ct][4 * q + 1], acc[rb][ct][4 * q + 2], acc[rb][ct][4 * q + 3]};
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const f32x4_t v = *reinterpret_cast<const f32x4_t*>(pr + pb + ps * 8 * 144);
+          if (r0 + rb * 32 + ps * 8 < p.M) *reinterpret_cast<f32x4_t*>(xg + (size_t)(rb * 32 + ps * 8) * (PC * 4) + ct * 128) = v;
+        }
+      }
   }
   P4_STAMP(6);
   if (p.u_out) {
     __syncthreads();
     float mean[4], rstd[4];
     row_stats(mean, rstd, je, he);
+    // normalised 16-bit rows: 64 B of a row per tile; patch rows padded to 80 B, 16 rows (of 64 B) per store instruction
+    char* patch = smem + L_A + wv * (16 * 1024);
+    char* pw = patch + je * 80 + he * 32;
+    const char* pr = patch + (le >> 2) * 80 + (le & 3) * 16;
+    char* ug = reinterpret_cast<char*>(p.u_out) + ((size_t)row_base * PC + 96 * wv) * 2 + (size_t)(le >> 2) * (PC * 2) + (le & 3) * 16;
+    const int r0 = row_base + (le >> 2);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      const int row = row_base + rb * 32 + je;
       const float nb = -mean[rb] * rstd[rb];
-      if (row < p.M) {
-        h16_t* ur = p.u_out + (size_t)row * PC + 96 * wv + 16 * he;
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
+      for (int ct = 0; ct < 3; ++ct) {
+        const int pb = ((rb * 3 + ct) & 1) * (32 * 80);
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            float v[8];
+        for (int s = 0; s < 2; ++s) {
+          float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaf(acc[rb][ct][8 * s + e], rstd[rb], nb);
-            *reinterpret_cast<u32x4_t*>(ur + 32 * ct + 8 * s) = pack8<BF>(v);
-          }
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(acc[rb][ct][8 * s + e], rstd[rb], nb);
+          *reinterpret_cast<u32x4_t*>(pw + pb + 16 * s) = pack8<BF>(v);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(pr + pb + ps * 16 * 80);
+          if (r0 + rb * 32 + ps * 16 < p.M) *reinterpret_cast<u32x4_t*>(ug + (size_t)(rb * 32 + ps * 16) * (PC * 2) + ct * 64) = v;
+        }
       }
     }
   }
