@@ -491,6 +491,8 @@ def main():
                     "default of the path (score-map MAE 1e-4); bf16 is BASELINE.json's wording for cfg-2 (MAE 8e-4, fp32's range)")
     ap.add_argument("--global-batch", type=int, default=128, help="fixed global batch of the strong-scaling leg (BASELINE.json configs[3]: ViT-B/14, 5 refs, "
                     "global bs=128 batch-sharded over the ranks); reported as scaling_cfg4 with mode 'strong'")
+    ap.add_argument("--panel-impl", type=int, default=-1, choices=(-1, 0, 1), help="token-panel kernel of the ViT-S encoder layers (cs_debug_panel_impl): 0 = panel.hip "
+                    "(8 waves), 1 = panel4.hip (4 waves); -1 = the library default")
     ap.add_argument("--rowln", type=int, default=1, choices=(0, 1, 2), help=argparse.SUPPRESS)  # cs_debug_rowln_enable (A/B runs; was the CS_NO_ROWLN environment read)
     ap.add_argument("--no-more-configs", action="store_true", help="skip the short legs of BASELINE configs[2] (ViT-B, 10 refs, bs 8) and configs[4] (1036 x 1036, bs 2)")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16-operand leg of the headline workload (dtype_legs)")
@@ -515,6 +517,9 @@ def main():
 
     if args.inflight < 0:
         raise SystemExit("--inflight must be >= 0")
+    if args.panel_impl >= 0:
+        from crossscore_amd import _lib
+        _lib.load().cs_debug_panel_impl(args.panel_impl)
     if args.rowln != 1:  # A/B runs (process-wide debug switch): 0 = the decoder's sub-block closings as GEMM + LayerNorm + GEMM launches again;
         from crossscore_amd import _lib  # 2 = linear + LayerNorm in one launch, the next linear as a GEMM of its own
         _lib.load().cs_debug_rowln_enable(args.rowln)

@@ -112,18 +112,23 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   f32x16_t acc[4][3];
   {
     f32x4_t xt[4][3][4];
+    auto load_xt = [&]() {
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      const size_t row = (size_t)min(row_base + rb * 32 + j, p.M - 1);
-      const float* xr = p.x + row * PC + 96 * wv + 16 * h;
+      for (int rb = 0; rb < 4; ++rb) {
+        const size_t row = (size_t)min(row_base + rb * 32 + j, p.M - 1);
+        const float* xr = p.x + row * PC + 96 * wv + 16 * h;
 #pragma unroll
-      for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xt[rb][ct][q] = *reinterpret_cast<const f32x4_t*>(xr + 32 * ct + 4 * q);
-    }
+          for (int q = 0; q < 4; ++q) xt[rb][ct][q] = *reinterpret_cast<const f32x4_t*>(xr + 32 * ct + 4 * q);
+      }
+    };
+    if constexpr (!OUTPROJ || (CS_P4_ABL & 32768)) load_xt();
     if constexpr (OUTPROJ) {
-      // every LDS-DMA piece of this wave has landed (the 48 residual loads behind them may still be in flight); then everybody's
-      asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
+      // every LDS-DMA piece of this wave has landed; then everybody's.  The residual rows are requested BEHIND this point (and behind the first
+      // weight fragments): issued in front of it, their 50 MB (chip-wide, from HBM) delayed the 25 MB of attention output every workgroup waits for
+      if constexpr (CS_P4_ABL & 32768) asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       P4_STAMP(1);
@@ -151,6 +156,8 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
       };
       sfor<PD>([&](auto K_) { wload(K_); });
       bload(IC<0>{});
+      CS_SB();
+      if constexpr (!(CS_P4_ABL & 32768)) load_xt();
       CS_SB();
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       sfor<KS>([&](auto K_) {
@@ -321,13 +328,11 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
     const unsigned soff = t * (unsigned)IMG_TICK + wv * 12 * FRAG;
     sfor<12>([&](auto K_) { dma_w1(K_, soff, dst); });
   };
-  auto pack_xp = [&](const f32x16_t (&ha)[2]) {
-#pragma unroll
-    for (int ht = 0; ht < 2; ++ht)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xp[4 * (2 * ht + s) + q] = pack_h16x2(ha[ht][8 * s + 2 * q], ha[ht][8 * s + 2 * q + 1]);
+  // the two packed registers of GELU group g (of 8): xp[2 g], xp[2 g + 1] = values r0 .. r0 + 3 of tile g / 4, r0 = 8 ((g / 2) & 1) + 4 (g & 1)
+  auto pack_group = [&](auto G_, const f32x16_t (&ha)[2]) {
+    constexpr int g = decltype(G_)::value, ht = g / 4, r0 = 8 * ((g / 2) & 1) + 4 * (g & 1);
+    xp[2 * g] = pack_h16x2(ha[ht][r0], ha[ht][r0 + 1]);
+    xp[2 * g + 1] = pack_h16x2(ha[ht][r0 + 2], ha[ht][r0 + 3]);
   };
   // GELU block B (0..47) of the tick: group B / 6 = packed registers 2 G, 2 G + 1, block B % 6 of its six
   auto gelu_block = [&](auto B_, const f32x16_t (&ha)[2]) {
@@ -336,17 +341,17 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
     if constexpr (!(CS_P4_ABL & 1))
       pk_gelu_block<B % 6, BF>(pg, xp[2 * G], xp[2 * G + 1], kk_, ha[ht][r0], ha[ht][r0 + 1], ha[ht][r0 + 2], ha[ht][r0 + 3]);
   };
-  // One iteration = 98 MFMA gaps and ONE barrier.  Iteration t:
-  //   F1  fc1 of tick t + 1 into hn (W1 from ring slot (t + 1) & 1: one LDS read per MFMA, eight ahead; the bias through one more k-step per
-  //       tile) -- gaps 0..49;
-  //   G   GELU of tick t (its pre-activations `ha`, packed to halves first) -- one block of the packed-half GELU every second gap of the whole
-  //       iteration; the activated slice of this wave's row block leaves as 4 B fragments into hand-off buffer t & 1 at the end;
-  //   F2  fc2 of tick t - 1 from buffer (t - 1) & 1 (written before the previous barrier): k-step kk, row block rb, column tile ct; W2 fragments
-  //       in registers, B fragment (kk, rb) from LDS once per 3 MFMAs -- gaps 50..97;
-  //   fetches: W1 of tick t + 2 into ring slot t & 1 (free since the previous barrier; 12 LDS-DMA pieces in the F1 phase, so they have half an
-  //       iteration to land before the closing wait), W2 of tick t into the registers F2 has just used (global loads, consumed an iteration on).
-  //       The closing wait leaves exactly those 12 register loads in flight (vmcnt counts in issue order).  (All 24 fetches in the F1 phase:
-  //       measured slower, 4 890 against 4 475 cycles per iteration -- that phase already carries the fragment reads.)
+  // One iteration = 98 MFMA gaps and ONE barrier.  Iteration t, in this order:
+  //   F2  fc2 of tick t - 1 from hand-off buffer (t - 1) & 1 (written before the previous barrier): k-step kk, row block rb, column tile ct; W2
+  //       fragments in registers, B fragment (kk, rb) from LDS once per 3 MFMAs -- 48 gaps.  First, because it needs nothing but three LDS reads
+  //       behind the barrier: the packing of the previous tick's pre-activations, the fc1 bias fragments and the first W1 fragment reads all
+  //       happen under its MFMAs.  It also carries every fetch of the iteration: W1 of tick t + 2 into ring slot t & 1 (free since the previous
+  //       barrier; 12 LDS-DMA pieces) and W2 of tick t into the registers just used (12 loads, consumed an iteration on) -- all issued in the
+  //       first half, so the closing vmcnt(0) finds them landed;
+  //   F1  fc1 of tick t + 1 into hn (W1 from ring slot (t + 1) & 1: one LDS read per MFMA, WPN ahead; the bias through one more k-step per
+  //       tile) -- 50 gaps;
+  //   G   GELU of tick t (its pre-activations `ha`, packed to halves at the start) -- one block of the packed-half GELU every second gap of the
+  //       whole iteration; the activated slice of this wave's row block leaves as 4 B fragments into hand-off buffer t & 1 at the end.
   auto tick = [&](auto F1_, auto G_, auto F2_, f32x16_t (&hn)[2], const f32x16_t (&ha)[2], int t) {
     constexpr bool F1 = decltype(F1_)::value, G = decltype(G_)::value, F2 = decltype(F2_)::value;
     const unsigned cur = ring + ((t + 1) & 1) * (48 * FRAG);
@@ -356,65 +361,82 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
     const unsigned w2s = (unsigned)t * (unsigned)IMG_TICK + (unsigned)IMG_W1 + wv * 12 * FRAG;
     constexpr int HBN = BF ? 3 : 4;  // (bf16 form: one register quad less, see WPN)
     h16x8_t hb[HBN];  // rolling pool of B fragments of fc2: fragment g = 4 kk + rb lives in hb[g % HBN], HBN - 1 groups ahead
-    if constexpr (G) pack_xp(ha);
-    if constexpr (F1) {
-      // fc1 bias through the matrix pipe: one more k-step per tile whose weight fragment carries b1 (split hi + lo: exact to 2^-22 / 2^-16) in
-      // contraction slots 0 and 1 and whose activation fragment is 1 there -- the accumulators start from the inline constant 0, nothing is
-      // written into them by the vector unit (the MFMA results live in accumulator registers: 32 v_accvgpr_write per tick otherwise)
-      float bv[2];
-      asm volatile("ds_read_b32 %0, %1" : "=&v"(bv[0]) : "v"(b1g + (t + 1) * (HT * 4)) : "memory");
-      asm volatile("ds_read_b32 %0, %1 offset:128" : "=&v"(bv[1]) : "v"(b1g + (t + 1) * (HT * 4)) : "memory");
-      sfor<WPN>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(cur, wp[decltype(F_)::value]); });
-      CS_LGKM(WPN);
+    float bv[2];      // fc1 bias of this lane's MFMA row, tiles 0 / 1 of tick t + 1
+    constexpr int PRE = F1 ? WPN : 0;   // LDS reads of the F1 phase issued behind the last fc2 fragment read
+    unsigned bfr0[2]; // ... as register 0 of the bias k-step's weight fragment (hi | lo << 16 in lane half 0)
+    unsigned b1a = b1g + (t + 1) * (HT * 4);
+    auto bias_reads = [&]() {
+      asm volatile("ds_read_b32 %0, %1" : "=&v"(bv[0]) : "v"(b1a) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:128" : "=&v"(bv[1]) : "v"(b1a) : "memory");
+    };
+    auto bias_prep = [&]() {
 #pragma unroll
       for (int ht = 0; ht < 2; ++ht) {
         const unsigned hi = BF ? (unsigned)f2bf(bv[ht]) : (unsigned)f2h(bv[ht]);
         const float rest = bv[ht] - (BF ? bf2f((h16_t)hi) : h2f((h16_t)hi));
         const unsigned lo = BF ? (unsigned)f2bf(rest) : (unsigned)f2h(rest);
-        const unsigned r0 = hm == 0 ? (hi | (lo << 16)) : 0u;
-        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        hn[ht] = mfma_32x32x16<BF>(__builtin_bit_cast(h16x8_t, u32x4_t{r0, 0u, 0u, 0u}), ones, zero);
+        bfr0[ht] = hm == 0 ? (hi | (lo << 16)) : 0u;
       }
-    }
-    sfor<48>([&](auto M_) {
-      constexpr int M = decltype(M_)::value;
-      if constexpr (F1) {
-        // consumption order: the two hidden tiles alternate; fragment M of the tick's W1 slice (in this order in the image) = tile ht, k-step ks.
-        // Fragment M is complete when at most (the LDS operations issued behind it) are outstanding: WPN - 1 reads in the steady state; at the
-        // tail fewer, plus the first three fc2 fragments, which are read behind fragment 47
-        constexpr int ht = M % 2, ks = M / 2;
-        constexpr int BEHIND = (M + WPN <= 48) ? WPN - 1 : 47 - M + (F2 ? HBN - 1 : 0);
-        if constexpr (!(CS_P4_ABL & 8)) CS_LGKM(BEHIND);
-        hn[ht] = mfma_32x32x16<BF>(wp[M % WPN], xf[ks], hn[ht]);
-        if constexpr (M + WPN < 48 && !(CS_P4_ABL & 2)) lds_read1<(M + WPN) * FRAG>(cur, wp[M % WPN]);
-        if constexpr (M == 47 - WPN && F2) sfor<HBN - 1>([&](auto G_) { constexpr int Gi = decltype(G_)::value; lds_read1<Gi * FRAG>(hr, hb[Gi]); });
-        if constexpr (M % 4 == 1 && !(CS_P4_ABL & 16)) {
-          dma_w1(IC<M / 4>{}, w1s, w1d);
-        }
-      }
-
-      if constexpr (G && M % 2 == 0) gelu_block(IC<M / 2>{}, ha);
-      CS_SB();
-    });
-    if constexpr (F2 && !F1) sfor<HBN - 1>([&](auto G_) { constexpr int Gi = decltype(G_)::value; lds_read1<Gi * FRAG>(hr, hb[Gi]); });
+    };
+    auto f1_first_reads = [&]() { sfor<WPN>([&](auto F_) { lds_read1<decltype(F_)::value * FRAG>(cur, wp[decltype(F_)::value]); }); };
+    // the bias reads lead the iteration's LDS queue (older than every fragment read: the first counted wait retires them)
+    if constexpr (F1) bias_reads();
+    if constexpr (F2) sfor<HBN - 1>([&](auto G_) { constexpr int Gi = decltype(G_)::value; lds_read1<Gi * FRAG>(hr, hb[Gi]); });
+    if constexpr (G) pack_group(IC<0>{}, ha);
+    // ---- F2 phase (with the fetches and GELU blocks 0..23) ----
     sfor<16>([&](auto G_) {
       constexpr int Gi = decltype(G_)::value;
       constexpr int kk = Gi / 4, rb = Gi % 4;
       if constexpr (F2) {
         if constexpr (Gi + HBN - 1 < 16 && !(CS_P4_ABL & 2)) lds_read1<(Gi + HBN - 1) * FRAG>(hr, hb[(Gi + HBN - 1) % HBN]);
-        constexpr int BEHIND = (Gi + HBN - 1 < 16) ? HBN - 1 : 15 - Gi;
+        if constexpr (Gi + HBN - 1 == 15 && F1) f1_first_reads();   // behind the last fc2 fragment read
+        constexpr int BEHIND = (Gi + HBN - 1 < 16) ? HBN - 1 + (Gi + HBN - 1 == 15 ? PRE : 0) : 15 - Gi + PRE;
         if constexpr (!(CS_P4_ABL & 8)) CS_LGKM(BEHIND);
       }
       sfor<3>([&](auto C_) {
         constexpr int ct = decltype(C_)::value;
         constexpr int M2 = Gi * 3 + ct;
         if constexpr (F2) acc[rb][ct] = mfma_32x32x16<BF>(w2r[kk * 3 + ct], hb[Gi % HBN], acc[rb][ct]);
-        // behind the last use of this weight fragment: refill it with tick t's (consumed by the fc2 phase of the next iteration; iteration 0,
-        // which has no fc2 phase of its own, fetches tick 0's here as well)
-        if constexpr ((F2 || G) && rb == 3 && !(CS_P4_ABL & 16)) w2r[kk * 3 + ct] = __builtin_bit_cast(h16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_mlp, lm16 + ((kk * 3 + ct) & 3) * FRAG, w2s + ((kk * 3 + ct) & ~3) * FRAG, 0));
-        if constexpr (G && M2 % 2 == 0) gelu_block(IC<24 + M2 / 2>{}, ha);
+        if constexpr (F2 || G) {
+          // behind the last use of this weight fragment: refill it with tick t's (consumed by the fc2 phase of the next iteration)
+          if constexpr (rb == 3 && !(CS_P4_ABL & 16))
+            w2r[kk * 3 + ct] = __builtin_bit_cast(h16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_mlp, lm16 + ((kk * 3 + ct) & 3) * FRAG, w2s + ((kk * 3 + ct) & ~3) * FRAG, 0));
+        }
+        if constexpr (F1 && rb != 3 && ct == 1 && !(CS_P4_ABL & 16)) dma_w1(IC<kk * 3 + rb>{}, w1s, w1d);   // 12 gaps: one W1 piece each
+        if constexpr (G && M2 % 2 == 0) gelu_block(IC<M2 / 2>{}, ha);
+        // the packing of groups 1..7 (before the fc1 phase overwrites the accumulators they are packed from) and the bias fragments: odd gaps
+        if constexpr (G && M2 % 4 == 1 && M2 / 4 >= 1 && M2 / 4 <= 7) pack_group(IC<M2 / 4>{}, ha);
+        // (only behind this phase's counted waits -- F2: in the prologue iteration, which has none, an early bias_prep would read the registers
+        //  before the LDS data has landed, and hipcc merges the later, correct one with it: common subexpressions of the same asm outputs)
+        if constexpr (F1 && F2 && M2 == 3) bias_prep();
         CS_SB();
       });
+    });
+    // ---- F1 phase (with GELU blocks 24..47) ----
+    if constexpr (F1) {
+      // fc1 bias through the matrix pipe: one more k-step per tile whose weight fragment carries b1 (split hi + lo: exact to 2^-22 / 2^-16) in
+      // contraction slots 0 and 1 and whose activation fragment is 1 there -- the accumulators start from the inline constant 0, nothing is
+      // written into them by the vector unit (the MFMA results live in accumulator registers: 32 v_accvgpr_write per tick otherwise)
+      if constexpr (!F2) { f1_first_reads(); CS_LGKM(WPN); bias_prep(); }
+#pragma unroll
+      for (int ht = 0; ht < 2; ++ht) {
+        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        hn[ht] = mfma_32x32x16<BF>(__builtin_bit_cast(h16x8_t, u32x4_t{bfr0[ht], 0u, 0u, 0u}), ones, zero);
+      }
+    }
+    sfor<48>([&](auto M_) {
+      constexpr int M = decltype(M_)::value;
+      if constexpr (F1) {
+        // consumption order: the two hidden tiles alternate; fragment M of the tick's W1 slice (in this order in the image) = tile ht, k-step ks.
+        // Fragment M is complete when at most (the LDS reads issued behind it) are outstanding: WPN - 1 in the steady state, fewer at the tail
+        constexpr int ht = M % 2, ks = M / 2;
+        constexpr int BEHIND = (M + WPN <= 48) ? WPN - 1 : 47 - M;
+        if constexpr (!(CS_P4_ABL & 8)) CS_LGKM(BEHIND);
+        hn[ht] = mfma_32x32x16<BF>(wp[M % WPN], xf[ks], hn[ht]);
+        if constexpr (M + WPN < 48 && !(CS_P4_ABL & 2)) lds_read1<(M + WPN) * FRAG>(cur, wp[M % WPN]);
+      }
+      if constexpr (G && M % 2 == 0) gelu_block(IC<24 + M / 2>{}, ha);
+      CS_SB();
     });
     if constexpr (G) {
       const unsigned a = hbw + (t & 1) * (16 * FRAG);
@@ -423,10 +445,8 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
         lds_write16<K * 4 * FRAG>(a, u32x4_t{xp[4 * K], xp[4 * K + 1], xp[4 * K + 2], xp[4 * K + 3]});
       });
     }
-    // everything but the 12 register loads of this iteration's fc2 phase has landed: the LDS-DMA pieces of the ring slot the next iteration
-    // reads, and (older) the previous iteration's register loads (vmcnt counts in issue order)
-    if constexpr (F2 || G) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // every fetch of the iteration was issued in its first half: the LDS-DMA pieces of the ring slot the next iteration reads have landed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     CS_SB();
