@@ -204,7 +204,10 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
   //      squared deviations), each: 48 values in the lane + the other half of the wave + the other three waves through LDS, summed in a fixed order ----
   float* red = reinterpret_cast<float*>(smem + L_RED);
   auto row_stats = [&](float (&mean)[4], float (&rstd)[4], int j, int h) {
-    float s[4];
+    // per wave: mean and sum of squared deviations of its 96 columns of each row (two passes in registers, no exchange); then ONE exchange of the
+    // four waves' (mean, M2) pairs and their exact combination  M2 = sum M2_w + 96 sum (mean_w - mean)^2  -- as accurate as the two-pass form
+    // over the whole row (no E[x^2] - mean^2 cancellation) at one barrier instead of three.  Fixed order: a row's result does not depend on
+    // where the row sits.
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       float t = 0.f;
@@ -212,34 +215,29 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
       for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; r += 4) t += (acc[rb][ct][r] + acc[rb][ct][r + 1]) + (acc[rb][ct][r + 2] + acc[rb][ct][r + 3]);
-      s[rb] = add_other_half(t);
-      if (h == 0) red[wv * ROWS + rb * 32 + j] = s[rb];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      const float* r0 = red + rb * 32 + j;
-      mean[rb] = ((r0[0] + r0[ROWS]) + (r0[2 * ROWS] + r0[3 * ROWS])) * (1.0f / PC);
-    }
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+      const float mw = add_other_half(t) * (1.0f / 96.0f);
       float q = 0.f;
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float d = acc[rb][ct][r] - mean[rb];
+          const float d = acc[rb][ct][r] - mw;
           q = fmaf(d, d, q);
         }
       q = add_other_half(q);
-      if (h == 0) red[4 * ROWS + wv * ROWS + rb * 32 + j] = q;
+      if (h == 0) { red[wv * ROWS + rb * 32 + j] = mw; red[4 * ROWS + wv * ROWS + rb * 32 + j] = q; }
     }
     __syncthreads();
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      const float* r0 = red + 4 * ROWS + rb * 32 + j;
-      const float q = (r0[0] + r0[ROWS]) + (r0[2 * ROWS] + r0[3 * ROWS]);
-      rstd[rb] = 1.0f / sqrtf(q * (1.0f / PC) + p.eps);
+      const float* r0 = red + rb * 32 + j;
+      const float m0 = r0[0], m1 = r0[ROWS], m2 = r0[2 * ROWS], m3 = r0[3 * ROWS];
+      const float m = ((m0 + m1) + (m2 + m3)) * 0.25f;
+      const float* q0 = r0 + 4 * ROWS;
+      const float d0 = m0 - m, d1 = m1 - m, d2 = m2 - m, d3 = m3 - m;
+      const float M2 = ((q0[0] + q0[ROWS]) + (q0[2 * ROWS] + q0[3 * ROWS])) + 96.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+      mean[rb] = m;
+      rstd[rb] = 1.0f / sqrtf(M2 * (1.0f / PC) + p.eps);
     }
     __syncthreads();  // (the scratch may be rewritten by the next call)
   };
@@ -481,7 +479,8 @@ __global__ __launch_bounds__(256) void cs_panel4_kernel(CsPanelParams p) {
     tick(T_{}, T_{}, T_{}, hB, hA, NTICK - 2);
     tick(F_{}, T_{}, T_{}, hA, hB, NTICK - 1);
   } else {
-    for (int t = 0; t < NTICK - 1; ++t) tick(T_{}, T_{}, T_{}, hA, hA, t);
+    tick(T_{}, T_{}, F_{}, hA, hA, 0);  // (no fc2 phase yet; the bf16 form runs the full body on zero operands instead: see above)
+    for (int t = 1; t < NTICK - 1; ++t) tick(T_{}, T_{}, T_{}, hA, hA, t);
     tick(F_{}, T_{}, T_{}, hA, hA, NTICK - 1);
   }
   tick(F_{}, F_{}, T_{}, hA, hA, NTICK);

@@ -610,3 +610,36 @@ def test_bad_inputs_raise():
         net(q, torch.zeros(1, 2, 3, 70, 70, device="cuda"), True, 8, False)   # head id out of range (8 heads)
     with pytest.raises(ValueError):
         net(torch.zeros(1, 3, 10, 70, device="cuda"), torch.zeros(1, 2, 3, 10, 70, device="cuda"), False, 0, False)  # < one patch
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_four_wave_panel_kernel_through_the_forward(golden_dir, dtype):
+    """The round-6 token-panel kernel (csrc/panel4.hip: 4 waves, one per SIMD; cs_debug_panel_impl(1), opt-in) through the whole forward at the
+    BASELINE cfg-2 shape (B = 1): item 0 against the reference's own golden g1 at the same bounds as the default path, the launch census shows
+    that it -- not the 8-wave kernel -- ran (12 layers x 2 chunks), the score map stays within the operand-rounding distance of the default
+    path's, and the forward repeats bit-identically."""
+    from crossscore_amd import _lib
+    lib = _lib.load()
+    g = np.load(os.path.join(golden_dir, "g1_vits_518_n5.npz"))
+    q, r = synth.make_inputs(int(g["B"]), int(g["N"]), int(g["H"]), int(g["W"]), int(g["seed"]))
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    net8, arch, sd = _net("facebook/dinov2-small", int(g["seed"]))
+    net8.operand_dtype = dtype
+    ref8 = net8(tq, tr, False, 0, False)["score_map_ref_cross"]
+    lib.cs_debug_panel_impl(1)
+    try:
+        net4, _, _ = _net("facebook/dinov2-small", int(g["seed"]))   # (a handle packs its panel images for the kernel selected at cs_finalize)
+        net4.operand_dtype = dtype
+        out = net4(tq, tr, False, 0, False)["score_map_ref_cross"]
+        torch.cuda.synchronize()
+        k = net4.forward_stats()["kernels"]
+        again = net4(tq, tr, False, 0, False)["score_map_ref_cross"]
+    finally:
+        lib.cs_debug_panel_impl(0)
+    assert k.get("panel4", 0) >= 12 and "panel" not in k, k
+    assert torch.equal(out, again)
+    mae_rows, mae_grid, dmean = _check_compact(g, out)
+    d = (out - ref8).abs()
+    print(f"panel4 forward ({dtype}): MAE(rows) vs golden {mae_rows:.2e}, vs the 8-wave kernel's forward mean {float(d.mean()):.2e} max {float(d.max()):.2e}")
+    assert mae_rows < (MAE_TOL if dtype == "bf16" else MAE_TARGET) and mae_grid < (MAE_TOL if dtype == "bf16" else MAE_TARGET)
+    assert net4.nonfinite_count() == 0
