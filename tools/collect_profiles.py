@@ -20,6 +20,12 @@ for src, dst in (("default_kernel_stats.csv", "kernel_stats.csv"), ("alone_kerne
         open(os.path.join(P, f"{tag}_{dst}"), "w").write("".join(l for l in open(os.path.join(O, src)) if keep in l))
     else:
         shutil.copy(os.path.join(O, src), os.path.join(P, f"{tag}_{dst}"))
+for src, dst, keep in (("panel4_ab.log", "panel4_ab.txt", "impl"), ("panel4_pmc.txt", "panel4_pmc.txt", ""), ("panel4_phases.txt", "panel4_phases.txt", "")):
+    if os.path.exists(os.path.join(O, src)):
+        open(os.path.join(P, f"{tag}_{dst}"), "w").write("".join(l for l in open(os.path.join(O, src)) if keep in l and "amdgpu.ids" not in l))
+import glob
+for f in glob.glob(os.path.join(O, "stats_panel4", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(P, f"{tag}_kernel_stats_panel4.csv"))
 for src, dst, cmd in (("alone_hbm_traffic.json", "hbm_traffic.json", "bench.py --no-cpu-baseline --no-eager --no-cfg4 --inflight 1 --lanes 1 --chunk 48 --steps 3 --warmup 1"),
                       ("alone_cfg4_hbm_traffic.json", "hbm_traffic_cfg4.json", "bench.py --workload cfg4 --no-cpu-baseline --no-eager --no-cfg4 --inflight 1 --lanes 1 --chunk 96 --steps 2 --warmup 1")):
     t = json.load(open(os.path.join(O, src)))
@@ -32,7 +38,7 @@ sys.path.insert(0, R)
 from crossscore_amd.build import EXTRA_FLAGS  # the flags the library is built with
 tmp = tempfile.mkdtemp(prefix="audit_")
 lines = [f"asm audit at {commit}: hipcc --offload-arch=gfx950 -O3 -S (crossscore_amd/build.py's flags per file) of the MFMA kernels (tools/asm_audit.py, tools/asm_audit_gl.py)"]
-for src in ("gemm256.hip", "panel.hip", "patch.hip", "attention.hip", "gemm.hip"):
+for src in ("gemm256.hip", "panel.hip", "panel4.hip", "patch.hip", "attention.hip", "gemm.hip"):
     out = os.path.join(tmp, src + ".s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + EXTRA_FLAGS.get(src, []) +
                           ["-S", "--cuda-device-only", "-o", out, os.path.join(R, "crossscore_amd", "csrc", src)], stderr=subprocess.DEVNULL)

@@ -28,6 +28,13 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY 
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_attn2 -- python3 $R/tools/attn_pmc.py > $O/pmc_attn2.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_k1 -- python3 $R/tools/panel_pmc.py > $O/pmc_k1.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_k2 -- python3 $R/tools/panel_pmc.py > $O/pmc_k2.log 2>&1 || exit 1
+# the four-wave token-panel kernel (csrc/panel4.hip, opt-in): alone (both kernels, one process, alternating), its SQ counters and its phase clocks
+cd $R && python3 tools/panel4_ab.py > $O/panel4_ab.log 2>&1 || exit 1
+cd /tmp && CS_PANEL_M=65760 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_panel4 -- python3 $R/tools/panel4_pmc.py > $O/stats_panel4.log 2>&1 || exit 1
+CS_PANEL_M=65760 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_p4a -- python3 $R/tools/panel4_pmc.py > $O/pmc_p4a.log 2>&1 || exit 1
+CS_PANEL_M=65760 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM --output-format csv -d $O/pmc_p4b -- python3 $R/tools/panel4_pmc.py > $O/pmc_p4b.log 2>&1 || exit 1
+cd $R && python3 tools/pmc_quick.py $O/pmc_p4a $O/pmc_p4b > $O/panel4_pmc.txt 2>&1 || exit 1
+cd $R && if [ -d tools/_var/p4stamp ]; then CS_VARIANT=p4stamp python3 tools/panel4_phases.py > $O/panel4_phases.txt 2>&1 || exit 1; fi
 echo "attention, panel and GEMM counters done"
 cd $R && python3 tools/summarise_attn_pmc.py $O/attn_pmc.json $O/pmc_attn1 $O/pmc_attn2 > /dev/null || exit 1
 cd $R && python3 tools/summarise_kernel_pmc.py $O/kernel_pmc.json $O/pmc_k1 $O/pmc_k2 > /dev/null || exit 1
