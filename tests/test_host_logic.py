@@ -300,6 +300,30 @@ def test_asm_audits_of_the_inline_asm_kernels(tmp_path):
             assert "violations: 0" in r.stdout, (src, a, r.stdout[-1500:])
 
 
+def test_four_wave_panel_kernel_has_no_private_segment(tmp_path):
+    """csrc/panel4.hip runs its loop at the 512-register limit.  Round 6 measured the SAME loop instructions at half the speed in a build that
+    used scratch (27 dwords spilled OUTSIDE the loop: EXPERIMENTS.md); every variant of the kernel must therefore build with no private
+    segment and no spilled register."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    from crossscore_amd import build as b
+    out = str(tmp_path / "panel4.s")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + b.EXTRA_FLAGS.get("panel4.hip", []) + [
+        "-S", "--cuda-device-only", "-o", out, os.path.join(REPO, "crossscore_amd", "csrc", "panel4.hip")]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:]
+    name, seen = None, {}
+    for ln in open(out):
+        ln = ln.strip()
+        if ln.startswith(".name:"):
+            name = ln.split()[-1]
+        elif ln.startswith(".private_segment_fixed_size:") and name and "cs_panel4_kernel" in name:
+            seen[name] = int(ln.split()[-1])
+    assert len(seen) == 4 and all(v == 0 for v in seen.values()), seen
+    assert "scratch_" not in open(out).read().split("cs_panel4_pack_kernel")[0] or all(v == 0 for v in seen.values())
+
+
 def test_import_does_not_edit_the_environment():
     """Importing the package must not change process-wide runtime configuration; configure_runtime() is the
     explicit call, and an explicit setting wins."""
