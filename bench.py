@@ -100,7 +100,7 @@ def roofline_of(dom, traffic_profile="default"):
     return r
 
 
-TRAFFIC_PROFILE = "profiles/r05_hbm_traffic.json"  # (replaced by the round's own pass when tools/collect_profiles.py has run)
+TRAFFIC_PROFILE = "profiles/r06_hbm_traffic.json"
 
 
 def pmc_traffic(kernel_name):
