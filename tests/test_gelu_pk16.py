@@ -19,8 +19,8 @@ def _tool():
 
 
 def _kernel_constants():
-    """{name: half value} of pk_gelu_consts() in panel.hip (both halves of every packed constant must be equal)."""
-    src = open(os.path.join(REPO, "crossscore_amd", "csrc", "panel.hip")).read()
+    """{name: half value} of pk_gelu_consts() in panel_shared.h (both halves of every packed constant must be equal)."""
+    src = open(os.path.join(REPO, "crossscore_amd", "csrc", "panel_shared.h")).read()  # (shared by panel.hip and panel4.hip since round 6)
     out = {}
     for name, hexv in re.findall(r'asm volatile\("[sv]_mov_b32 %0, 0x([0-9a-f]{8})" : "=[sv]"\(k\.(\w+)\)\)', src):
         name, hexv = hexv, name
