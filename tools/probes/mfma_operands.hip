@@ -196,6 +196,42 @@ template <int RANDOM> void run6(unsigned long long* cyc, const char* what) {
   double m = 0; for (int i = 0; i < 256; ++i) m += h[i]; m /= 256;
   printf("%-70s %.1f cycles per MFMA; %.1f us per launch -> %.2f GHz\n", what, m / (400 * 96.0), ms * 1e3 / 50, m / (ms * 1e3 / 50) / 1e3);
 }
+
+// k7: the same work as k6 on v_mfma_f32_16x16x32_f16: twice the MFMA instructions (4 accumulator registers each), the same fragment reads and
+// vector fillers per FLOP -- which shape does the chip run faster BY WALL on random operands (cdna_hip_programming.md rule 28)?
+#define MF16(acc, a, b) "v_mfma_f32_16x16x32_f16 a[" STR(acc) ":" STR(acc+3) "], v[" STR(a) ":" STR(a+3) "], v[" STR(b) ":" STR(b+3) "], a[" STR(acc) ":" STR(acc+3) "]\n\t"
+// one "32x32x16 gap" = two 16x16x32 MFMAs + the gap's ds_read + 4 VALU + wait
+#define H16(acc, a, b) MF16(acc, a, b) "ds_read_b128 v[" STR(a) ":" STR(a+3) "], v202\n\t" MF16(acc+4, a, b+4) FILLV "s_waitcnt lgkmcnt(7)\n\t"
+#define ROW16(b0) H16(0,0,b0) H16(8,4,b0) H16(16,8,b0+8) H16(24,12,b0+8) H16(0,16,b0+16) H16(8,20,b0+16) H16(16,24,b0+24) H16(24,28,b0+24)
+#define G16(acc, a, b) MF16(acc, a, b) MF16(acc+4, a, b+4)
+#define GRP16(a0, b) G16(32,a0,b) G16(40,a0+4,b) G16(48,a0+8,b) G16(56,a0,b+8) G16(64,a0+4,b+8) G16(72,a0+8,b+8) G16(80,a0,b+16) G16(88,a0+4,b+16) G16(96,a0+8,b+16) G16(104,a0,b+24) G16(112,a0+4,b+24) G16(120,a0+8,b+24)
+template <int RANDOM>
+__global__ __launch_bounds__(256) void k7(unsigned long long* cyc, int iters) {
+  __shared__ unsigned lds[2048];
+  unsigned long long t0, t1;
+  for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = RANDOM ? (((i + 1) * 2654435761u) & 0xbbffbbffu) : 0u;
+  __syncthreads();
+  asm volatile("v_mov_b32 v202, %0" :: "v"((unsigned)(size_t)lds + (threadIdx.x & 63) * 16) : "v202");
+  asm volatile(LD4(0, 0) LD4(16, 16) LD4(64, 32) LD4(80, 48) LD4(96, 64) LD4(112, 80) LD4(128, 96) LD4(144, 112) "ds_read_b64 v[200:201], v202 offset:128\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
+  for (int it = 0; it < iters; ++it) {
+    asm volatile(ROW16(64) ROW16(96) ROW16(128) ROW16(64) ROW16(96) ROW16(128) ::: "memory");
+    asm volatile(GRP16(0, 64) GRP16(12, 96) GRP16(0, 128) GRP16(12, 64) ::: "memory");
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+  asm volatile("" ::: "v0", "v31", "v64", "v159", "v200", "v201", "v202", "v255", "a0", "a255");
+}
+template <int RANDOM> void run7(unsigned long long* cyc, const char* what) {
+  for (int r = 0; r < 30; ++r) k7<RANDOM><<<256, 256>>>(cyc, 400);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0); for (int r = 0; r < 50; ++r) k7<RANDOM><<<256, 256>>>(cyc, 400); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+  double m = 0; for (int i = 0; i < 256; ++i) m += h[i]; m /= 256;
+  printf("%-70s %.1f cycles per 32x32x16-equivalent; %.1f us per launch -> %.2f GHz\n", what, m / (400 * 96.0), ms * 1e3 / 50, m / (ms * 1e3 / 50) / 1e3);
+}
 int main() {
   unsigned long long* cyc; hipMalloc(&cyc, 256 * 8);
   run<0>(cyc, "A cycles 8 quads, B cycles 24 quads (v64..), 2 accumulators");
@@ -224,5 +260,9 @@ int main() {
   run5<1>(cyc, "the same with accumulator reads between the two groups");
   run6<0>(cyc, "fc1 gaps (MFMA + ds_read + 4 VALU) + fc2 group, zero data");
   run6<1>(cyc, "fc1 gaps (MFMA + ds_read + 4 VALU) + fc2 group, random data");
+  run7<0>(cyc, "16x16x32: fc1 gaps + fc2 group, zero data");
+  run7<1>(cyc, "16x16x32: fc1 gaps + fc2 group, random data");
+  run6<1>(cyc, "32x32x16 again: fc1 gaps + fc2 group, random data");
+  run7<1>(cyc, "16x16x32 again: fc1 gaps + fc2 group, random data");
   return 0;
 }
