@@ -51,6 +51,7 @@ SYMBOLS = {
     "cs_profile_read_bytes": (_i, [_vp, _i, C.POINTER(C.c_double)]),
     "cs_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _f,
                         _vp, _vp, _i, _vp, _i, _vp, _f, _vp]),
+    "cs_op_head_score": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "cs_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "cs_op_attention_weights": (_i, [_vp, _vp, _i, _i, _ll, _ll, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "cs_op_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),

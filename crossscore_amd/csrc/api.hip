@@ -51,7 +51,6 @@ hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, 
 hipError_t cs_spin_launch(unsigned long long ticks, int blocks, int lds_bytes, hipStream_t st);
 constexpr float LOG2E = 1.4426950408889634f;
 hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int head, float* out, hipStream_t st);
-hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st);
 hipError_t cs_score_gray16_launch(const float* score, size_t n, int signed_range, uint16_t* out, hipStream_t stream);
 hipError_t cs_score_rgb_launch(const float* score, size_t n, float vmin, float vmax, const uint8_t* lut, uint8_t* out, hipStream_t stream);
 int cs_panel_supported(int C, int mlp_ratio);
@@ -226,6 +225,7 @@ struct Plan {
   float* pmean[CS_MAX_LANES];                            // per-patch channel means removed by im2col
   // decoder
   float *xq, *y, *lse; h16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
+  float* mean_part; unsigned* mean_cnt;  // the head launch's per-image mean (CsGemmParams::mean_*)
 };
 
 Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* base) {
@@ -274,6 +274,8 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
   p.dob = a.take<h16_t>(M * C);
   p.dhid = a.take<h16_t>(M * C);
   p.lse = a.take<float>((size_t)B * c.dec_heads * p.Np);
+  p.mean_part = a.take<float>(M * 4 * (size_t)cs_gemm_column_tiles(c.patch * c.patch));
+  p.mean_cnt = a.take<unsigned>((size_t)B);
   p.total = a.off;
   return p;
 }
@@ -808,6 +810,9 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   }
   Plan p = make_plan(h, B, N_plan, N_enc, H, W, h->ws);
   if (int r = ensure_tables(h, p.gh, p.gw, H == W, st)) return r;
+  // the head launch's arrival counters (per-image mean in the same launch) start from zero; its finisher waves leave them at zero again, but the
+  // workspace may have been carved differently by the previous call
+  if (mean_out && mode != 2) HIPCHK(hipMemsetAsync(p.mean_cnt, 0, (size_t)B * sizeof(unsigned), st));
   const int enc_dh = C / c.enc_heads, dec_dh = C / c.dec_heads;
   const int F = c.mlp_ratio * C;
   const int KV = 2 * C * c.dec_layers;
@@ -1163,6 +1168,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     {
       CsGemmParams g = gp(dhid, C, h->Wh2, C, M, P * P, C, h->bh2, score_out + (size_t)b0 * p.gh * P * p.gw * P, 4);
       g.Np = p.Np; g.gw = p.gw; g.P = P; g.act = c.act; g.powp = c.pow_p;
+      if (mean_out) { g.mean_part = p.mean_part + ro * 4 * (size_t)cs_gemm_column_tiles((int)(P * P)); g.mean_cnt = p.mean_cnt + b0; g.mean_out = mean_out + b0; }
       L.gemm(g, CS_EPI_HEAD_SCORE);
     }
     if (h->capture && !L.rc) {
@@ -1228,9 +1234,6 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   }
   Launcher L{h, st};
   if (!c.skip_finite_check) L.misc(cs_score_check_launch(score_out, (size_t)B * p.gh * P * p.gw * P, h->nonfinite, st), "score_check");
-  if (mean_out) {
-    L.begin(32, 0); L.misc(cs_score_mean_launch(score_out, B, p.gh * P * p.gw * P, mean_out, st), "score_mean"); L.end();
-  }
   return L.rc;
 }
 
@@ -1269,7 +1272,7 @@ int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_token
 // What the last forward-class call on this handle launched, and what it cost the host: `launches` = kernel launches (memcpy taps of capture
 // mode not counted), `host_ms` = wall time of the call on the calling thread (everything is enqueued, nothing waited for), `names` (optional,
 // `names_bytes` long) = "kernel=count kernel=count ..." by kernel: gemm256 / gemm128 (cs_gemm256_kernel / cs_gemm_kernel), attn<dh>, panel,
-// rowln, patch, im2col, ln1 / ln2 / ln (layernorm_kernel), cls, final_ln, score_check, score_mean, ...
+// rowln, patch, im2col, ln1 / ln2 / ln (layernorm_kernel), cls, final_ln, score_check, ...
 int cs_forward_stats(cs_handle h, int* launches, double* host_ms, char* names, size_t names_bytes) {
   if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
   int n = 0;
@@ -1430,6 +1433,17 @@ int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, in
   if (epi < 0 || epi > CS_EPI_RESID_F32_LN) return fail(CS_ERR_BAD_ARG, "gemm: unknown epilogue %d", epi);
   if (const char* e = cs_gemm_check(&g, epi)) return fail(CS_ERR_BAD_ARG, "%s", e);
   HIPCHK(cs_gemm_launch(&g, epi, (hipStream_t)stream));
+  return 0;
+}
+
+int cs_op_head_score(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int K, const float* bias, float* score, int Np, int gw, int P,
+                     int act, float powp, float* mean_part, unsigned* mean_cnt, float* mean_out, cs_stream stream) {
+  CsGemmParams g = gp(A, lda, W, ldw, M, P * P, K, bias, score, 4);
+  g.Np = Np; g.gw = gw; g.P = P; g.act = act; g.powp = powp;
+  g.mean_part = mean_part; g.mean_cnt = mean_cnt; g.mean_out = mean_out;
+  g.bf16 = g_op_bf16;
+  if (const char* e = cs_gemm_check(&g, CS_EPI_HEAD_SCORE)) return fail(CS_ERR_BAD_ARG, "%s", e);
+  HIPCHK(cs_gemm_launch(&g, CS_EPI_HEAD_SCORE, (hipStream_t)stream));
   return 0;
 }
 

@@ -162,6 +162,11 @@ struct CsGemmParams {
   int P;              // patch size (head)
   int act;            // 0 sigmoid, 1 tanh
   float powp;         // 1 -> identity
+  // CS_EPI_HEAD_SCORE: the per-image mean of the score map in the same launch (score_summariser.py:180-192); all three or none.
+  float* mean_part;     // [M][4 x column tiles] fp32 scratch: per patch row, the sum of one wave's columns (any contents on entry)
+  unsigned* mean_cnt;   // [M / Np] arrival counters, ZERO on entry; the wave that completes an image's count sums its partials in a fixed
+                        // order, writes the mean and puts the counter back to zero
+  float* mean_out;      // [M / Np] fp32
   // LayerNorm fold (see CS_EPI_LN_*): producer side (RESID_F32_LN, PATCH_F32) ...
   h16_t* out_f16;    // [rows][ldc] fp16 copy of the fp32 rows written (the next GEMM's A operand), or null
   float* stats_out;    // [rows][stats_sp][2] partial (sum, sumsq) per row: slot = column_tile*4 + wave, or null

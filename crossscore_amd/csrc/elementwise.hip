@@ -448,18 +448,6 @@ __global__ void spin_kernel(unsigned long long ticks) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
-// per-image mean of the score map (feeds the CSV writer, score_summariser.py:180-192): one block per image
-__global__ __launch_bounds__(256) void score_mean_kernel(const float* __restrict__ score, int n, float* __restrict__ out) {
-  __shared__ float part[4];
-  const float* s = score + (size_t)blockIdx.x * n;
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) acc += s[i];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1] + part[2] + part[3]) / (float)n;
-}
-
 // number of non-finite values of the score map, added to a device counter (cs_nonfinite_count): an fp16 operand that overflowed upstream
 // (|x| > 65504 -> inf -> NaN in the next LayerNorm / softmax) reaches every pixel of its image as NaN, so the output is where it shows
 __global__ __launch_bounds__(256) void score_check_kernel(const float* __restrict__ score, size_t n, unsigned* __restrict__ counter) {
@@ -627,9 +615,5 @@ hipError_t cs_spin_launch(unsigned long long ticks, int blocks, int lds_bytes, h
   return hipGetLastError();
 }
 
-hipError_t cs_score_mean_launch(const float* score, int B, int n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(score_mean_kernel, dim3(B), dim3(256), 0, st, score, n, out);
-  return hipGetLastError();
-}
 
 }  // extern "C"

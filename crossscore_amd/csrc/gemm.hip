@@ -69,6 +69,45 @@ __device__ __noinline__ float head_activation(float v, int act, float powp) {
   return y;
 }
 
+// ---- per-image mean of the score map inside the head launch (CsGemmParams::mean_*; score_summariser.py:180-192: score_map.mean(dim=[-1, -2])) ----
+// A patch row's P*P pixels are spread over the 4 lanes (lane >> 4) x the waves x the column tiles that hold its columns.  Each (wave, column tile)
+// leaves ONE partial per row in mean_part[row][sp]: its four lanes' sums added pairwise (l ^ 16, then l ^ 32: the same bits in all four lanes).
+// Nothing depends on where the row sits in a tile or the image in the batch, so an item's mean has the same bits alone and inside any batch.
+__device__ __forceinline__ void head_row_partial(float* mean_part, int m, float ps, int sp, int slot, int lane) {
+  ps += __shfl_xor(ps, 16, 64);
+  ps += __shfl_xor(ps, 32, 64);
+  if (lane < 16 && m >= 0) mean_part[(size_t)m * sp + slot] = ps;
+}
+// After a wave's eighth epilogue step of a tile: its partials of rows [r0, r1) are written.  Per image those rows belong to, the wave adds the
+// row count to the image's counter; the Np * sp-th row-slot to arrive makes its wave the image's finisher: lane l sums the partials of patch rows
+// l, l + 64, .. (a row's slots in ascending order), the lanes are added by a fixed xor tree, mean = sum / (Np * N).  Agent-scope fences on both
+// sides (the partials of other workgroups come through other XCDs' L2s).  The finisher zeroes the counter for the next launch.
+// (scalars, not the parameter block: a reference to it would put a copy of the whole block into a private segment)
+__device__ __noinline__ void head_mean_arrive(const float* mean_part, unsigned* mean_cnt, float* mean_out, int Np, int N, int r0, int r1, int sp, int lane) {
+  struct { const float* mean_part; unsigned* mean_cnt; float* mean_out; int Np, N; } p{mean_part, mean_cnt, mean_out, Np, N};
+  __threadfence();
+  for (int b = r0 / p.Np; b * p.Np < r1; ++b) {
+    const int lo = max(r0, b * p.Np), hi = min(r1, (b + 1) * p.Np);
+    unsigned old = 0;
+    if (lane == 0) old = atomicAdd(p.mean_cnt + b, (unsigned)(hi - lo));
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old + (unsigned)(hi - lo) != (unsigned)p.Np * (unsigned)sp) continue;
+    __threadfence();
+    float a = 0.f;
+    for (int r = lane; r < p.Np; r += 64) {
+      const float* q = p.mean_part + ((size_t)b * p.Np + r) * sp;
+      float t = q[0];
+      for (int k = 1; k < sp; ++k) t += q[k];
+      a += t;
+    }
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) {
+      p.mean_out[b] = a / ((float)p.Np * (float)p.N);
+      __hip_atomic_store(p.mean_cnt + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- wave-private LDS patch access by inline asm (the compiler must not treat it as aliasing the LDS-DMA ring) ----
 // (constant byte offsets go into the instruction's offset field: one address register per access group)
 template <int OFF = 0>
@@ -363,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
         const int gh = p.Np / p.gw;
         const int Ws = p.P * p.gw;
         float* dst = reinterpret_cast<float*>(p.out) + ((size_t)b * gh * p.P + (size_t)pi * p.P) * Ws + pj * p.P;
+        float ps = 0.f;  // this lane's part of the patch's pixel sum, columns in ascending order
 #pragma unroll
         for (int j = 0; j < NSUB; ++j) {
           const int n = ncol0 + j * 16 + (lane >> 4) * 4;
@@ -371,9 +411,17 @@ __global__ __launch_bounds__(256, 2) void cs_gemm_kernel(CsGemmParams p) {
           for (int r = 0; r < 4; ++r) {
             const int nn = n + r;
             const int py = nn / p.P, px = nn - py * p.P;
-            dst[(size_t)py * Ws + px] = head_activation(prv[I][j][r], p.act, p.powp);
+            const float y = head_activation(prv[I][j][r], p.act, p.powp);
+            dst[(size_t)py * Ws + px] = y;
+            ps += y;
           }
         }
+        if (p.mean_part) head_row_partial(p.mean_part, m, ps, 4 * tiles_n, (pn0 / BN) * 4 + wn, lane);
+      } else if (p.mean_part) {
+        head_row_partial(p.mean_part, -1, 0.f, 4 * tiles_n, 0, lane);  // (the cross-lane exchange is wave-wide)
+      }
+      if constexpr (I == 7) {
+        if (p.mean_part) head_mean_arrive(p.mean_part, p.mean_cnt, p.mean_out, p.Np, p.N, pm0, min(pm0 + BM, p.M), 4 * tiles_n, lane);
       }
       return -1;
     } else {
@@ -784,6 +832,9 @@ extern "C" const char* cs_gemm_check(const CsGemmParams* p, int epi) {
   if (epi == CS_EPI_PATCH_F32 && (!p->pos || p->Np <= 0 || p->M % p->Np)) return "gemm: bad patch epilogue params";
   if (epi == CS_EPI_HEAD_SCORE && (p->Np <= 0 || p->gw <= 0 || p->Np % p->gw || p->M % p->Np || p->N != p->P * p->P))
     return "gemm: bad head epilogue params";
+  if (epi == CS_EPI_HEAD_SCORE && (!p->mean_part != !p->mean_cnt || !p->mean_part != !p->mean_out))
+    return "gemm: the head's mean needs mean_part, mean_cnt and mean_out together";
+  if (epi != CS_EPI_HEAD_SCORE && (p->mean_part || p->mean_cnt || p->mean_out)) return "gemm: mean_* belong to the head epilogue";
   if ((long long)p->M * p->lda >= (1ll << 31) || (long long)p->N * p->ldw >= (1ll << 31)) return "gemm: operand too large for 32-bit offsets";
   return nullptr;
 }

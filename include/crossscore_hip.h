@@ -108,7 +108,8 @@ int cs_finalize(cs_handle h);
  *   score_out: (B, P*(H/P), P*(W/P)) fp32 device
  *   attn_out:  NULL, or (B, h, w, N, h, w) fp32 device = probabilities of head `head_id` of the LAST decoder
  *              layer's cross-attention (model/cross_reference.py:91-93)
- *   mean_out:  NULL, or (B) fp32 device = per-image mean of the score map (utils/io/score_summariser.py:180-192) */
+ *   mean_out:  NULL, or (B) fp32 device = per-image mean of the score map (utils/io/score_summariser.py:180-192), formed inside the head's
+ *              launch (no pass over the map); an item's mean has the same bits alone and at any position of any batch */
 int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N, int H, int W, float* score_out,
                float* attn_out, int head_id, float* mean_out, cs_stream stream);
 /* Reference-feature cache.  In predict the N references of every query are drawn from one finite
@@ -181,6 +182,12 @@ int cs_op_gemm(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, in
                /* LayerNorm fold (CsEpilogue 7-9): producer outputs, then consumer inputs; NULL / 0 when unused */
                uint16_t* out_f16, float* stats_out, int stats_sp, const float* ln_part, int ln_sp, const float* col_s,
                float ln_eps, cs_stream stream);
+/* The head's last linear with its epilogue (model/regression_layer.py:26-62 activation, utils/misc/image.py:8-21 jigsaw) and, when the three
+ * mean_* pointers are given, the per-image mean of the score map from the SAME launch (utils/io/score_summariser.py:180-192
+ * score_map.mean(dim=[-1, -2])): score (M / Np, gh P, gw P) fp32; mean_part (M, 4 * ceil(P*P / 128)) fp32 scratch; mean_cnt (M / Np) uint32,
+ * ZERO on entry and zero again on completion; mean_out (M / Np) fp32.  An image's mean has the same bits at any position of any batch. */
+int cs_op_head_score(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int K, const float* bias, float* score, int Np, int gw, int P,
+                     int act, float powp, float* mean_part, unsigned* mean_cnt, float* mean_out, cs_stream stream);
 /* softmax(QK^T/sqrt(dh))V for `batch` x `heads`; strides in elements; lse may be NULL. */
 /* O = softmax(Q K^T / sqrt(dh)) V computed in the base-2 domain: p = 2^(q_scale * q.k - m).  The forward folds log2(e)/sqrt(dh) into its
  * Q projections and passes q_scale = 1 (Q arrives pre-multiplied); q_scale = 0 means log2(e)/sqrt(dh) applied here, to raw Q, at the

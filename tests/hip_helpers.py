@@ -33,6 +33,22 @@ def gemm(A, W, bias=None, epi=_lib.EPI_BIAS_F16, resid=None, out=None, pos=None,
     return out
 
 
+def head_score(A, W, bias, B, gh, gw, P, act=0, powp=1.0, want_mean=True, cnt=None):
+    """The head's last linear + activation + jigsaw and the per-image mean from the same launch -> (score (B, gh P, gw P), mean (B,), counters)."""
+    lib = _lib.load()
+    M, lda = A.shape
+    Np = gh * gw
+    score = torch.full((B, gh * P, gw * P), 777.0, dtype=torch.float32, device=A.device)
+    sp = 4 * ((P * P + 127) // 128 if (P * P) % 192 else (P * P) // 192)
+    part = torch.full((M, sp), float("nan"), dtype=torch.float32, device=A.device) if want_mean else None
+    if want_mean and cnt is None:
+        cnt = torch.zeros((B,), dtype=torch.int32, device=A.device)
+    mean = torch.full((B,), 777.0, dtype=torch.float32, device=A.device) if want_mean else None
+    _lib.check(lib.cs_op_head_score(_p(A), lda, _p(W), W.shape[1], M, lda, _p(bias), _p(score), Np, gw, P, act, powp, _p(part),
+                                    _p(cnt) if want_mean else None, _p(mean), _stream()))
+    return score, mean, cnt
+
+
 def ln_finalize(part, Cc, eps=1e-6):
     """(M, sp, 2) partial sums of the 256-tile GEMM's residual epilogue -> (ceil(M / 256) * 256, 1, 2) finalised (mean, rstd) rows."""
     lib = _lib.load()

@@ -438,13 +438,18 @@ def test_batch8_vits_matches_oracle_per_item_and_is_batch_invariant():
     net, arch, sd = _net("facebook/dinov2-small", 1)
     q, r = synth.make_inputs(8, 5, 518, 518, 1)
     tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
-    full = net(tq, tr, False, 0, False)["score_map_ref_cross"]
+    both = net(tq, tr, False, 0, False, return_mean=True)
+    full, full_mean = both["score_map_ref_cross"], both["score_mean_ref_cross"]
     part = net(tq[2:4], tr[2:4], False, 0, False)["score_map_ref_cross"]
     torch.cuda.synchronize()
     assert torch.equal(full[2:4], part)
+    assert torch.equal(full, net(tq, tr, False, 0, False)["score_map_ref_cross"])  # asking for the means does not change the map
+    assert (full_mean.double() - full.double().mean(dim=(-1, -2))).abs().max() < 2e-6
     for i in range(8):  # EVERY item alone (a one-item shard: other chunking, other panel / tile boundaries) gives the same bits
-        alone = net(tq[i:i + 1], tr[i:i + 1], False, 0, False)["score_map_ref_cross"]
-        assert torch.equal(full[i:i + 1], alone), i
+        alone = net(tq[i:i + 1], tr[i:i + 1], False, 0, False, return_mean=True)
+        assert torch.equal(full[i:i + 1], alone["score_map_ref_cross"]), i
+        # ... and so does its mean, which the head launch forms from per-patch-row partials in an order fixed inside the image
+        assert torch.equal(full_mean[i:i + 1], alone["score_mean_ref_cross"]), i
     for i in (0, 3, 7):  # first, middle and last item of the batch against the fp32 oracle
         ref = _oracle(arch, sd, q[i:i + 1], r[i:i + 1])["score_map_ref_cross"]
         mae, mx = _compare(full[i:i + 1], ref)
@@ -507,8 +512,9 @@ def test_reference_token_cache_is_bit_identical():
     tok = net.encode_references(pool)
     assert tok.shape == (5, 5 * 7, arch.hidden) and tok.dtype == torch.float16
     idx = torch.tensor([[0, 1], [2, 3], [1, 4]], device="cuda")
-    cached = net.forward_cached(tq, tok[idx], True, 5)
+    cached = net.forward_cached(tq, tok[idx], True, 5, return_mean=True)
     torch.cuda.synchronize()
+    assert torch.equal(cached["score_mean_ref_cross"], net(tq, tr, False, 0, False, return_mean=True)["score_mean_ref_cross"])
     assert torch.equal(cached["score_map_ref_cross"], full["score_map_ref_cross"])
     assert torch.equal(cached["attn_weights_map_ref_cross"], full["attn_weights_map_ref_cross"])
 

@@ -523,6 +523,38 @@ def test_attention_dh96_long_keys():
     assert (lse * math.log(2.0) - lse_ref).abs().max() < 5e-4
 
 
+@pytest.mark.parametrize("gh,gw,B", [(5, 6, 3), (37, 37, 8), (1, 1, 5), (16, 9, 2)])
+def test_head_score_mean_from_the_same_launch(gh, gw, B):
+    """score_summariser.py:180-192: score_map.mean(dim=[-1, -2]).  The head launch leaves it (CsGemmParams::mean_*): the score map is the one the
+    launch writes without the mean, the mean is the fp64 mean of that map to fp32 rounding, an image's mean has the same bits wherever the image
+    sits in the batch (row tiles of 128 straddle images: 30 / 1369 / 1 / 144 patch rows per image), alone or not, launch after launch (the
+    finisher waves put the arrival counters back to zero), and a launch that finds a counter not at zero is what the contract says it is: wrong."""
+    P, Cc = 14, 384
+    Np = gh * gw
+    g = _rng(90 + gh)
+    one = g.standard_normal((Np, Cc), dtype=np.float32)
+    rows = np.concatenate([one if b in (0, B - 1) else g.standard_normal((Np, Cc), dtype=np.float32) for b in range(B)])
+    A = _bf(_t(rows))
+    W = _bf(_t(g.standard_normal((P * P, Cc), dtype=np.float32) / math.sqrt(Cc)))
+    b = _t(g.standard_normal((P * P,), dtype=np.float32))
+    plain, _, _ = hh.head_score(A, W, b, B, gh, gw, P, want_mean=False)
+    score, mean, cnt = hh.head_score(A, W, b, B, gh, gw, P)
+    torch.cuda.synchronize()
+    assert torch.equal(score, plain)
+    ref = score.double().mean(dim=(-1, -2))
+    err = float((mean.double() - ref).abs().max())
+    print(f"head mean {gh}x{gw} B={B}: max |mean - fp64 mean of the map| = {err:.2e}")
+    assert err < 2e-7 * max(1.0, math.sqrt(Np * P * P) / 64)
+    assert int(cnt.abs().sum()) == 0
+    assert mean[0].item() == mean[B - 1].item()           # the same image first and last in the batch
+    solo, smean, _ = hh.head_score(A[:Np].contiguous(), W, b, 1, gh, gw, P)
+    assert torch.equal(solo[0], score[0]) and smean[0].item() == mean[0].item()
+    for _ in range(3):                                     # the same counters again
+        _, again, _ = hh.head_score(A, W, b, B, gh, gw, P, cnt=cnt)
+        assert torch.equal(again, mean)
+    assert int(cnt.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("act,powp", [(0, 1.0), (0, 2.0), (0, 0.5), (1, 1.0)])
 def test_gemm_head_score_jigsaw(act, powp):
     """sigmoid/tanh (+pow) + jigsaw store (regression_layer.py:26-62, utils/misc/image.py:8-21)."""
