@@ -26,8 +26,15 @@ class CsConfig(C.Structure):
     ]
 
 
+class CsU8Image(C.Structure):
+    """cs_u8_image: one decoded uint8 HWC image on the device and its resize / crop geometry (cs_forward_u8)."""
+    _fields_ = [("data", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("row_bytes", C.c_int), ("rs_h", C.c_int), ("rs_w", C.c_int),
+                ("crop_y", C.c_int), ("crop_x", C.c_int)]
+
+
 # every symbol include/crossscore_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+_fp = C.POINTER(C.c_float)
 SYMBOLS = {
     "cs_create": (_vp, [C.POINTER(CsConfig)]),
     "cs_destroy": (None, [_vp]),
@@ -40,6 +47,10 @@ SYMBOLS = {
     "cs_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "cs_encode_references": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "cs_forward_cached": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "cs_forward_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _fp, _fp, _vp, _vp, _i, _vp, _vp]),
+    "cs_encode_references_u8": (_i, [_vp, _vp, _i, _i, _i, _fp, _fp, _vp, _vp]),
+    "cs_forward_cached_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _fp, _fp, _vp, _vp, _i, _vp, _vp]),
+    "cs_u8_input_supported": (_i, [_vp, _vp, _i, _i]),
     "cs_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "cs_nonfinite_count": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "cs_forward_stats": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_char_p, _sz]),
@@ -59,6 +70,7 @@ SYMBOLS = {
     "cs_op_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cs_op_patch_embed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cs_op_patch_embed_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cs_op_patch_embed_fused_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "cs_debug_patch_fused_enable": (None, [_i]),
     "cs_set_lanes": (_i, [_vp, _i]),
     "cs_redraw_lane_streams": (_i, [_vp]),

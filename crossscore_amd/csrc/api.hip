@@ -20,6 +20,10 @@
 size_t cs_patch_pack_elems(int C);
 hipError_t cs_patch_pack_launch(const float* w, int C, h16_t* out, int bf, hipStream_t st);
 int cs_patch_fused_supported(int H, int W, int P, int C);
+hipError_t cs_patch_fused_u8_launch(const CsU8Desc* descs, int nq, int N, int img0, int I, int H, int W, int C, int row_span, const float* mean3,
+                                    const float* std3, const h16_t* wfrag, const float* bias, const float* pos, const float* wsum, float* x, int bf,
+                                    hipStream_t st);
+int cs_patch_u8_runs(int W, int row_span);
 hipError_t cs_patch_fused_launch(const float* xq, const float* xr, int N, int img0, int I, int H, int W, int C, const h16_t* wfrag,
                                  const float* bias, const float* pos, const float* wsum, float* x, int bf, hipStream_t st);
 
@@ -28,6 +32,7 @@ const char* cs_gemm_check(const CsGemmParams* p, int epi);
 hipError_t cs_gemm_launch(const CsGemmParams* p, int epi, hipStream_t stream);
 const char* cs_attn_check(const CsAttnParams* p, int dh, int batch);
 hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, hipStream_t stream);
+hipError_t cs_preprocess_tables(int in_h, int in_w, int rs_h, int rs_w, int crop_y, int gh, int P, CsU8Tables* out, int* row_span);
 hipError_t cs_im2col_launch(const float* q, const float* refs, int N, int img0, h16_t* out, int I, int H, int W, int P, int Kp,
                             float* pmean, int bf, hipStream_t st);
 hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipStream_t st);
@@ -154,6 +159,12 @@ struct cs_model {
   // lanes: internal streams that run independent image chunks / batch groups concurrently (forked from and joined to
   // the caller's stream with events), so one kernel's tail and the memory-bound stages overlap another's MFMA work
   hipStream_t lane_st[CS_MAX_LANES] = {};
+  // one-pass input stage: pinned host copies of the per-image descriptors of the last U8_SLOTS forwards (the upload is asynchronous; a slot is
+  // reused only behind the event recorded after its copy)
+  static constexpr int U8_SLOTS = 4;
+  struct U8Slot { CsU8Desc* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+  U8Slot u8_slot[U8_SLOTS];
+  int u8_next = 0;
   std::vector<hipStream_t> lane_st_old;  // given back by cs_redraw_lane_streams; destroyed once the next forward has drawn their replacements
   int lanes_now = 0;  // cs_set_lanes: lanes of the next forwards (0 = as configured)
   hipStream_t last_stream = nullptr; hipEvent_t ev_done = nullptr;  // ordering of calls that arrive on different streams
@@ -226,6 +237,7 @@ struct Plan {
   // decoder
   float *xq, *y, *lse; h16_t *q_bf, *mem_bf, *kv, *dqkv, *dq, *dob, *dhid;
   float* mean_part; unsigned* mean_cnt;  // the head launch's per-image mean (CsGemmParams::mean_*)
+  CsU8Desc* u8desc;                      // one-pass input stage: B query descriptors, then B * N_enc reference descriptors
 };
 
 Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* base) {
@@ -276,6 +288,7 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
   p.lse = a.take<float>((size_t)B * c.dec_heads * p.Np);
   p.mean_part = a.take<float>(M * 4 * (size_t)cs_gemm_column_tiles(c.patch * c.patch));
   p.mean_cnt = a.take<unsigned>((size_t)B);
+  p.u8desc = a.take<CsU8Desc>((size_t)p.I);
   p.total = a.off;
   return p;
 }
@@ -508,6 +521,7 @@ void cs_destroy(cs_handle h) {
   for (hipStream_t o : h->lane_st_old) hipStreamDestroy(o);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->nonfinite) hipFree(h->nonfinite);
+  for (auto& u : h->u8_slot) { if (u.host) hipHostFree(u.host); if (u.ev) hipEventDestroy(u.ev); }
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (auto& kv : h->taps) if (kv.second.d) hipFree(kv.second.d);
   delete h;
@@ -772,15 +786,21 @@ static int streams_overlap(hipStream_t a, hipStream_t b, bool* yes) {
 
 // mode 0: full forward (query + reference images); mode 1: query images + cached reference tokens (`ref_tokens`, fp16
 // [B][N][Np][C]); mode 2: encode `B` images as references into `tokens_out` (fp16 [B][Np][C]), no decoder.
+// the images of a forward as decoded uint8 (cs_forward_u8 and its siblings): host arrays of cs_u8_image
+struct U8In { const cs_u8_image* query; const cs_u8_image* refs; const float* mean3; const float* std3; };
+
 static int forward_body(cs_handle h, int mode, const float* query, const float* refs, const h16_t* ref_tokens, h16_t* tokens_out,
                         int B, int N, int H, int W, float* score_out, float* attn_out, int head_id, float* mean_out,
-                        cs_stream stream) {
+                        cs_stream stream, const U8In* u8 = nullptr) {
   if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
   if (!h->finalized) return fail(CS_ERR_STATE, "cs_forward before cs_finalize");
   const cs_config& c = h->cfg;
-  if (mode == 0 && (!query || !refs || !score_out)) return fail(CS_ERR_BAD_ARG, "null tensor (ref_cross_imgs is required when do_reference_cross)");
-  if (mode == 1 && (!query || !ref_tokens || !score_out)) return fail(CS_ERR_BAD_ARG, "null tensor");
-  if (mode == 2 && (!query || !tokens_out)) return fail(CS_ERR_BAD_ARG, "null tensor");
+  const bool have_q = u8 ? u8->query != nullptr : query != nullptr, have_r = u8 ? u8->refs != nullptr : refs != nullptr;
+  if (mode == 0 && (!have_q || !have_r || !score_out)) return fail(CS_ERR_BAD_ARG, "null tensor (ref_cross_imgs is required when do_reference_cross)");
+  if (mode == 1 && (!have_q || !ref_tokens || !score_out)) return fail(CS_ERR_BAD_ARG, "null tensor");
+  if (mode == 2 && (!have_q || !tokens_out)) return fail(CS_ERR_BAD_ARG, "null tensor");
+  if (u8 && (!u8->mean3 || !u8->std3 || !(u8->std3[0] > 0.f) || !(u8->std3[1] > 0.f) || !(u8->std3[2] > 0.f)))
+    return fail(CS_ERR_BAD_ARG, "uint8 input: mean / std missing or std not positive");
   if (B <= 0 || (mode != 2 && N <= 0)) return fail(CS_ERR_BAD_ARG, "empty batch or no reference views");
   if (H < c.patch || W < c.patch) return fail(CS_ERR_BAD_ARG, "image smaller than one patch");
   if (attn_out && (head_id < 0 || head_id >= c.dec_heads)) return fail(CS_ERR_BAD_ARG, "need_attn_weights_head_id %d out of range", head_id);
@@ -813,6 +833,40 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
   // the head launch's arrival counters (per-image mean in the same launch) start from zero; its finisher waves leave them at zero again, but the
   // workspace may have been carved differently by the previous call
   if (mean_out && mode != 2) HIPCHK(hipMemsetAsync(p.mean_cnt, 0, (size_t)B * sizeof(unsigned), st));
+  // ---- one-pass input stage: per-image descriptors (filter tables of the image's resize geometry, crop corner) -> workspace ----
+  int u8_span = 0;
+  if (u8) {
+    if (h->lnfold || !h->Wpatch_frag || !cs_patch_fused_supported(H, W, P, C))
+      return fail(CS_ERR_UNSUPPORTED, "uint8 input needs the one-launch patch embedding (14-pixel patches, hidden a multiple of 384, LayerNorm fold off)");
+    const int n_desc = p.I;  // B + B * N_enc
+    cs_model::U8Slot& sl = h->u8_slot[h->u8_next];
+    h->u8_next = (h->u8_next + 1) % cs_model::U8_SLOTS;
+    if (sl.used) HIPCHK(hipEventSynchronize(sl.ev));  // the copy of four forwards ago: long done
+    if (sl.cap < (size_t)n_desc) {
+      if (sl.host) HIPCHK(hipHostFree(sl.host));
+      sl.host = nullptr; sl.cap = 0;
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sl.host), (size_t)n_desc * sizeof(CsU8Desc), hipHostMallocDefault));
+      sl.cap = (size_t)n_desc;
+    }
+    if (!sl.ev) HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    for (int i = 0; i < n_desc; ++i) {
+      const cs_u8_image& im = i < B ? u8->query[i] : u8->refs[i - B];
+      CsU8Desc d{};
+      if (im.h <= 0 || im.w <= 0 || im.rs_h <= 0 || im.rs_w <= 0 || im.row_bytes < 3 * im.w || im.crop_y < 0 || im.crop_x < 0 ||
+          im.crop_y + H > im.rs_h || im.crop_x + W > im.rs_w)
+        return fail(CS_ERR_BAD_ARG, "uint8 input %d: bad sizes (the %d x %d window must lie inside the resized image %d x %d)", i, H, W, im.rs_h, im.rs_w);
+      int span = 0;
+      HIPCHK(cs_preprocess_tables(im.h, im.w, im.rs_h, im.rs_w, im.crop_y, p.gh, P, &d.t, &span));
+      d.data = im.data; d.row_bytes = im.row_bytes; d.crop_y = im.crop_y; d.crop_x = im.crop_x;
+      u8_span = std::max(u8_span, span);
+      sl.host[i] = d;
+    }
+    if (cs_patch_u8_runs(W, u8_span) <= 0)
+      return fail(CS_ERR_UNSUPPORTED, "uint8 input: a patch row reaches %d source rows, more than the one-pass form holds; use cs_op_preprocess_u8 + cs_forward", u8_span);
+    HIPCHK(hipMemcpyAsync(p.u8desc, sl.host, (size_t)n_desc * sizeof(CsU8Desc), hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(sl.ev, st));
+    sl.used = true;
+  }
   const int enc_dh = C / c.enc_heads, dec_dh = C / c.dec_heads;
   const int F = c.mlp_ratio * C;
   const int KV = 2 * C * c.dec_layers;
@@ -884,7 +938,13 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     L.begin(32, 0);
     L.misc(cs_cls_rows_launch(x, ic, p.T, C, h->cls, h->pos_tab, fold ? u : nullptr, fold ? stats : nullptr, h->ln_sp, bf, s), "cls");
     L.end();
-    if (!fold && h->Wpatch_frag && cs_patch_fused_supported(H, W, P, C)) {
+    if (u8) {
+      // the same launch fed from the decoded uint8 images (checked above: the one-launch form is available)
+      L.begin(41, 2.0 * ic * p.Np * C * 3.0 * P * P, 3.0 * ic * H * W + 4.0 * ic * p.Np * C + 4.0 * p.Np * C);
+      L.misc(cs_patch_fused_u8_launch(p.u8desc, B, N_enc, i0, ic, H, W, C, u8_span, u8->mean3, u8->std3, h->Wpatch_frag, h->bpatch, h->pos_tab, h->wsum,
+                                      x, bf, s), "patch_u8");
+      L.end();
+    } else if (!fold && h->Wpatch_frag && cs_patch_fused_supported(H, W, P, C)) {
       // one launch: strip -> centred fp16 tile in LDS -> MFMA -> token rows (patch.hip).  Algorithmic bytes: the images once, the rows once
       L.begin(41, 2.0 * ic * p.Np * C * 3.0 * P * P, 12.0 * ic * H * W + 4.0 * ic * p.Np * C + 4.0 * p.Np * C);
       L.misc(cs_patch_fused_launch(query, refs, N_enc, i0, ic, H, W, C, h->Wpatch_frag, h->bpatch, h->pos_tab, h->wsum, x, bf, s), "patch");
@@ -1239,7 +1299,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
 
 static int forward_impl(cs_handle h, int mode, const float* query, const float* refs, const h16_t* ref_tokens, h16_t* tokens_out,
                         int B, int N, int H, int W, float* score_out, float* attn_out, int head_id, float* mean_out,
-                        cs_stream stream) {
+                        cs_stream stream, const U8In* u8 = nullptr) {
   // The workspace is shared by every call on this handle: a call on a different stream than the previous one first waits for that
   // one to finish (calls on one stream are ordered anyway).
   if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
@@ -1247,7 +1307,7 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
   if (h->ev_done && h->last_stream != st) HIPCHK(hipStreamWaitEvent(st, h->ev_done, 0));
   h->census.clear();
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = forward_body(h, mode, query, refs, ref_tokens, tokens_out, B, N, H, W, score_out, attn_out, head_id, mean_out, stream);
+  const int rc = forward_body(h, mode, query, refs, ref_tokens, tokens_out, B, N, H, W, score_out, attn_out, head_id, mean_out, stream, u8);
   h->host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!h->ev_done) HIPCHK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
   HIPCHK(hipEventRecord(h->ev_done, st));
@@ -1267,6 +1327,36 @@ int cs_encode_references(cs_handle h, const float* imgs, int R, int H, int W, ui
 int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_tokens, int B, int N, int H, int W, float* score_out,
                       float* attn_out, int head_id, float* mean_out, cs_stream stream) {
   return forward_impl(h, 1, query, nullptr, ref_tokens, nullptr, B, N, H, W, score_out, attn_out, head_id, mean_out, stream);
+}
+
+// The three forwards fed from decoded uint8 images (SURVEY.md 8f-4 as worded: uint8 in, tokens out; include/crossscore_hip.h)
+int cs_forward_u8(cs_handle h, const cs_u8_image* query, const cs_u8_image* refs, int B, int N, int H, int W, const float* mean3, const float* std3,
+                  float* score_out, float* attn_out, int head_id, float* mean_out, cs_stream stream) {
+  const U8In u{query, refs, mean3, std3};
+  return forward_impl(h, 0, nullptr, nullptr, nullptr, nullptr, B, N, H, W, score_out, attn_out, head_id, mean_out, stream, &u);
+}
+
+int cs_encode_references_u8(cs_handle h, const cs_u8_image* imgs, int R, int H, int W, const float* mean3, const float* std3, uint16_t* tokens_out,
+                            cs_stream stream) {
+  const U8In u{imgs, nullptr, mean3, std3};
+  return forward_impl(h, 2, nullptr, nullptr, nullptr, tokens_out, R, 0, H, W, nullptr, nullptr, 0, nullptr, stream, &u);
+}
+
+int cs_forward_cached_u8(cs_handle h, const cs_u8_image* query, const uint16_t* ref_tokens, int B, int N, int H, int W, const float* mean3,
+                         const float* std3, float* score_out, float* attn_out, int head_id, float* mean_out, cs_stream stream) {
+  const U8In u{query, nullptr, mean3, std3};
+  return forward_impl(h, 1, nullptr, nullptr, ref_tokens, nullptr, B, N, H, W, score_out, attn_out, head_id, mean_out, stream, &u);
+}
+
+int cs_u8_input_supported(cs_handle h, const cs_u8_image* im, int H, int W) {
+  if (!h || !h->finalized || !im) return 0;
+  const cs_config& c = h->cfg;
+  if (h->lnfold || !h->Wpatch_frag || !cs_patch_fused_supported(H, W, c.patch, c.hidden)) return 0;
+  if (im->h <= 0 || im->w <= 0 || im->rs_h <= 0 || im->rs_w <= 0 || im->crop_y < 0 || im->crop_x < 0 || im->crop_y + H > im->rs_h || im->crop_x + W > im->rs_w) return 0;
+  CsU8Tables t{};
+  int span = 0;
+  if (cs_preprocess_tables(im->h, im->w, im->rs_h, im->rs_w, im->crop_y, H / c.patch, c.patch, &t, &span) != hipSuccess) return 0;
+  return cs_patch_u8_runs(W, span) > 0 ? 1 : 0;
 }
 
 // What the last forward-class call on this handle launched, and what it cost the host: `launches` = kernel launches (memcpy taps of capture
@@ -1508,6 +1598,36 @@ int cs_op_patch_embed_fused(const float* x, const float* w, const float* bias, c
   if (!rc) chk(cs_patch_fused_launch(x, nullptr, 0, 0, I, H, W, C, wf, bias, pos, wsum, out, g_op_bf16, st), "patch");
   chk(hipStreamSynchronize(st), "sync");
   hipFree(wf); hipFree(wsum);
+  return rc;
+}
+
+// The same launch fed from ONE decoded uint8 image geometry (test entry point of the one-pass input stage): imgs = I device images of identical
+// size (I, in_h, row_bytes) -> out (I * (1 + Np), C) as cs_op_patch_embed_fused on cs_op_preprocess_u8's output of each image.
+int cs_op_patch_embed_fused_u8(const uint8_t* imgs, int I, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int H, int W,
+                               const float* mean3, const float* std3, const float* w, const float* bias, const float* pos, int P, int C, float* out,
+                               cs_stream stream) {
+  if (!imgs || !w || !bias || !pos || !out || !mean3 || !std3 || I <= 0 || !cs_patch_fused_supported(H, W, P, C) || crop_y < 0 || crop_x < 0 ||
+      crop_y + H > rs_h || crop_x + W > rs_w || row_bytes < 3 * in_w)
+    return fail(CS_ERR_BAD_ARG, "patch_embed_fused_u8: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  CsU8Tables t{};
+  int span = 0;
+  HIPCHK(cs_preprocess_tables(in_h, in_w, rs_h, rs_w, crop_y, H / P, P, &t, &span));
+  if (cs_patch_u8_runs(W, span) <= 0) return fail(CS_ERR_UNSUPPORTED, "patch_embed_fused_u8: %d source rows per patch row do not fit", span);
+  std::vector<CsU8Desc> hd(I);
+  for (int i = 0; i < I; ++i) { hd[i].data = imgs + (size_t)i * in_h * row_bytes; hd[i].t = t; hd[i].row_bytes = row_bytes; hd[i].crop_y = crop_y; hd[i].crop_x = crop_x; }
+  h16_t* wf = nullptr; float* wsum = nullptr; CsU8Desc* dd = nullptr;
+  HIPCHK(hipMalloc(&wf, cs_patch_pack_elems(C) * sizeof(h16_t)));
+  HIPCHK(hipMalloc(&wsum, (size_t)3 * C * sizeof(float)));
+  HIPCHK(hipMalloc(&dd, (size_t)I * sizeof(CsU8Desc)));
+  int rc = 0;
+  auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = fail(CS_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
+  chk(hipMemcpy(dd, hd.data(), (size_t)I * sizeof(CsU8Desc), hipMemcpyHostToDevice), "descriptors");
+  chk(cs_patch_pack_launch(w, C, wf, g_op_bf16, st), "pack");
+  chk(cs_patch_wsum_launch(w, C, P, wsum, st), "wsum");
+  if (!rc) chk(cs_patch_fused_u8_launch(dd, I, 0, 0, I, H, W, C, span, mean3, std3, wf, bias, pos, wsum, out, g_op_bf16, st), "patch_u8");
+  chk(hipStreamSynchronize(st), "sync");
+  hipFree(wf); hipFree(wsum); hipFree(dd);
   return rc;
 }
 

@@ -192,6 +192,19 @@ struct CsAttnParams {
   int bf16;                                            // operand type of Q, K, V, P and O: 0 IEEE half, 1 bfloat16
 };
 
+// One-pass input stage (SURVEY.md 8f-4 as worded: uint8 in, tokens out).  Filter tables of one resize geometry (preprocess.hip) and the per-image
+// descriptor the patch kernel reads (patch.hip); images of one launch may differ in source size and geometry, not in the H x W window they produce.
+struct CsU8Tables {
+  const int *xmin, *xsize, *ymin, *ysize;  // per resized column / row: first source tap, number of taps
+  const float *wx, *wy;                    // [rs_w][taps_x], [rs_h][taps_y] normalised triangle weights
+  int taps_x, taps_y;
+};
+struct CsU8Desc {
+  const uint8_t* data;  // device HWC RGB; null = the all-zero placeholder image (nvs_dataset.py:459-470: zeros BEFORE T.Normalize)
+  CsU8Tables t;
+  int row_bytes, crop_y, crop_x, pad_;
+};
+
 // Encoder "token panel" kernel (panel.hip): one launch per DINOv2 layer does, for 128-row panels of the residual stream,
 //   x += attn_o Wo'^T + bo'                 (attention output projection, LayerScale folded; HF modeling_dinov2.py:249-252,365-370)
 //   x += GELU(LN2(x) W1'^T + b1') W2'^T + b2'   (norm2 + MLP + LayerScale; HF:373-378, 293-297)

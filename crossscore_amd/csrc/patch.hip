@@ -72,9 +72,14 @@ struct PatchParams {
   int nsx;                           // runs per patch row
   const h16_t* wfrag; const float* bias; const float* pos; const float* wsum;  // pos ((1 + gh gw), C); wsum (3, C)
   float* x;                          // (images of the chunk, 1 + gh gw, C) fp32 token rows; CLS rows are not written here
+  // U8 form (SURVEY.md 8f-4 as worded: uint8 in, tokens out): the strip comes from the decoded images through the input stage's own arithmetic
+  const CsU8Desc* u8;                // [nq query images][nq * N reference images]
+  int nq;
+  int lut_off;                       // byte offset of the 256-entry x / 255 table in LDS (behind the largest horizontal-pass buffer)
+  float mean[3], stdv[3];
 };
 
-template <bool BF>
+template <bool BF, bool U8>
 __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
   extern __shared__ __attribute__((aligned(16))) char pf_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
 
   const int g_img = p.img0 + img;
   const int bb = g_img / (1 + p.N), vv = g_img - bb * (1 + p.N);
-  const float* x = vv == 0 ? p.xq + (size_t)bb * 3 * p.H * p.W : p.xr + ((size_t)bb * p.N + (vv - 1)) * 3 * p.H * p.W;
+  [[maybe_unused]] const float* x = nullptr;
+  if constexpr (!U8) x = vv == 0 ? p.xq + (size_t)bb * 3 * p.H * p.W : p.xr + ((size_t)bb * p.N + (vv - 1)) * 3 * p.H * p.W;
 
   // ---------------- phase A: strip -> centred 16-bit A tile ----------------
   const int nseg = np * 3 * PF_P;
@@ -112,7 +118,68 @@ __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
     const int sg = tid + 256 * i;
     const int row = sg / np;  // ch * 14 + dy
     srow[i] = row; spj[i] = sg - row * np;
-    if (sg < nseg) {
+  }
+  if constexpr (U8) {
+    // The strip's pixels straight from the decoded uint8 image, by the operations of the two-launch input stage in their order (preprocess.hip:
+    // x / 255 -> width pass of the antialiased triangle filter -> height pass -> (v - mean) / std; an image that needs no resize has the identity
+    // table).  Per channel: the source rows the strip's 14 pixel rows reach (first tap of the first .. last tap of the last) go through the width
+    // pass into LDS, [source row][strip column] fp32, then every thread forms its 14-pixel segments by the height pass.  The buffer lives where the
+    // A tile and the epilogue patches will be: nothing of them exists before all segments are in registers.
+    const CsU8Desc& d = p.u8[vv == 0 ? bb : p.nq + bb * p.N + (vv - 1)];
+    float* tmp = reinterpret_cast<float*>(pf_smem);
+    float* lut = reinterpret_cast<float*>(pf_smem + p.lut_off);
+    lut[tid] = (float)tid / 255.0f;  // np.float32(img) / 255.0 (utils/io/images.py:14-29), one IEEE division per value instead of per tap
+    const int ry0 = pi * PF_P + d.crop_y, X0 = p0 * PF_P + d.crop_x, wpx = np * PF_P;
+    const int R0 = d.t.ymin[ry0];
+    int R1 = R0;
+    for (int dy = 0; dy < PF_P; ++dy) R1 = max(R1, d.t.ymin[ry0 + dy] + d.t.ysize[ry0 + dy]);
+    const int nout = (R1 - R0) * wpx;
+#pragma unroll 1
+    for (int ch = 0; ch < 3; ++ch) {
+      __syncthreads();  // the table is there / the previous channel's height pass is done
+      for (int o = tid; o < nout; o += 256) {
+        const int r = o / wpx, rx = X0 + (o - r * wpx);
+        float a = 0.f;
+        if (d.data) {
+          const int n = d.t.xsize[rx];
+          const uint8_t* src = d.data + (size_t)(R0 + r) * d.row_bytes + (size_t)d.t.xmin[rx] * 3 + ch;
+          const float* w = d.t.wx + (size_t)rx * d.t.taps_x;
+          for (int j = 0; j < n; ++j) {
+            const float px = lut[src[3 * j]];
+            a = j == 0 ? px * w[j] : __builtin_fmaf(px, w[j], a);
+          }
+        }
+        tmp[o] = a;
+      }
+      __syncthreads();
+      const float mu = p.mean[ch], sd = p.stdv[ch];
+#pragma unroll
+      for (int i = 0; i < PF_MAXSEG; ++i) {
+        const int dy = srow[i] - ch * PF_P;
+        if (tid + 256 * i < nseg && dy >= 0 && dy < PF_P) {
+          const int ry = ry0 + dy, n = d.t.ysize[ry];
+          const float* w = d.t.wy + (size_t)ry * d.t.taps_y;
+          const float* col = tmp + (d.t.ymin[ry] - R0) * wpx + spj[i] * PF_P;
+          float acc[PF_P];
+#pragma unroll
+          for (int e = 0; e < PF_P; ++e) acc[e] = 0.f;
+          for (int j = 0; j < n; ++j) {
+            const float wj = w[j];
+#pragma unroll
+            for (int e = 0; e < PF_P; ++e) acc[e] = j == 0 ? col[j * wpx + e] * wj : __builtin_fmaf(col[j * wpx + e], wj, acc[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < PF_P; ++e) v[i][e] = (acc[e] - mu) / sd;
+        }
+      }
+    }
+    __syncthreads();  // the row sums below overwrite the buffer
+  }
+#pragma unroll
+  for (int i = 0; i < PF_MAXSEG; ++i) {
+    const int sg = tid + 256 * i;
+    const int row = srow[i];
+    if (!U8 && sg < nseg) {
       const int ch = row / PF_P, dy = row - ch * PF_P;
       const float* src = x + ((size_t)ch * p.H + (pi * PF_P + dy)) * p.W + (p0 + spj[i]) * PF_P;
       // 56 bytes at an 8-byte-aligned address: 3 x 16 + 8 (global loads need dword alignment only; 7 x 8 bytes cost the address
@@ -274,6 +341,29 @@ int cs_patch_fused_supported(int H, int W, int P, int C) {
   return g_pf_enabled && P == PF_P && C % PF_NCOL == 0 && C > 0 && W % 2 == 0 && H >= P && W >= P;
 }
 
+namespace {
+
+constexpr int PF_U8_TMP = 64 * 1024;               // largest horizontal-pass buffer of the U8 form (one channel: source rows x strip columns, fp32)
+constexpr int PF_U8_LDS = PF_U8_TMP + 1024;        // + the x / 255 table
+
+template <bool BF, bool U8>
+hipError_t pf_launch(const PatchParams& p, int lds, long long blocks, hipStream_t st) {
+  if (blocks <= 0 || blocks >= (1ll << 31)) return hipErrorInvalidValue;
+  static std::atomic<bool> attr_done[16];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    const int cap = U8 && PF_U8_LDS > pf_lds(PF_MAXNP) ? PF_U8_LDS : pf_lds(PF_MAXNP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cs_patch_fused_kernel<BF, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL((cs_patch_fused_kernel<BF, U8>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
 hipError_t cs_patch_fused_launch(const float* xq, const float* xr, int N, int img0, int I, int H, int W, int C, const h16_t* wfrag,
                                  const float* bias, const float* pos, const float* wsum, float* x, int bf, hipStream_t st) {
   PatchParams p{};
@@ -281,20 +371,34 @@ hipError_t cs_patch_fused_launch(const float* xq, const float* xr, int N, int im
   p.nsx = (p.gw + PF_MAXNP - 1) / PF_MAXNP;
   p.wfrag = wfrag; p.bias = bias; p.pos = pos; p.wsum = wsum; p.x = x;
   const int npmax = (p.gw + p.nsx - 1) / p.nsx;
-  const int lds = pf_lds(npmax);
   const long long blocks = (long long)I * p.gh * p.nsx;
-  if (blocks <= 0 || blocks >= (1ll << 31)) return hipErrorInvalidValue;
-  static std::atomic<bool> attr_done[16][2];  // (zero-initialised; hipFuncSetAttribute is idempotent, a racing second caller only repeats it)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-  if (!attr_done[dev][bf ? 1 : 0]) {
-    const void* f = bf ? reinterpret_cast<const void*>(cs_patch_fused_kernel<true>) : reinterpret_cast<const void*>(cs_patch_fused_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, pf_lds(PF_MAXNP));
-    if (e != hipSuccess) return e;
-    attr_done[dev][bf ? 1 : 0] = true;
+  return bf ? pf_launch<true, false>(p, pf_lds(npmax), blocks, st) : pf_launch<false, false>(p, pf_lds(npmax), blocks, st);
+}
+
+// runs of a patch row the U8 form needs so that `row_span` source rows of a run fit the horizontal-pass buffer; 0: not even one patch per run does
+int cs_patch_u8_runs(int W, int row_span) {
+  const int gw = W / PF_P;
+  for (int nsx = (gw + PF_MAXNP - 1) / PF_MAXNP; nsx <= gw; ++nsx) {
+    const int npmax = (gw + nsx - 1) / nsx;
+    if ((long long)row_span * npmax * PF_P * 4 <= PF_U8_TMP) return nsx;
   }
-  const unsigned grid = (unsigned)blocks;
-  if (bf) hipLaunchKernelGGL(cs_patch_fused_kernel<true>, dim3(grid), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(cs_patch_fused_kernel<false>, dim3(grid), dim3(256), lds, st, p);
-  return hipGetLastError();
+  return 0;
+}
+
+// The same launch from decoded uint8 images: `descs` (device) = nq query descriptors, then nq * N reference descriptors; row_span = the largest number
+// of source rows a patch row of any of them reaches (cs_preprocess_tables).  hipErrorInvalidValue when the geometry does not fit (cs_patch_u8_runs).
+hipError_t cs_patch_fused_u8_launch(const CsU8Desc* descs, int nq, int N, int img0, int I, int H, int W, int C, int row_span, const float* mean3,
+                                    const float* std3, const h16_t* wfrag, const float* bias, const float* pos, const float* wsum, float* x, int bf,
+                                    hipStream_t st) {
+  PatchParams p{};
+  p.u8 = descs; p.nq = nq; p.N = N; p.img0 = img0; p.H = H; p.W = W; p.gh = H / PF_P; p.gw = W / PF_P; p.C = C;
+  p.nsx = cs_patch_u8_runs(W, row_span);
+  if (p.nsx <= 0 || row_span <= 0) return hipErrorInvalidValue;
+  for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.stdv[c] = std3[c]; }
+  p.wfrag = wfrag; p.bias = bias; p.pos = pos; p.wsum = wsum; p.x = x;
+  const int npmax = (p.gw + p.nsx - 1) / p.nsx;
+  p.lut_off = ((row_span * npmax * PF_P * 4 + 255) / 256) * 256;
+  const int lds = p.lut_off + 1024 > pf_lds(npmax) ? p.lut_off + 1024 : pf_lds(npmax);
+  const long long blocks = (long long)I * p.gh * p.nsx;
+  return bf ? pf_launch<true, true>(p, lds, blocks, st) : pf_launch<false, true>(p, lds, blocks, st);
 }

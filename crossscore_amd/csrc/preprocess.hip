@@ -10,6 +10,7 @@
 // reference's tensor.  HBM-bound byte work: one thread per output pixel, coalesced along x; H2D traffic drops 4x (uint8 in).
 #include "cs_common.h"
 #include <math.h>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -66,8 +67,48 @@ struct TableEntry {
   int taps_x = 0, taps_y = 0;
   int* d_int = nullptr;    // xmin[rs_w] xsize[rs_w] ymin[rs_h] ysize[rs_h]
   float* d_w = nullptr;    // wx[rs_w][taps_x] wy[rs_h][taps_y]
+  std::vector<int> h_ymin, h_yend;  // host copy of the row table (first source row, one past the last) for cs_preprocess_tables' row spans
 };
 std::vector<TableEntry> g_tabs;
+std::mutex g_tabs_mu;  // forwards of several handles may come from several host threads (pipeline.py)
+
+// the entry of (device, in_h, in_w, rs_h, rs_w), built and uploaded on first use; the caller holds g_tabs_mu
+hipError_t table_entry(int in_h, int in_w, int rs_h, int rs_w, const TableEntry** out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  for (const TableEntry& t : g_tabs)
+    if (t.dev == dev && t.in_h == in_h && t.in_w == in_w && t.rs_h == rs_h && t.rs_w == rs_w) { *out = &t; return hipSuccess; }
+  if (g_tabs.size() >= 64) {
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    for (TableEntry& t : g_tabs) { (void)hipFree(t.d_int); (void)hipFree(t.d_w); }
+    g_tabs.clear();
+  }
+  AxisTable tx, ty;
+  build_axis(in_w, rs_w, tx);
+  build_axis(in_h, rs_h, ty);
+  TableEntry t;
+  t.dev = dev; t.in_h = in_h; t.in_w = in_w; t.rs_h = rs_h; t.rs_w = rs_w; t.taps_x = tx.taps; t.taps_y = ty.taps;
+  t.h_ymin = ty.xmin;
+  t.h_yend.resize(rs_h);
+  for (int i = 0; i < rs_h; ++i) t.h_yend[i] = ty.xmin[i] + ty.xsize[i];
+  std::vector<int> h_int;
+  h_int.insert(h_int.end(), tx.xmin.begin(), tx.xmin.end());
+  h_int.insert(h_int.end(), tx.xsize.begin(), tx.xsize.end());
+  h_int.insert(h_int.end(), ty.xmin.begin(), ty.xmin.end());
+  h_int.insert(h_int.end(), ty.xsize.begin(), ty.xsize.end());
+  std::vector<float> h_w;
+  h_w.insert(h_w.end(), tx.w.begin(), tx.w.end());
+  h_w.insert(h_w.end(), ty.w.begin(), ty.w.end());
+  if ((e = hipMalloc(&t.d_int, h_int.size() * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMalloc(&t.d_w, h_w.size() * sizeof(float))) != hipSuccess) { (void)hipFree(t.d_int); return e; }
+  // fresh buffers nobody reads yet; hipMemcpy returns once the (pageable) host vectors have been consumed
+  if ((e = hipMemcpy(t.d_int, h_int.data(), h_int.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  if ((e = hipMemcpy(t.d_w, h_w.data(), h_w.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  g_tabs.push_back(std::move(t));
+  *out = &g_tabs.back();
+  return hipSuccess;
+}
 
 __global__ void u8_norm_kernel(const uint8_t* __restrict__ img, int row_bytes, int crop_y, int crop_x, int oh, int ow,
                                float m0, float m1, float m2, float s0, float s1, float s2, float* __restrict__ out) {
@@ -95,8 +136,9 @@ __global__ void u8_resize_w_kernel(const uint8_t* __restrict__ img, int row_byte
   for (int j = 0; j < n; ++j) {
     const float wj = w[j];
     const float v0 = (float)row[3 * j] / 255.0f, v1 = (float)row[3 * j + 1] / 255.0f, v2 = (float)row[3 * j + 2] / 255.0f;
+    // (explicit fma: the one-pass form in patch.hip repeats these operations and must round the same way whatever the compiler contracts)
     if (j == 0) { a0 = v0 * wj; a1 = v1 * wj; a2 = v2 * wj; }
-    else { a0 += v0 * wj; a1 += v1 * wj; a2 += v2 * wj; }
+    else { a0 = __builtin_fmaf(v0, wj, a0); a1 = __builtin_fmaf(v1, wj, a1); a2 = __builtin_fmaf(v2, wj, a2); }
   }
   float* o = tmp + ((size_t)y * rs_w + x) * 3;
   o[0] = a0; o[1] = a1; o[2] = a2;
@@ -118,7 +160,7 @@ __global__ void resize_h_norm_kernel(const float* __restrict__ tmp, int rs_w, in
     const float wj = w[j];
     const float* p = col + (size_t)j * rs_w * 3;
     if (j == 0) { a0 = p[0] * wj; a1 = p[1] * wj; a2 = p[2] * wj; }
-    else { a0 += p[0] * wj; a1 += p[1] * wj; a2 += p[2] * wj; }
+    else { a0 = __builtin_fmaf(p[0], wj, a0); a1 = __builtin_fmaf(p[1], wj, a1); a2 = __builtin_fmaf(p[2], wj, a2); }
   }
   const size_t plane = (size_t)oh * ow, o = (size_t)y * ow + x;
   out[o] = (a0 - m0) / s0;
@@ -179,39 +221,10 @@ extern "C" hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_
                        mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
     return hipGetLastError();
   }
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(g_tabs_mu);
   const TableEntry* hit = nullptr;
-  for (const TableEntry& t : g_tabs)
-    if (t.dev == dev && t.in_h == in_h && t.in_w == in_w && t.rs_h == rs_h && t.rs_w == rs_w) { hit = &t; break; }
-  if (!hit) {
-    if (g_tabs.size() >= 64) {
-      if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
-      for (TableEntry& t : g_tabs) { (void)hipFree(t.d_int); (void)hipFree(t.d_w); }
-      g_tabs.clear();
-    }
-    AxisTable tx, ty;
-    build_axis(in_w, rs_w, tx);
-    build_axis(in_h, rs_h, ty);
-    TableEntry t;
-    t.dev = dev; t.in_h = in_h; t.in_w = in_w; t.rs_h = rs_h; t.rs_w = rs_w; t.taps_x = tx.taps; t.taps_y = ty.taps;
-    std::vector<int> h_int;
-    h_int.insert(h_int.end(), tx.xmin.begin(), tx.xmin.end());
-    h_int.insert(h_int.end(), tx.xsize.begin(), tx.xsize.end());
-    h_int.insert(h_int.end(), ty.xmin.begin(), ty.xmin.end());
-    h_int.insert(h_int.end(), ty.xsize.begin(), ty.xsize.end());
-    std::vector<float> h_w;
-    h_w.insert(h_w.end(), tx.w.begin(), tx.w.end());
-    h_w.insert(h_w.end(), ty.w.begin(), ty.w.end());
-    if ((e = hipMalloc(&t.d_int, h_int.size() * sizeof(int))) != hipSuccess) return e;
-    if ((e = hipMalloc(&t.d_w, h_w.size() * sizeof(float))) != hipSuccess) { (void)hipFree(t.d_int); return e; }
-    // fresh buffers nobody reads yet; hipMemcpy returns once the (pageable) host vectors have been consumed
-    if ((e = hipMemcpy(t.d_int, h_int.data(), h_int.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMemcpy(t.d_w, h_w.data(), h_w.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return e;
-    g_tabs.push_back(t);
-    hit = &g_tabs.back();
-  }
+  hipError_t e = table_entry(in_h, in_w, rs_h, rs_w, &hit);
+  if (e != hipSuccess) return e;
   const TableEntry& T = *hit;
   const int* xmin = T.d_int;
   const int* xsize = T.d_int + rs_w;
@@ -226,4 +239,28 @@ extern "C" hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_
   hipLaunchKernelGGL(resize_h_norm_kernel, dim3((ow + 255) / 256, oh), blk, 0, stream, scratch, rs_w, T.taps_y, ymin, ysize, wy, crop_y,
                      crop_x, oh, ow, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
   return hipGetLastError();
+}
+
+// The filter tables of one resize geometry for the one-pass input stage (patch.hip, cs_patch_fused_u8_launch): device pointers that stay valid until the
+// cache is dropped (65th geometry, behind a device synchronisation), and the largest number of source rows any row of `gh` P-pixel patches starting
+// at resized row crop_y needs (first tap of its first pixel row .. last tap of its last): what the kernel has to hold in LDS per channel.
+extern "C" hipError_t cs_preprocess_tables(int in_h, int in_w, int rs_h, int rs_w, int crop_y, int gh, int P, CsU8Tables* out, int* row_span) {
+  std::lock_guard<std::mutex> lock(g_tabs_mu);
+  const TableEntry* hit = nullptr;
+  hipError_t e = table_entry(in_h, in_w, rs_h, rs_w, &hit);
+  if (e != hipSuccess) return e;
+  const TableEntry& T = *hit;
+  out->xmin = T.d_int; out->xsize = T.d_int + rs_w; out->ymin = T.d_int + 2 * rs_w; out->ysize = out->ymin + rs_h;
+  out->wx = T.d_w; out->wy = T.d_w + (size_t)rs_w * T.taps_x;
+  out->taps_x = T.taps_x; out->taps_y = T.taps_y;
+  int span = 0;
+  for (int pi = 0; pi < gh; ++pi) {
+    const int r0 = crop_y + pi * P, r1 = r0 + P - 1;
+    if (r0 < 0 || r1 >= rs_h) return hipErrorInvalidValue;
+    int hi = 0;
+    for (int r = r0; r <= r1; ++r) hi = T.h_yend[r] > hi ? T.h_yend[r] : hi;
+    span = hi - T.h_ymin[r0] > span ? hi - T.h_ymin[r0] : span;
+  }
+  *row_span = span;
+  return hipSuccess;
 }

@@ -74,6 +74,7 @@ class InputStage:
         self.crop_size = crop_size
         self.integer_patches = integer_patches
         self.patch = patch
+        self.mean_std = tuple(float(v) for v in mean_std)
         self._mean = (C.c_float * 3)(*mean_std[:3])
         self._std = (C.c_float * 3)(*mean_std[3:])
         self._scratch: Optional[torch.Tensor] = None
@@ -112,6 +113,24 @@ class InputStage:
                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         # d_img may be released once the stream has consumed it
         d_img.record_stream(torch.cuda.current_stream(self.device))
+
+
+    # -- the one-pass form (SURVEY.md 8f-4 as worded): nothing is computed here, the patch-embedding launch does the pixel work --------------
+    def describe(self, img_u8: np.ndarray):
+        """The decoded image on the device with its geometry (model.U8Image) for CrossScoreNet.forward_u8 and its siblings."""
+        from .model import U8Image
+        h, w, _ = img_u8.shape
+        rs, crop = self.geometry(h, w)
+        return U8Image(torch.from_numpy(img_u8).to(self.device, non_blocking=False), h, w, rs, crop[0], crop[1])
+
+    def placeholder(self, size):
+        """The all-zero image (placeholders of short reference lists, zero_reference: nvs_dataset.py:459-470) of the processed size."""
+        from .model import U8Image
+        return U8Image(None, size[0], size[1], size)
+
+    def batch(self, images, size):
+        from .model import U8Batch
+        return U8Batch(images, size, self.mean_std)
 
 
 class SimpleReferenceItems:
@@ -178,13 +197,42 @@ def load_batch(items: List[Dict[str, object]], stage: InputStage, zero_reference
     return {"query/img": query, "reference/cross/imgs": refs, "item_paths": item_paths}
 
 
+def load_batch_u8(items: List[Dict[str, object]], stage: InputStage, zero_reference: bool = False,
+                  decoded: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, object]:
+    """load_batch for the one-pass input stage: "query/img" and "reference/cross/imgs" are model.U8Batch objects (decoded images on the device +
+    geometry) for CrossScoreNet.forward_u8; no processed fp32 tensor exists."""
+    decoded = decoded if decoded is not None else {}
+    get = lambda p: decoded[p] if p in decoded else read_image_u8(p)  # noqa: E731
+    q_imgs = [get(it["query/img"]) for it in items]
+    geo = {stage.geometry(*im.shape[:2])[1][2:] for im in q_imgs}
+    if len(geo) != 1:
+        raise ValueError(f"query images of one batch must share the processed size, got {sorted(geo)}")
+    size = next(iter(geo))
+    N = len(items[0]["reference/cross/imgs"])
+    refs = []
+    for it in items:
+        for p in it["reference/cross/imgs"]:
+            if p == EMPTY or zero_reference:
+                refs.append(stage.placeholder(size))
+                continue
+            ri = get(p)
+            if stage.geometry(*ri.shape[:2])[1][2:] != size:
+                raise ValueError(f"{p}: processed size differs from the query's {size[0]}x{size[1]}")
+            refs.append(stage.describe(ri))
+    item_paths = {"query/img": [it["query/img"] for it in items], "query/score_map": [it["query/score_map"] for it in items],
+                  "reference/cross/imgs": [[it["reference/cross/imgs"][n] for it in items] for n in range(N)]}
+    return {"query/img": stage.batch([stage.describe(qi) for qi in q_imgs], size), "reference/cross/imgs": stage.batch(refs, size),
+            "item_paths": item_paths}
+
+
 class ReferenceTokenCache:
     """SURVEY.md 8f-3 inside the predict loop: references are sampled from one finite directory, so each reference image is
     pre-processed and encoded ONCE (CrossScoreNet.encode_references) and queries are scored with forward_cached -- the same bits
     as the full forward (tests/test_hip_forward.py), with 1 instead of 1 + N images through the encoder per query."""
 
-    def __init__(self, net, stage: InputStage, keep_images: bool, max_images: int = 4096):
+    def __init__(self, net, stage: InputStage, keep_images: bool, max_images: int = 4096, from_u8: bool = False):
         self.net, self.stage, self.keep_images, self.max_images = net, stage, keep_images, max_images
+        self.from_u8 = bool(from_u8) and not keep_images  # one-pass input stage: no processed fp32 image exists to keep
         self.tokens: Dict[object, torch.Tensor] = {}
         self.images: Dict[object, torch.Tensor] = {}
 
@@ -201,7 +249,21 @@ class ReferenceTokenCache:
                 self.tokens.clear()
                 self.images.clear()
                 missing = list(dict.fromkeys(k for ks in keys for k in ks))
-            buf = torch.empty((len(missing), 3, oh, ow), dtype=torch.float32, device=self.stage.device)
+            if self.from_u8:
+                descs = []
+                for k in missing:
+                    if k[0] == EMPTY:
+                        descs.append(self.stage.placeholder((oh, ow)))
+                        continue
+                    img = decoded[k[0]] if k[0] in decoded else read_image_u8(k[0])
+                    if self.stage.geometry(*img.shape[:2])[1][2:] != (oh, ow):
+                        raise ValueError(f"{k[0]}: processed size differs from the query's {oh}x{ow}")
+                    descs.append(self.stage.describe(img))
+                tok = self.net.encode_references_u8(self.stage.batch(descs, (oh, ow)))
+                for i, k in enumerate(missing):
+                    self.tokens[k] = tok[i]
+                missing = []
+            buf = torch.empty((len(missing), 3, oh, ow), dtype=torch.float32, device=self.stage.device) if missing else None
             for i, k in enumerate(missing):
                 if k[0] == EMPTY:
                     buf[i] = self.stage.zero_image_value[:, None, None]
@@ -210,7 +272,7 @@ class ReferenceTokenCache:
                 if self.stage.geometry(*img.shape[:2])[1][2:] != (oh, ow):
                     raise ValueError(f"{k[0]}: processed size differs from the query's {oh}x{ow}")
                 self.stage(img, buf[i])
-            tok = self.net.encode_references(buf)
+            tok = self.net.encode_references(buf) if missing else None
             for i, k in enumerate(missing):
                 self.tokens[k] = tok[i]
                 if self.keep_images:
@@ -234,3 +296,16 @@ def load_query_batch(items: List[Dict[str, object]], stage: InputStage, decoded:
     item_paths = {"query/img": [it["query/img"] for it in items], "query/score_map": [it["query/score_map"] for it in items],
                   "reference/cross/imgs": [[it["reference/cross/imgs"][n] for it in items] for n in range(N)]}
     return {"query/img": query, "reference/cross/imgs": None, "item_paths": item_paths}, (oh, ow)
+
+
+def load_query_batch_u8(items: List[Dict[str, object]], stage: InputStage, decoded: Dict[str, np.ndarray]):
+    """load_query_batch for the one-pass input stage: "query/img" is a model.U8Batch."""
+    q_imgs = [decoded[it["query/img"]] if it["query/img"] in decoded else read_image_u8(it["query/img"]) for it in items]
+    geo = {stage.geometry(*im.shape[:2])[1][2:] for im in q_imgs}
+    if len(geo) != 1:
+        raise ValueError(f"query images of one batch must share the processed size, got {sorted(geo)}")
+    size = next(iter(geo))
+    N = len(items[0]["reference/cross/imgs"])
+    item_paths = {"query/img": [it["query/img"] for it in items], "query/score_map": [it["query/score_map"] for it in items],
+                  "reference/cross/imgs": [[it["reference/cross/imgs"][n] for it in items] for n in range(N)]}
+    return {"query/img": stage.batch([stage.describe(qi) for qi in q_imgs], size), "reference/cross/imgs": None, "item_paths": item_paths}, size

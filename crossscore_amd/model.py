@@ -67,6 +67,54 @@ def arch_from_cfg(cfg) -> ArchSpec:
                                do_self_attn=bool(m.decoder_do_self_attn))
 
 
+class U8Image:
+    """One decoded image on the device with its input-stage geometry (cs_u8_image): data (h, w, 3) uint8 CUDA tensor (rows may be padded:
+    row_bytes), rs = size after T.Resize, (crop_y, crop_x) = top-left corner of the processed window.  data None = the all-zero placeholder
+    image the reference pads short reference lists with (nvs_dataset.py:459-470)."""
+    __slots__ = ("data", "h", "w", "row_bytes", "rs", "crop_y", "crop_x")
+
+    def __init__(self, data: Optional[torch.Tensor], h: int, w: int, rs, crop_y: int = 0, crop_x: int = 0, row_bytes: Optional[int] = None):
+        if data is not None and (not data.is_cuda or data.dtype != torch.uint8 or not data.is_contiguous()):
+            raise ValueError("U8Image.data must be a contiguous uint8 CUDA tensor")
+        self.data, self.h, self.w, self.rs, self.crop_y, self.crop_x = data, int(h), int(w), (int(rs[0]), int(rs[1])), int(crop_y), int(crop_x)
+        self.row_bytes = int(row_bytes) if row_bytes is not None else 3 * self.w
+
+    def c_struct(self) -> "_lib.CsU8Image":
+        return _lib.CsU8Image(C.c_void_p(self.data.data_ptr()) if self.data is not None else None, self.h, self.w, self.row_bytes,
+                              self.rs[0], self.rs[1], self.crop_y, self.crop_x)
+
+
+class U8Batch:
+    """The images of a forward as decoded uint8 (CrossScoreNet.forward_u8 and its siblings): `images` in batch order (references item-major:
+    item 0's N views, item 1's, ...), all producing the same (H, W) window; mean_std = the six T.Normalize numbers (task/predict.py:68-74)."""
+
+    def __init__(self, images, size, mean_std=synth.IMAGENET_MEAN_STD):
+        self.images, self.size = list(images), (int(size[0]), int(size[1]))
+        self.mean = (C.c_float * 3)(*mean_std[:3])
+        self.std = (C.c_float * 3)(*mean_std[3:])
+
+    def __len__(self) -> int:
+        return len(self.images)
+
+    def c_array(self, lo: int, hi: int):
+        arr = (_lib.CsU8Image * (hi - lo))()
+        for i in range(lo, hi):
+            arr[i - lo] = self.images[i].c_struct()
+        return arr
+
+    def record_stream(self, s) -> None:
+        for im in self.images:
+            if im.data is not None:
+                im.data.record_stream(s)
+
+    @property
+    def device(self):
+        for im in self.images:
+            if im.data is not None:
+                return im.data.device
+        return None
+
+
 class _Node(torch.nn.Module):
     """Parameter container; the tree of _Nodes reproduces the reference module paths."""
 
@@ -334,6 +382,98 @@ class CrossScoreNet(torch.nn.Module):
                     C.c_void_p(score[b0:b1].data_ptr()),
                     C.c_void_p(attn[b0:b1].data_ptr()) if attn is not None else None, int(need_attn_weights_head_id),
                     C.c_void_p(mean_out[b0:b1].data_ptr()) if mean_out is not None else None, C.c_void_p(stream)))
+        results = {"score_map_ref_cross": score, "attn_weights_map_ref_cross": attn}
+        if return_mean:
+            results["score_mean_ref_cross"] = mean_out
+        return results
+
+    # -- the same three calls fed from decoded uint8 images (SURVEY.md 8f-4 as worded: uint8 in, tokens out) --------------------------------
+    def u8_input_supported(self, img: U8Image, size, device=None) -> bool:
+        """Whether forward_u8 / encode_references_u8 / forward_cached_u8 take this image geometry (else: InputStage + the fp32 calls)."""
+        dev = device or (img.data.device if img.data is not None else None)
+        if dev is None or not self._do_reference_cross:
+            return False
+        st = img.c_struct()
+        return bool(_lib.load().cs_u8_input_supported(self._ensure_handle(dev), C.byref(st), int(size[0]), int(size[1])))
+
+    def _u8_out(self, B, N, H, W, dev, need_attn_weights, return_mean):
+        P = self.arch.patch
+        h, w = H // P, W // P
+        score = torch.empty((B, h * P, w * P), dtype=torch.float32, device=dev)
+        attn = torch.empty((B, h, w, N, h, w), dtype=torch.float32, device=dev) if need_attn_weights else None
+        mean_out = torch.empty((B,), dtype=torch.float32, device=dev) if return_mean else None
+        return score, attn, mean_out
+
+    @torch.no_grad()
+    def forward_u8(self, query: U8Batch, refs: U8Batch, need_attn_weights=False, need_attn_weights_head_id=0, return_mean=False):
+        """forward() from decoded uint8 images: query = B images, refs = B * N images (item-major).  The resize / crop / normalise of the input
+        stage happens inside the patch-embedding launch; results are bit-identical to InputStage + forward()."""
+        B = len(query)
+        if B == 0 or len(refs) % B or query.size != refs.size:
+            raise ValueError("expected B query images and B * N reference images of one processed size")
+        N = len(refs) // B
+        H, W = query.size
+        dev = query.device
+        if dev is None:
+            raise _lib.CrossScoreHipError("forward_u8 needs device images: the hot path has no CPU fallback")
+        self._check_pe_mode(H, W)
+        lib = _lib.load()
+        handle = self._ensure_handle(dev)
+        P = self.arch.patch
+        with torch.cuda.device(dev):
+            score, attn, mean_out = self._u8_out(B, N, H, W, dev, need_attn_weights, return_mean)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for b0, b1 in self._sub_batches(B, N, (H // P) * (W // P)):
+                _lib.check(lib.cs_forward_u8(handle, query.c_array(b0, b1), refs.c_array(b0 * N, b1 * N), b1 - b0, N, H, W, query.mean, query.std,
+                                             C.c_void_p(score[b0:b1].data_ptr()), C.c_void_p(attn[b0:b1].data_ptr()) if attn is not None else None,
+                                             int(need_attn_weights_head_id),
+                                             C.c_void_p(mean_out[b0:b1].data_ptr()) if mean_out is not None else None, C.c_void_p(stream)))
+        results = {"score_map_ref_cross": score, "attn_weights_map_ref_cross": attn}
+        if return_mean:
+            results["score_mean_ref_cross"] = mean_out
+        return results
+
+    @torch.no_grad()
+    def encode_references_u8(self, imgs: U8Batch):
+        """encode_references() from decoded uint8 images."""
+        R = len(imgs)
+        H, W = imgs.size
+        dev = imgs.device
+        if R == 0 or dev is None:
+            raise ValueError("expected at least one device image")
+        self._check_pe_mode(H, W)
+        P = self.arch.patch
+        handle = self._ensure_handle(dev)
+        with torch.cuda.device(dev):
+            tok = torch.empty((R, (H // P) * (W // P), self.arch.hidden), dtype=self.token_dtype, device=dev)
+            _lib.check(_lib.load().cs_encode_references_u8(handle, imgs.c_array(0, R), R, H, W, imgs.mean, imgs.std, C.c_void_p(tok.data_ptr()),
+                                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return tok
+
+    @torch.no_grad()
+    def forward_cached_u8(self, query: U8Batch, ref_tokens, need_attn_weights=False, need_attn_weights_head_id=0, return_mean=False):
+        """forward_cached() with the query images as decoded uint8."""
+        B = len(query)
+        H, W = query.size
+        dev = ref_tokens.device
+        if ref_tokens.dim() != 4 or ref_tokens.shape[0] != B or not ref_tokens.is_cuda or ref_tokens.dtype != self.token_dtype:
+            raise ValueError("expected CUDA ref_tokens (B,N,h*w,C) of this module's operand type")
+        t = ref_tokens.contiguous()
+        N = t.shape[1]
+        P = self.arch.patch
+        if t.shape[2] != (H // P) * (W // P) or t.shape[3] != self.arch.hidden:
+            raise ValueError("ref_tokens do not match the query's patch grid / hidden size")
+        self._check_pe_mode(H, W)
+        lib = _lib.load()
+        handle = self._ensure_handle(dev)
+        with torch.cuda.device(dev):
+            score, attn, mean_out = self._u8_out(B, N, H, W, dev, need_attn_weights, return_mean)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for b0, b1 in self._sub_batches(B, N, (H // P) * (W // P)):
+                _lib.check(lib.cs_forward_cached_u8(handle, query.c_array(b0, b1), C.c_void_p(t[b0:b1].data_ptr()), b1 - b0, N, H, W, query.mean, query.std,
+                                                    C.c_void_p(score[b0:b1].data_ptr()), C.c_void_p(attn[b0:b1].data_ptr()) if attn is not None else None,
+                                                    int(need_attn_weights_head_id),
+                                                    C.c_void_p(mean_out[b0:b1].data_ptr()) if mean_out is not None else None, C.c_void_p(stream)))
         results = {"score_map_ref_cross": score, "attn_weights_map_ref_cross": attn}
         if return_mean:
             results["score_mean_ref_cross"] = mean_out

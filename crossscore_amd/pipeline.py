@@ -116,13 +116,13 @@ class ForwardPipeline:
                 chosen.append(cand)
         return chosen
 
-    def calibrate(self, query_img, ref_cross_imgs, tries: int = 4, steps: int = 6, cached: bool = False) -> Dict[str, Any]:
+    def calibrate(self, query_img, ref_cross_imgs, tries: int = 4, steps: int = 6, cached: bool = False, u8: bool = False) -> Dict[str, Any]:
         """The HIP runtime multiplexes streams onto a few hardware queues, and two streams that land on one queue serialise: the
         replicas then run one after another (measured 9.0 instead of 6.7 ms per cfg-2 batch); which streams collide depends on
         what else the process created before.  This times `steps` batches one at a time on replica 0, then in flight on up to
         `tries` fresh sets of streams, and keeps the first set that beats the serial time by 15 % (else the fastest seen).  Call
         it once, outside any timed region, with inputs of the working shape; returns what it measured.  cached=True: the second argument
-        holds reference TOKENS (submit_cached: the predict driver's default mode)."""
+        holds reference TOKENS (submit_cached: the predict driver's default mode); u8=True: the images are model.U8Batch objects (the *_u8 calls)."""
         if self.depth == 1:
             return {"serial_s": None, "in_flight_s": []}
         import time
@@ -130,7 +130,10 @@ class ForwardPipeline:
         def in_flight(n):
             last = None
             for _ in range(n):
-                last = self.submit_cached(query_img, ref_cross_imgs) if cached else self.submit(query_img, ref_cross_imgs, False, 0, False)
+                if u8:
+                    last = self.submit_cached_u8(query_img, ref_cross_imgs) if cached else self.submit_u8(query_img, ref_cross_imgs)
+                else:
+                    last = self.submit_cached(query_img, ref_cross_imgs) if cached else self.submit(query_img, ref_cross_imgs, False, 0, False)
             self.result(last)
             torch.cuda.synchronize(self.device)
 
@@ -138,7 +141,9 @@ class ForwardPipeline:
         t0 = time.perf_counter()
         with torch.cuda.stream(self.streams[0]):
             for _ in range(steps):
-                if cached:
+                if u8:
+                    (self.nets[0].forward_cached_u8 if cached else self.nets[0].forward_u8)(query_img, ref_cross_imgs)
+                elif cached:
                     self.nets[0].forward_cached(query_img, ref_cross_imgs)
                 else:
                     self.nets[0](query_img, ref_cross_imgs, False, 0, False)
@@ -212,7 +217,7 @@ class ForwardPipeline:
             if self._marks is not None:
                 self._marks.append((i, a, ev))
         for a in list(args) + list(kwargs.values()):
-            if isinstance(a, torch.Tensor) and a.is_cuda:
+            if (isinstance(a, torch.Tensor) and a.is_cuda) or hasattr(a, "images"):  # (model.U8Batch: the decoded images of the one-pass input stage)
                 a.record_stream(s)  # the caching allocator must not recycle an input before the replica has read it
         return Ticket(out, ev, s)
 
@@ -223,6 +228,28 @@ class ForwardPipeline:
     def submit_cached(self, query_img, ref_tokens, *args, **kwargs) -> Ticket:
         """CrossScoreNet.forward_cached on the next replica; the tokens may come from any replica's encode_references."""
         return self._run("forward_cached", (query_img, ref_tokens) + args, kwargs)
+
+    def submit_u8(self, query, refs, *args, **kwargs) -> Ticket:
+        """CrossScoreNet.forward_u8 on the next replica (query / refs: model.U8Batch)."""
+        return self._run("forward_u8", (query, refs) + args, kwargs)
+
+    def submit_cached_u8(self, query, ref_tokens, *args, **kwargs) -> Ticket:
+        """CrossScoreNet.forward_cached_u8 on the next replica."""
+        return self._run("forward_cached_u8", (query, ref_tokens) + args, kwargs)
+
+    def encode_references_u8(self, imgs) -> torch.Tensor:
+        """CrossScoreNet.encode_references_u8 through replica 0 (see encode_references)."""
+        net = self.nets[0]
+        if self.depth == 1:
+            return net.encode_references_u8(imgs)
+        cur, s = torch.cuda.current_stream(self.device), self.streams[0]
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            tok = net.encode_references_u8(imgs)
+        cur.wait_stream(s)
+        imgs.record_stream(s)
+        tok.record_stream(cur)
+        return tok
 
     def encode_references(self, ref_imgs: torch.Tensor) -> torch.Tensor:
         """CrossScoreNet.encode_references through replica 0, ordered with that replica's own forwards (a handle's workspace serves

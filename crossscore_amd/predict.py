@@ -27,7 +27,8 @@ import torch
 
 from . import parallel, synth
 from .config import load_config
-from .data import InputStage, ReferenceTokenCache, SimpleReferenceItems, decode_items, load_batch, load_query_batch
+from .data import (InputStage, ReferenceTokenCache, SimpleReferenceItems, decode_items, load_batch, load_batch_u8, load_query_batch,
+                   load_query_batch_u8, read_image_u8)
 from .model import CrossScoreNet, load_lightning_checkpoint
 from .pipeline import ForwardPipeline
 from .writers import BatchWriter, ScoreSummariser
@@ -111,8 +112,23 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
     # module (pipeline.py), so one batch's decoder runs beside the next batch's encoder; outputs are consumed depth-1 submits later,
     # in batch order, bit-identical to the one-at-a-time loop
     pipe = ForwardPipeline(net, depth=max(1, int(cfg.this_main.get("batches_in_flight", 3))))
+    # this_main.fused_input_stage (this build's key, default "auto"): uint8 in, tokens out -- the resize / crop / normalise of the
+    # input stage happens inside the patch-embedding launch and no processed fp32 image is written.  The writers' image_query / image_reference
+    # outputs (on by default, as in the reference's config) ARE that processed image, so "auto" takes the one-pass form only when neither is
+    # written, and only for geometries it holds (cs_u8_input_supported); True insists, False never.  Results are bit-identical either way.
+    want_imgs = writer is not None and bool(cfg.logger.predict.write.flag.image_query or cfg.logger.predict.write.flag.image_reference)
+    fused_cfg = cfg.this_main.get("fused_input_stage", "auto")
+    fused_in = False
+    if fused_cfg not in (False, "false", "False", 0) and len(items) > lo and not want_imgs:
+        probe = read_image_u8(items[lo]["query/img"])
+        rs0, crop0 = stage.geometry(*probe.shape[:2])
+        from .model import U8Image
+        fused_in = net.u8_input_supported(U8Image(None, probe.shape[0], probe.shape[1], rs0, crop0[0], crop0[1]), crop0[2:], device)
+    if fused_cfg in (True, "true", "True", 1) and not fused_in:
+        raise ValueError("this_main.fused_input_stage=True, but " + ("the writers need the processed images (logger.predict.write.flag.image_query / "
+                         "image_reference)" if want_imgs else "this backbone / image geometry is not taken by the one-pass input stage"))
     cache = ReferenceTokenCache(pipe, stage, keep_images=bool(writer is not None and cfg.logger.predict.write.flag.image_reference),
-                                max_images=int(cfg.this_main.get("reference_cache_max_images", 4096))) if use_cache else None
+                                max_images=int(cfg.this_main.get("reference_cache_max_images", 4096)), from_u8=fused_in) if use_cache else None
     cached_paths = lambda: {k[0] for k in cache.tokens} if cache is not None else ()  # noqa: E731
     pending = prefetch.submit(decode_items, batches[0], zero_ref, pool, cached_paths()) if batches else None
     need_w, head_id = bool(cfg.model.need_attn_weights), int(cfg.model.need_attn_weights_head_id)
@@ -121,7 +137,7 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
     def consume(entry):
         ticket, batch, idx = entry
         out = pipe.result(ticket)
-        summariser.update(batch, out)
+        summariser.update(batch, out, means=out.get("score_mean_ref_cross"))  # the per-image means the head launch left (score_summariser.py:180-192)
         if writer is not None:
             files.extend(writer.write_out(batch, out, local_rank, idx))
 
@@ -132,23 +148,26 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
         decoded = pending.result()
         if cache is None:
             pending = prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool) if batch_idx + 1 < len(batches) else None
-            batch = load_batch(its, stage, zero_ref, decoded)
+            batch = (load_batch_u8 if fused_in else load_batch)(its, stage, zero_ref, decoded)
             if batch_idx == 0 and len(batches) >= 16:  # a long run: make sure the batches in flight really overlap (pipeline.py)
-                pipe.calibrate(batch["query/img"], batch["reference/cross/imgs"])
-                if pipe.depth == 1:  # one batch at a time: then it is the forward's two lanes that have to overlap (model.py)
+                pipe.calibrate(batch["query/img"], batch["reference/cross/imgs"], u8=fused_in)
+                if pipe.depth == 1 and not fused_in:  # one batch at a time: then it is the forward's two lanes that have to overlap (model.py)
                     net.calibrate_lanes(batch["query/img"], batch["reference/cross/imgs"])
-            ticket = pipe.submit(batch["query/img"], batch["reference/cross/imgs"], need_w, head_id, False)
+            if fused_in:
+                ticket = pipe.submit_u8(batch["query/img"], batch["reference/cross/imgs"], need_w, head_id, True)
+            else:
+                ticket = pipe.submit(batch["query/img"], batch["reference/cross/imgs"], need_w, head_id, False, return_mean=True)
         else:
-            batch, size = load_query_batch(its, stage, decoded)
+            batch, size = (load_query_batch_u8 if fused_in else load_query_batch)(its, stage, decoded)
             tokens, ref_imgs = cache.gather([it["reference/cross/imgs"] for it in its], decoded, size, zero_ref)
             batch["reference/cross/imgs"] = ref_imgs
             # (submitted after gather so that the set of cached paths is current; decoding overlaps the forward below)
             pending = (prefetch.submit(decode_items, batches[batch_idx + 1], zero_ref, pool, cached_paths())
                        if batch_idx + 1 < len(batches) else None)
             if batch_idx == 0 and len(batches) >= 16:  # the same check for the (default) cached mode
-                pipe.calibrate(batch["query/img"], tokens, cached=True)
-            ticket = pipe.submit_cached(batch["query/img"], tokens, need_w, head_id)
-        n_done += batch["query/img"].shape[0]
+                pipe.calibrate(batch["query/img"], tokens, cached=True, u8=fused_in)
+            ticket = (pipe.submit_cached_u8 if fused_in else pipe.submit_cached)(batch["query/img"], tokens, need_w, head_id, True)
+        n_done += len(batch["query/img"])
         queued.append((ticket, batch, batch_idx))
         while len(queued) >= pipe.depth:
             consume(queued.pop(0))
@@ -186,6 +205,7 @@ def predict(cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None, now: Opti
                                  "run with trainer.precision=bf16-mixed (model.backbone.operand_dtype=bf16); the outputs written are under "
                                  f"{cfg.logger.predict.out_dir}")
     return {"out_dir": cfg.logger.predict.out_dir, "files": files, "rows": summariser.rows,
+            "input_stage": "one-pass (uint8 in, tokens out)" if fused_in else "two-launch (uint8 -> fp32 image -> tokens)",
             "query_images_per_sec": n_done / t_loop if t_loop > 0 else 0.0}  # the whole scoring loop: input stage, forwards, output stage
 
 

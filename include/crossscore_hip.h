@@ -121,6 +121,30 @@ int cs_forward(cs_handle h, const float* query, const float* refs, int B, int N,
 int cs_encode_references(cs_handle h, const float* imgs, int R, int H, int W, uint16_t* tokens_out, cs_stream stream);
 int cs_forward_cached(cs_handle h, const float* query, const uint16_t* ref_tokens, int B, int N, int H, int W,
                       float* score_out, float* attn_out, int head_id, float* mean_out, cs_stream stream);
+/* The same three forwards fed from DECODED uint8 images (SURVEY.md 8f-4 as worded: uint8 in, tokens out).  Replaces, together with the patch
+ * embedding, the reference's CPU input transforms -- np.float32(img) / 255 (utils/io/images.py:14-29), T.Resize(short side, BILINEAR, antialias)
+ * (task/predict.py:87-93, nvs_dataset.py:218-225), the deterministic / integer-patch crop (dataloading/transformation/crop.py:8-25,
+ * nvs_dataset.py:227-241), T.Normalize (task/predict.py:68-74) -- inside the patch-embedding launch: no fp32 image tensor is written or read.  The
+ * strip of pixels a patch row needs is formed in LDS by the operations of cs_op_preprocess_u8 in their order, so the token rows, and with them every
+ * later value, are bit-identical to cs_op_preprocess_u8 + the fp32 entry point (tested).  query / refs / imgs are HOST arrays of descriptors (B; B * N,
+ * item-major; R); an image's `data` is DEVICE memory and must stay valid until the stream has passed the call; data == NULL is the all-zero placeholder
+ * image (nvs_dataset.py:459-470: zeros before T.Normalize).  Images of one call may differ in size and geometry, not in the H x W window.  mean3 /
+ * std3 are HOST pointers.  CS_ERR_UNSUPPORTED when the handle does not run the one-launch patch embedding (patch 14, hidden a multiple of 384) or a
+ * patch row reaches more source rows than the launch holds in LDS (1 170: a down-scale beyond ~70 x): cs_u8_input_supported asks beforehand. */
+typedef struct cs_u8_image {
+  const uint8_t* data;   /* device, HWC RGB, rows row_bytes apart; NULL: all-zero image */
+  int h, w, row_bytes;   /* decoded size */
+  int rs_h, rs_w;        /* size after T.Resize (== h, w: no resize) */
+  int crop_y, crop_x;    /* top-left corner of the H x W window inside the resized image */
+} cs_u8_image;
+int cs_forward_u8(cs_handle h, const cs_u8_image* query, const cs_u8_image* refs, int B, int N, int H, int W, const float* mean3, const float* std3,
+                  float* score_out, float* attn_out, int head_id, float* mean_out, cs_stream stream);
+int cs_encode_references_u8(cs_handle h, const cs_u8_image* imgs, int R, int H, int W, const float* mean3, const float* std3, uint16_t* tokens_out,
+                            cs_stream stream);
+int cs_forward_cached_u8(cs_handle h, const cs_u8_image* query, const uint16_t* ref_tokens, int B, int N, int H, int W, const float* mean3,
+                         const float* std3, float* score_out, float* attn_out, int head_id, float* mean_out, cs_stream stream);
+/* 1 when the three calls above take this image geometry on this handle, 0 when not (then: cs_op_preprocess_u8 + the fp32 entry points) */
+int cs_u8_input_supported(cs_handle h, const cs_u8_image* img, int H, int W);
 /* Overflow report.  With fp16 operands an activation beyond 65504 becomes inf and reaches the score map as NaN (nothing clamps in
  * the hot kernels); every forward counts the non-finite values of its score map on the device.  This call waits for the handle's last
  * forward, returns the count since the previous call in *count and resets it: > 0 means "switch to operand_dtype = 1 (bf16)". */
@@ -215,6 +239,11 @@ int cs_op_patch_embed(const float* x, const float* w, const float* bias, const f
  * Arguments and result as cs_op_patch_embed(centred = 1); CS_ERR_BAD_ARG for other shapes.  Replaces HF modeling_dinov2.py:141-149. */
 int cs_op_patch_embed_fused(const float* x, const float* w, const float* bias, const float* pos, int I, int H, int W, int P, int C,
                             float* out, cs_stream stream);
+/* The same launch fed from I decoded uint8 images of one size and geometry (test entry point of the one-pass input stage, cs_forward_u8):
+ * out = cs_op_patch_embed_fused applied to cs_op_preprocess_u8's output of every image, bit for bit. */
+int cs_op_patch_embed_fused_u8(const uint8_t* imgs, int I, int in_h, int in_w, int row_bytes, int rs_h, int rs_w, int crop_y, int crop_x, int H, int W,
+                               const float* mean3, const float* std3, const float* w, const float* bias, const float* pos, int P, int C, float* out,
+                               cs_stream stream);
 /* debug switch, process-wide (see cs_debug_* above): 0 = cs_forward goes back to im2col + GEMM for the patch embedding; default 1 */
 void cs_debug_patch_fused_enable(int on);
 /* Input stage: device uint8 HWC image (3 channels, rows in_row_bytes apart) -> fp32 CHW [3][out_h][out_w], the

@@ -208,6 +208,20 @@ def patch_embed_fused(x, w, bias, pos, P):
     return out
 
 
+def patch_embed_fused_u8(imgs_u8, rs, crop, mean, std, w, bias, pos, P):
+    """imgs_u8 (I, h, row_bytes) uint8 device, rows of w*3 bytes (+ padding) -> token rows as patch_embed_fused of the input stage's output"""
+    import ctypes as C
+    lib = _lib.load()
+    I, h, row = imgs_u8.shape
+    y0, x0, H, W, in_w = crop
+    C_ = w.shape[0]
+    Np = (H // P) * (W // P)
+    out = torch.full((I * (1 + Np), C_), 7.0, dtype=torch.float32, device=imgs_u8.device)
+    _lib.check(lib.cs_op_patch_embed_fused_u8(_p(imgs_u8), I, h, in_w, row, rs[0], rs[1], y0, x0, H, W, (C.c_float * 3)(*mean), (C.c_float * 3)(*std),
+                                              _p(w), _p(bias), _p(pos), P, C_, _p(out), _stream()))
+    return out
+
+
 def patch_embed(x, w, bias, pos, P, centred):
     """(I,3,H,W) images -> (I * (1 + Np), C) fp32 token rows (patch rows written, CLS rows left at 7.0)."""
     lib = _lib.load()

@@ -223,6 +223,47 @@ def test_reference_token_cache_gives_identical_outputs(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("use_cache", [True, False])
+def test_fused_input_stage_gives_identical_outputs(tmp_path, use_cache):
+    """this_main.fused_input_stage (uint8 in, tokens out: SURVEY.md 8f-4 as worded) on / off at the ViT-S width, with and without the reference
+    token cache: same files, same bytes in the score maps, the same CSV values.  "auto" takes the one-pass form exactly when the writers do not
+    ask for the processed images; insisting on it while they do is an error."""
+    from PIL import Image
+    from crossscore_amd.predict import predict
+
+    back = "synthetic/dinov2-small-2l"
+    qd, rd = _make_scene(str(tmp_path / "data"), n_query=5, n_ref=4, h=70, w=90)  # -> 56 x 72 (the one-launch patch embedding takes even widths)
+    from crossscore_amd.config import model_config
+    from crossscore_amd.model import CrossScoreNet
+    arch = CrossScoreNet(model_config(**{"backbone.from_pretrained": back})).arch
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(arch, 6).items()}
+    common = [f"data.dataset.query_dir={qd}", f"data.dataset.reference_dir={rd}", f"model.backbone.from_pretrained={back}",
+              "this_main.resize_short_side=56", "data.neighbour_config.cross=3", "data.loader.validation.batch_size=2",
+              f"this_main.cache_reference_tokens={use_cache}", "logger.predict.write.config.score_map_colour_mode=gray",
+              "logger.predict.write.flag.image_query=False", "logger.predict.write.flag.image_reference=False"]
+    outs = {}
+    for mode in ("auto", False):
+        np.random.seed(0)
+        outs[mode] = predict(load_config("default_predict", common + [f"logger.predict.out_dir={tmp_path}/out_{mode}", f"this_main.fused_input_stage={mode}"]),
+                             state_dict=sd, now="T")
+    a, b = outs["auto"], outs[False]
+    assert a["input_stage"] == "one-pass (uint8 in, tokens out)" and b["input_stage"].startswith("two-launch")
+    assert [r[:3] for r in a["rows"]] == [r[:3] for r in b["rows"]] and [r[3] for r in a["rows"]] == [r[3] for r in b["rows"]]
+    fa = sorted(f[len(a["out_dir"]):] for f in a["files"])
+    fb = sorted(f[len(b["out_dir"]):] for f in b["files"])
+    assert fa == fb and len(fa) > 5
+    for rel in fa:
+        if rel.endswith(".png"):
+            assert np.array_equal(np.array(Image.open(a["out_dir"] + rel)), np.array(Image.open(b["out_dir"] + rel))), rel
+    # the reference's default flags write the processed images: "auto" then stays with the two-launch stage, True is refused
+    with_imgs = [c for c in common if "flag.image" not in c]
+    c = predict(load_config("default_predict", with_imgs + [f"logger.predict.out_dir={tmp_path}/out_imgs"]), state_dict=sd, now="T")
+    assert c["input_stage"].startswith("two-launch") and [r[3] for r in c["rows"]] == [r[3] for r in a["rows"]]
+    with pytest.raises(ValueError):
+        predict(load_config("default_predict", with_imgs + [f"logger.predict.out_dir={tmp_path}/out_x", "this_main.fused_input_stage=True"]), state_dict=sd, now="T")
+
+
+@pytest.mark.gpu
 def test_output_stage_kernels_bit_exact():
     from crossscore_amd.writers import ScoreMapEncoder
 

@@ -116,6 +116,103 @@ def test_hip_preprocess_feeds_forward_bit_identically():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("backbone,dtype", [("synthetic/dinov2-small-2l", "fp16"), ("synthetic/dinov2-small-2l", "bf16"), ("synthetic/dinov2-base-2l", "fp16")])
+def test_forwards_fed_from_uint8_are_bit_identical(backbone, dtype):
+    """cs_forward_u8 / cs_encode_references_u8 / cs_forward_cached_u8 (uint8 in, tokens out: the input stage inside the patch-embedding launch)
+    against cs_op_preprocess_u8 + the fp32 entry points: score maps, means, attention-weight maps and reference tokens bit for bit; images of
+    different decoded sizes in one call, a placeholder reference (data = NULL = zeros before T.Normalize), a geometry the one-pass form refuses."""
+    import torch
+    from crossscore_amd.config import model_config
+    from crossscore_amd.data import InputStage
+    from crossscore_amd.model import CrossScoreNet, U8Image
+    from crossscore_amd import synth
+
+    net = CrossScoreNet(model_config(**{"backbone.from_pretrained": backbone}))
+    net.load_numpy_state_dict(synth.make_state_dict(net.arch, 3))
+    net.operand_dtype = dtype
+    net = net.cuda()
+    dev = torch.device("cuda:0")
+    stage = InputStage(dev, resize_short_side=70, integer_patches=True)
+    rng = np.random.Generator(np.random.PCG64(11))
+    B, N = 2, 2
+    # 4:3 images of two decoded sizes, both -> 70 x 93 -> the 70 x 84 window
+    sizes = [(120, 160), (90, 120), (120, 160), (150, 200), (90, 120), (120, 160)]
+    imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    size = stage.geometry(*sizes[0])[1][2:]
+    assert all(stage.geometry(h, w)[1][2:] == size for h, w in sizes) and size == (70, 84)
+    q32 = torch.empty((B, 3) + size, device=dev)
+    r32 = torch.empty((B, N, 3) + size, device=dev)
+    for b in range(B):
+        stage(imgs[b], q32[b])
+    refs_u8 = []
+    for b in range(B):
+        for n in range(N):
+            if (b, n) == (1, 1):  # a placeholder of a short reference list
+                r32[b, n] = stage.zero_image_value[:, None, None]
+                refs_u8.append(stage.placeholder(size))
+            else:
+                stage(imgs[B + b * N + n], r32[b, n])
+                refs_u8.append(stage.describe(imgs[B + b * N + n]))
+    q_u8 = stage.batch([stage.describe(imgs[b]) for b in range(B)], size)
+    r_u8 = stage.batch(refs_u8, size)
+    assert net.u8_input_supported(q_u8.images[0], size)
+    want = net(q32, r32, True, 3, False, return_mean=True)
+    got = net.forward_u8(q_u8, r_u8, True, 3, True)
+    torch.cuda.synchronize()
+    for k in ("score_map_ref_cross", "score_mean_ref_cross", "attn_weights_map_ref_cross"):
+        assert torch.equal(got[k], want[k]), k
+    tok32 = net.encode_references(r32.reshape((B * N, 3) + size))
+    tok_u8 = net.encode_references_u8(r_u8)
+    assert torch.equal(tok_u8, tok32)
+    cached = net.forward_cached_u8(q_u8, tok_u8.reshape((B, N) + tuple(tok_u8.shape[1:])), False, 0, True)
+    torch.cuda.synchronize()
+    assert torch.equal(cached["score_map_ref_cross"], want["score_map_ref_cross"]) and torch.equal(cached["score_mean_ref_cross"], want["score_mean_ref_cross"])
+    stats = net.forward_stats()
+    assert stats["kernels"].get("patch_u8", 0) >= 1 and "patch" not in stats["kernels"], stats["kernels"]
+    # a 114 x down-scale: 14 pixel rows reach 1 800 source rows, more than the launch holds for even one patch per run (1 170)
+    far = U8Image(None, 8000, 9600, (70, 84), 0, 0)
+    assert not net.u8_input_supported(far, size, dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,short,crop,pad", [
+    (70, 84, 0, None, 0),              # no resize (identity tables), 5 x 6 patches
+    (90, 131, 70, None, 3),            # down 1.29 x, window 70 x 98 of the 70 x 101 image (integer patches), padded source rows
+    (45, 60, 98, (5, 10, 84, 112), 0), # up 2.2 x, crop window off the corner
+    (300, 410, 56, None, 1),           # down 5.4 x: 14 pixel rows reach 87 source rows
+    (777, 1036, 518, None, 0),         # the BASELINE geometry from a 4:3 photo: 518 x 686 window, 37 x 49 patches -> two runs per patch row
+    (2100, 2100, 518, None, 0),        # down 4.05 x at full width: the run is cut so that the source rows fit the LDS buffer
+])
+def test_patch_embedding_straight_from_uint8_is_bit_identical(h, w, short, crop, pad):
+    """SURVEY.md 8f-4 as worded (uint8 in, tokens out; task/predict.py:68-93, nvs_dataset.py:218-241): the one-pass form repeats the operations of
+    cs_op_preprocess_u8 inside the patch-embedding launch, so its token rows are those of the two-launch path bit for bit -- whatever the scale,
+    the crop, the row padding and the number of runs a patch row is cut into."""
+    import torch
+    import hip_helpers as hh
+
+    P, Cc = 14, 384
+    rng = np.random.Generator(np.random.PCG64(h * 7 + w))
+    imgs = rng.integers(0, 256, size=(2, h, w, 3), dtype=np.uint8)
+    imgs[1, ..., 1] = ((np.arange(h)[:, None] * 3 + np.arange(w)[None, :] * 2) % 256).astype(np.uint8)
+    rs = po.resized_output_size(h, w, short) if short else (h, w)
+    if crop is None:
+        crop = (0, 0, rs[0] - rs[0] % P, rs[1] - rs[1] % P)
+    if crop[3] % 2:
+        crop = (crop[0], crop[1], crop[2], crop[3] - P)  # (the one-launch patch embedding takes even widths)
+    y0, x0, H, W = crop
+    two = np.stack([_hip_preprocess(im, rs, crop, pad_row=pad) for im in imgs])
+    wgt = torch.from_numpy((rng.standard_normal((Cc, 3, P, P)) / 24).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(Cc).astype(np.float32)).cuda()
+    pos = torch.from_numpy(rng.standard_normal((1 + (H // P) * (W // P), Cc)).astype(np.float32)).cuda()
+    ref = hh.patch_embed_fused(torch.from_numpy(two).cuda(), wgt, bias, pos, P)
+    buf = np.zeros((2, h, w * 3 + pad), np.uint8)
+    buf[:, :, : w * 3] = imgs.reshape(2, h, w * 3)
+    got = hh.patch_embed_fused_u8(torch.from_numpy(buf).cuda(), rs, (y0, x0, H, W, w), po.IMAGENET_MEAN, po.IMAGENET_STD, wgt, bias, pos, P)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.gpu
 def test_hip_preprocess_bad_arguments():
     img = np.zeros((20, 30, 3), np.uint8)
     with pytest.raises(Exception):

@@ -19,10 +19,17 @@ for i in range(32): Image.fromarray(img(i)).save(os.path.join(qd, f"frame_{i:05}
 for i in range(20): Image.fromarray(img(100 + i)).save(os.path.join(rd, f"frame_{i:05}.png"))
 arch = CrossScoreNet(model_config()).arch
 sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(arch, 1).items()}
-for cache in (True, False):
-    for write in (True, False):
-        cfg = load_config("default_predict", [f"data.dataset.query_dir={qd}", f"data.dataset.reference_dir={rd}", f"this_main.cache_reference_tokens={cache}",
-                                              f"logger.predict.out_dir={root}/out_{cache}_{write}", f"logger.predict.write.flag.batch={write}"])
-        t0 = time.perf_counter(); res = predict(cfg, state_dict=sd, now="T"); dt = time.perf_counter() - t0
-        print(json.dumps({"cache_reference_tokens": cache, "write_png": write, "wall_s": round(dt, 2), "query_images_per_sec_wall": round(32 / dt, 1),
-                          "query_images_per_sec_model_only": round(res["query_images_per_sec"], 1), "files": len(res["files"])}), flush=True)
+# write: "all" = the reference's default flags (score maps + the processed query / reference images), "maps" = score maps only, False = nothing;
+# fused = this_main.fused_input_stage (uint8 in, tokens out; "auto" takes it when no processed image is written)
+for rnd in range(2):  # (the first round pays table builds, stream probes and page-ins)
+    for cache in (True, False):
+        for write, fused in (("all", "auto"), ("maps", False), ("maps", "auto"), (False, False), (False, "auto")):
+            over = [f"data.dataset.query_dir={qd}", f"data.dataset.reference_dir={rd}", f"this_main.cache_reference_tokens={cache}",
+                    f"logger.predict.out_dir={root}/out_{rnd}_{cache}_{write}_{fused}", f"logger.predict.write.flag.batch={bool(write)}",
+                    f"this_main.fused_input_stage={fused}"]
+            if write == "maps":
+                over += ["logger.predict.write.flag.image_query=False", "logger.predict.write.flag.image_reference=False"]
+            t0 = time.perf_counter(); res = predict(load_config("default_predict", over), state_dict=sd, now="T"); dt = time.perf_counter() - t0
+            print(json.dumps({"round": rnd, "cache_reference_tokens": cache, "write_png": write, "input_stage": res["input_stage"].split(" ")[0],
+                              "wall_s": round(dt, 2), "query_images_per_sec_wall": round(32 / dt, 1),
+                              "query_images_per_sec_loop": round(res["query_images_per_sec"], 1), "files": len(res["files"])}), flush=True)
