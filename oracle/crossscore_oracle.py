@@ -219,10 +219,20 @@ def dinov2_encoder(imgs: Tensor, Wt: Dict[str, Tensor], enc_heads: int, P: int, 
         a = linear(a, Wt[p + "attention.output.dense.weight"], Wt[p + "attention.output.dense.bias"], rnd)
         x = x + a * Wt[p + "layer_scale1.lambda1"]
         u = layer_norm(x, Wt[p + "norm2.weight"], Wt[p + "norm2.bias"], 1e-6)
-        m = gelu_erf(linear(u, Wt[p + "mlp.fc1.weight"], Wt[p + "mlp.fc1.bias"], rnd))
-        if taps is not None:
-            taps[f"enc_mlp_hidden_absmax_{l}"] = m.abs().amax(dim=(0, 1))  # per hidden unit (range tests of the 16-bit operand types)
-        m = linear(m, Wt[p + "mlp.fc2.weight"], Wt[p + "mlp.fc2.bias"], rnd)
+        if p + "mlp.weights_in.weight" in Wt:
+            # Dinov2SwiGLUFFN (HF modeling_dinov2.py:300-316, use_swiglu_ffn: facebook/dinov2-giant): x1, x2 = weights_in(u).chunk(2, -1);
+            # weights_out(silu(x1) * x2)
+            x12 = linear(u, Wt[p + "mlp.weights_in.weight"], Wt[p + "mlp.weights_in.bias"], rnd)
+            x1, x2 = x12.chunk(2, dim=-1)
+            m = x1 * torch.sigmoid(x1) * x2
+            if taps is not None:
+                taps[f"enc_mlp_hidden_absmax_{l}"] = m.abs().amax(dim=(0, 1))
+            m = linear(m, Wt[p + "mlp.weights_out.weight"], Wt[p + "mlp.weights_out.bias"], rnd)
+        else:
+            m = gelu_erf(linear(u, Wt[p + "mlp.fc1.weight"], Wt[p + "mlp.fc1.bias"], rnd))
+            if taps is not None:
+                taps[f"enc_mlp_hidden_absmax_{l}"] = m.abs().amax(dim=(0, 1))  # per hidden unit (range tests of the 16-bit operand types)
+            m = linear(m, Wt[p + "mlp.fc2.weight"], Wt[p + "mlp.fc2.bias"], rnd)
         x = x + m * Wt[p + "layer_scale2.lambda1"]
         if taps is not None:
             taps[f"enc_layer_{l}"] = x.clone()

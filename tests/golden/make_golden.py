@@ -55,7 +55,7 @@ def _import_reference():
 
 def _patch_backbone(Dinov2Config, Dinov2Model, arch: synth.ArchSpec):
     kw = dict(hidden_size=arch.hidden, num_hidden_layers=arch.enc_layers, num_attention_heads=arch.enc_heads,
-              image_size=arch.pos_grid * arch.patch, patch_size=arch.patch, mlp_ratio=arch.mlp_ratio)
+              image_size=arch.pos_grid * arch.patch, patch_size=arch.patch, mlp_ratio=arch.mlp_ratio, use_swiglu_ffn=bool(arch.swiglu))
     Dinov2Config.from_pretrained = classmethod(lambda cls, *_a, **_k: cls(**kw))
     Dinov2Model.from_pretrained = classmethod(lambda cls, *_a, **_k: cls(Dinov2Config(**kw)))
 
@@ -265,6 +265,25 @@ def main():
         np.savez_compressed(os.path.join(HERE, "g8_vits_width_all.npz"), seed=8, B=Bq, N=Nq, H=Hq, W=Wq,
                             score=out["score_map_ref_cross"].numpy(), attn_head3=out["attn_weights_map_ref_cross"].numpy(), **taps)
         print("g8 done", out["score_map_ref_cross"].shape, {k: v.shape for k, v in taps.items()})
+
+    # G9 (round 6): the SwiGLU MLP of facebook/dinov2-giant (HF Dinov2SwiGLUFFN, use_swiglu_ffn) -- the giant's width (1536, decoder heads of 192
+    # channels) and the base width, two encoder layers each; B = 2, N = 2, 98 x 112; the last encoder layer's output of image 0 beside the map
+    if want("g9"):
+        for tag, key, seed in (("g9_swiglu_base_width", "synthetic/dinov2-swiglu-2l", 9), ("g9_swiglu_giant_width", "synthetic/dinov2-giant-2l", 19)):
+            a9 = synth.BACKBONES[key]
+            _patch_backbone(DC, DM, a9)
+            net = core.CrossScoreNet(make_cfg(a9)).eval()
+            assert type(net.backbone.encoder.layer[0].mlp).__name__ == "Dinov2SwiGLUFFN"
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(a9, seed).items()}, strict=True)
+            q, r = synth.make_inputs(2, 2, 98, 112, seed)
+            taps = {}
+            hk = net.backbone.encoder.layer[-1].register_forward_hook(
+                lambda m, i, o: taps.__setitem__("enc_last_img0", (o[0] if isinstance(o, tuple) else o)[0].detach().numpy().copy()))
+            with torch.no_grad():
+                out = net(torch.from_numpy(q), torch.from_numpy(r), False, 0, False)
+            hk.remove()
+            np.savez_compressed(os.path.join(HERE, tag + ".npz"), seed=seed, B=2, N=2, H=98, W=112, score=out["score_map_ref_cross"].numpy(), **taps)
+            print(tag, "done", out["score_map_ref_cross"].shape, taps["enc_last_img0"].shape)
 
     def big(name, arch, seed, B, N, H, W):
         _, out, dt = run_reference(core, DC, DM, arch, seed, B, N, H, W)

@@ -70,6 +70,22 @@ VARIANTS = {
 }
 
 
+@pytest.mark.parametrize("tag,key", [("g9_swiglu_base_width", "synthetic/dinov2-swiglu-2l"), ("g9_swiglu_giant_width", "synthetic/dinov2-giant-2l")])
+def test_g9_swiglu_mlp(golden_dir, tag, key):
+    """g9: the SwiGLU MLP of facebook/dinov2-giant (HF Dinov2SwiGLUFFN: weights_in -> chunk -> silu(x1) * x2 -> weights_out) at the giant's and at
+    the base width, from the imported reference: the last encoder layer's rows of image 0 and the score map."""
+    arch = synth.BACKBONES[key]
+    assert arch.swiglu and arch.ffn_hidden == {768: 2048, 1536: 4096}[arch.hidden]
+    g = _golden(golden_dir, tag + ".npz")
+    W = orc.to_torch(synth.make_state_dict(arch, int(g["seed"])))
+    q, r = synth.make_inputs(int(g["B"]), int(g["N"]), int(g["H"]), int(g["W"]), int(g["seed"]))
+    taps = {}
+    out = orc.forward(W, dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r), False, 0, taps=taps)
+    last = taps[f"enc_layer_{arch.enc_layers - 1}"][0].numpy()
+    assert np.abs(last - g["enc_last_img0"]).max() < TOL * max(1.0, float(np.abs(g["enc_last_img0"]).max()))
+    assert np.abs(out["score_map_ref_cross"].numpy() - g["score"]).max() < TOL
+
+
 @pytest.mark.parametrize("name", sorted(VARIANTS))
 def test_g5_flag_variants(golden_dir, name):
     g = _golden(golden_dir, "g5_tiny_flags.npz")
