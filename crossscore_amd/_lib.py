@@ -22,7 +22,7 @@ class CsConfig(C.Structure):
         ("patch", C.c_int), ("pos_grid", C.c_int), ("pe_h", C.c_int), ("pe_w", C.c_int),
         ("dec_layers", C.c_int), ("dec_heads", C.c_int), ("do_self_attn", C.c_int), ("do_short_cut", C.c_int),
         ("act", C.c_int), ("pow_p", C.c_float), ("enc_chunk_images", C.c_int), ("ln_fold", C.c_int), ("lanes", C.c_int), ("pos_interp_legacy", C.c_int), ("enc_fused", C.c_int),
-        ("operand_dtype", C.c_int), ("pe_interp_mode", C.c_int), ("skip_finite_check", C.c_int),
+        ("operand_dtype", C.c_int), ("pe_interp_mode", C.c_int), ("skip_finite_check", C.c_int), ("swiglu", C.c_int),
     ]
 
 

@@ -52,6 +52,7 @@ hipError_t cs_pe_interp_launch(const float* pe, int ph, int pw, int C, int gh, i
 hipError_t cs_pack_f16_launch(const float* w, int rows, int K, h16_t* out, int ldo, const float* row_scale, const float* col_scale,
                                int bf, hipStream_t st);
 hipError_t cs_score_check_launch(const float* score, size_t n, unsigned* counter, hipStream_t st);
+hipError_t cs_silu_mul_launch(h16_t* x, int M, int F, int ld, int bf, hipStream_t st);
 hipError_t cs_vec_mul_launch(const float* a, const float* b, float* out, int n, hipStream_t st);
 hipError_t cs_spin_launch(unsigned long long ticks, int blocks, int lds_bytes, hipStream_t st);
 constexpr float LOG2E = 1.4426950408889634f;
@@ -193,9 +194,10 @@ std::vector<std::string> expected_names(const cs_config& c) {
     for (const char* s : {"norm1.weight", "norm1.bias", "attention.attention.query.weight", "attention.attention.query.bias",
                           "attention.attention.key.weight", "attention.attention.key.bias", "attention.attention.value.weight",
                           "attention.attention.value.bias", "attention.output.dense.weight", "attention.output.dense.bias",
-                          "layer_scale1.lambda1", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
-                          "mlp.fc2.bias", "layer_scale2.lambda1"})
+                          "layer_scale1.lambda1", "norm2.weight", "norm2.bias", "layer_scale2.lambda1"})
       n.push_back(p + s);
+    if (c.swiglu) for (const char* s : {"mlp.weights_in.weight", "mlp.weights_in.bias", "mlp.weights_out.weight", "mlp.weights_out.bias"}) n.push_back(p + s);
+    else for (const char* s : {"mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"}) n.push_back(p + s);
   }
   n.push_back("backbone.layernorm.weight"); n.push_back("backbone.layernorm.bias");
   n.push_back("pos_enc_fn.PE");
@@ -213,6 +215,12 @@ std::vector<std::string> expected_names(const cs_config& c) {
   for (const char* s : {"ref_cross.head.0.weight", "ref_cross.head.0.bias", "ref_cross.head.2.weight", "ref_cross.head.2.bias"})
     n.push_back(s);
   return n;
+}
+
+// hidden features of the encoder's MLP: mlp_ratio * hidden, or the SwiGLU form's (int(hidden * mlp_ratio * 2 / 3) + 7) / 8 * 8 (HF modeling_dinov2.py:303-305)
+int ffn_hidden(const cs_config& c) {
+  const int f = c.mlp_ratio * c.hidden;
+  return c.swiglu ? ((int)((double)f * 2 / 3) + 7) / 8 * 8 : f;
 }
 
 bool supported_dh(int dh) { return dh == 16 || dh == 48 || dh == 64 || dh == 96 || dh == 128; }
@@ -269,7 +277,7 @@ Plan make_plan(const cs_model* m, int B, int N, int N_enc, int H, int W, char* b
   for (int l = 0; l < nsets; ++l) {
     p.x[l] = a.take<float>(Mc * C);
     p.u[l] = a.take<h16_t>(Mc * C);
-    p.r1[l] = a.take<h16_t>(std::max(Mc * (size_t)c.mlp_ratio * C, std::max(Mc * (size_t)m->qkv_n, (size_t)p.Ic * p.Np * m->Kp)));
+    p.r1[l] = a.take<h16_t>(std::max(Mc * (size_t)(c.swiglu ? 2 * ffn_hidden(c) : ffn_hidden(c)), std::max(Mc * (size_t)m->qkv_n, (size_t)p.Ic * p.Np * m->Kp)));
     p.ob[l] = a.take<h16_t>(m->lnfold || m->fold256 ? Mc * C : 0);
     p.pmean[l] = a.take<float>((size_t)p.Ic * p.Np * 4);
     const size_t Mpad = (Mc + 255) / 256 * 256;
@@ -478,6 +486,9 @@ cs_handle cs_create(const cs_config* cfg) {
   if (c.pe_interp_mode != 0 && c.pe_interp_mode != 1) { fail(CS_ERR_BAD_ARG, "pe_interp_mode must be 0 (bilinear) or 1 (bicubic)"); return nullptr; }
   if (c.operand_dtype != 0 && c.operand_dtype != 1) { fail(CS_ERR_BAD_ARG, "operand_dtype must be 0 (fp16) or 1 (bf16)"); return nullptr; }
   if (c.operand_dtype == 1 && c.ln_fold == 1) { fail(CS_ERR_UNSUPPORTED, "the LayerNorm-folded epilogues (ln_fold = 1) are built for fp16 operands only"); return nullptr; }
+  if (c.swiglu != 0 && c.swiglu != 1) { fail(CS_ERR_BAD_ARG, "swiglu must be 0 or 1"); return nullptr; }
+  if (c.swiglu && ffn_hidden(c) % 64) { fail(CS_ERR_UNSUPPORTED, "SwiGLU hidden features %d must be a multiple of 64 (the GEMM's K)", ffn_hidden(c)); return nullptr; }
+  if (c.swiglu && c.ln_fold == 1) { fail(CS_ERR_UNSUPPORTED, "ln_fold = 1 is built for the GELU MLP only"); return nullptr; }
   cs_model* m = new cs_model();
   m->cfg = c;
   m->names = expected_names(c);
@@ -489,10 +500,10 @@ cs_handle cs_create(const cs_config* cfg) {
   // at the 256-register limit and their tile-switch loads drain the LDS-DMA queue)
   m->lnfold = c.ln_fold == 1 && (m->ln_sp == 4 || m->ln_sp == 8 || m->ln_sp == 16);
   // default for ViT-S: out-proj + norm2 + MLP + next norm1 in one launch per layer, the 4C hidden never leaves the registers
-  m->panel = c.enc_fused != 1 && !m->lnfold && cs_panel_supported(c.hidden, c.mlp_ratio);
+  m->panel = c.enc_fused != 1 && !m->lnfold && !c.swiglu && cs_panel_supported(c.hidden, c.mlp_ratio);
   m->panel_impl = g_panel_impl;
   // wide backbones (r5): the encoder's LayerNorms ride in the 256-tile GEMM's epilogues; ln_fold = 2 keeps the separate LayerNorm launches
-  m->fold256 = c.ln_fold == 0 && !m->panel && c.hidden >= 512 && c.hidden % 256 == 0 && (c.mlp_ratio * c.hidden) % 256 == 0;
+  m->fold256 = c.ln_fold == 0 && !m->panel && !c.swiglu && c.hidden >= 512 && c.hidden % 256 == 0 && (c.mlp_ratio * c.hidden) % 256 == 0;
   return m;
 }
 
@@ -572,7 +583,7 @@ int cs_finalize(cs_handle h) {
   if (!h) return fail(CS_ERR_BAD_ARG, "null handle");
   if (h->finalized) return 0;
   const cs_config& c = h->cfg;
-  const int64_t C = c.hidden, P = c.patch, F = (int64_t)c.mlp_ratio * C;
+  const int64_t C = c.hidden, P = c.patch, F = ffn_hidden(c), F1 = c.swiglu ? 2 * F : F;  // F1: rows of the first projection (x1 | x2 for SwiGLU)
   auto need = [&](const std::string& n, std::vector<int64_t> shp) -> Tensor* {
     auto it = h->w.find(n);
     if (it == h->w.end()) { fail(CS_ERR_STATE, "missing key %s", n.c_str()); return nullptr; }
@@ -632,8 +643,8 @@ int cs_finalize(cs_handle h) {
     NEED(vw, p + "attention.attention.value.weight", C, C) NEED(vb, p + "attention.attention.value.bias", C)
     NEED(ow, p + "attention.output.dense.weight", C, C) NEED(ob, p + "attention.output.dense.bias", C)
     NEED(l1, p + "layer_scale1.lambda1", C) NEED(l2, p + "layer_scale2.lambda1", C)
-    NEED(f1w, p + "mlp.fc1.weight", F, C) NEED(f1b, p + "mlp.fc1.bias", F)
-    NEED(f2w, p + "mlp.fc2.weight", C, F) NEED(f2b, p + "mlp.fc2.bias", C)
+    NEED(f1w, p + (c.swiglu ? "mlp.weights_in.weight" : "mlp.fc1.weight"), F1, C) NEED(f1b, p + (c.swiglu ? "mlp.weights_in.bias" : "mlp.fc1.bias"), F1)
+    NEED(f2w, p + (c.swiglu ? "mlp.weights_out.weight" : "mlp.fc2.weight"), C, F) NEED(f2b, p + (c.swiglu ? "mlp.weights_out.bias" : "mlp.fc2.bias"), C)
     L.ln1g = n1w->d; L.ln1b = n1b->d; L.ln2g = n2w->d; L.ln2b = n2b->d; L.b1 = f1b->d;
     // LayerScale (x += lambda * (a Wo^T + bo), HF:367-370,376-378) is folded into the projection: rows of Wo / W2 and the
     // biases are scaled by lambda once, so the GEMM epilogue is a plain residual add
@@ -652,9 +663,9 @@ int cs_finalize(cs_handle h) {
     if (int r = pack(vw->d, (int)C, (int)C, (int)C, wqkv + 2 * C * C, nullptr, g1)) return r;
     HIPCHK(cs_vec_mul_launch(qb->d, qs_enc, bqkv, (int)C, st));
     D2D(bqkv + C, kb->d, C); D2D(bqkv + 2 * C, vb->d, C);
-    ALLOC_BF(wo, (size_t)C * C) ALLOC_BF(w1, (size_t)F * C) ALLOC_BF(w2, (size_t)C * F)
+    ALLOC_BF(wo, (size_t)C * C) ALLOC_BF(w1, (size_t)F1 * C) ALLOC_BF(w2, (size_t)C * F)
     if (int r = pack(ow->d, (int)C, (int)C, (int)C, wo, l1->d)) return r;
-    if (int r = pack(f1w->d, (int)F, (int)C, (int)C, w1, nullptr, g2)) return r;
+    if (int r = pack(f1w->d, (int)F1, (int)C, (int)C, w1, nullptr, g2)) return r;
     if (int r = pack(f2w->d, (int)C, (int)F, (int)F, w2, l2->d)) return r;
     L.Wqkv = wqkv; L.bqkv = bqkv; L.Wo = wo; L.W1 = w1; L.W2 = w2;
     L.s_qkv = L.c_qkv = L.s_1 = L.c_1 = nullptr;
@@ -868,7 +879,7 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
     sl.used = true;
   }
   const int enc_dh = C / c.enc_heads, dec_dh = C / c.dec_heads;
-  const int F = c.mlp_ratio * C;
+  const int F = ffn_hidden(c);
   const int KV = 2 * C * c.dec_layers;
   const int bf = c.operand_dtype;  // 16-bit operand type of every activation buffer and packed weight: 0 IEEE half, 1 bfloat16
 
@@ -1093,6 +1104,16 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
         L.gemm(g, CS_EPI_RESID_F32);
       }
       L.begin(32, 0); L.misc(cs_layernorm_launch(x, Mc, C, pf ? h->ones : E.ln2g, pf ? h->zeros : E.ln2b, 1e-6f, nullptr, u, bf, s), "ln2"); L.end();
+      if (c.swiglu) {
+        // Dinov2SwiGLUFFN (HF:300-316): [x1 | x2] = LN2(x) Win^T + b (2F columns), hidden = silu(x1) * x2 in place over the x1 half, x += hidden Wout'^T + b'
+        L.gemm(gp(u, C, E.W1, C, Mc, 2 * F, C, E.b1, r1, 2 * F), CS_EPI_BIAS_F16);
+        L.begin(32, 0, 6.0 * Mc * F); L.misc(cs_silu_mul_launch(r1, Mc, F, 2 * F, bf, s), "silu_mul"); L.end();
+        CsGemmParams g = gp(r1, 2 * F, E.W2, F, Mc, C, F, E.b2, x, C);
+        g.resid = x; g.ldr = C;
+        L.gemm(g, CS_EPI_RESID_F32);
+        tap_layer(l);
+        continue;
+      }
       L.gemm(gp(u, C, E.W1, C, Mc, F, C, pf ? E.c_1 : E.b1, r1, F), CS_EPI_BIAS_GELU_F16);
       {
         CsGemmParams g = gp(r1, F, E.W2, F, Mc, C, F, E.b2, x, C);

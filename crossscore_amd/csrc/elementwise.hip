@@ -448,6 +448,31 @@ __global__ void spin_kernel(unsigned long long ticks) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// The gate of Dinov2SwiGLUFFN (HF modeling_dinov2.py:311-315: x1, x2 = weights_in(u).chunk(2, -1); hidden = silu(x1) * x2), in place on the 16-bit
+// rows the weights_in projection wrote: x[m][j] = silu(x[m][j]) * x[m][F + j], j < F, rows `ld` (>= 2 F) apart; fp32 arithmetic, one rounding.
+// 8 values per thread (16-byte accesses; F % 8 == 0).
+__global__ __launch_bounds__(256) void silu_mul_kernel(h16_t* __restrict__ x, long long n8, int F8, int ld, int bf) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const long long m = i / F8;
+  const int j = (int)(i - m * F8) * 8;
+  h16_t* row = x + m * ld;
+  const uint4 a = *reinterpret_cast<const uint4*>(row + j), b = *reinterpret_cast<const uint4*>(row + F8 * 8 + j);
+  const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+  unsigned ow[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float r[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float x1 = o2f((h16_t)(aw[k] >> (16 * e)), bf), x2 = o2f((h16_t)(bw[k] >> (16 * e)), bf);
+      r[e] = x1 / (1.0f + __expf(-x1)) * x2;
+    }
+    ow[k] = pack_o16x2(r[0], r[1], bf);
+  }
+  *reinterpret_cast<uint4*>(row + j) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+
 // number of non-finite values of the score map, added to a device counter (cs_nonfinite_count): an fp16 operand that overflowed upstream
 // (|x| > 65504 -> inf -> NaN in the next LayerNorm / softmax) reaches every pixel of its image as NaN, so the output is where it shows
 __global__ __launch_bounds__(256) void score_check_kernel(const float* __restrict__ score, size_t n, unsigned* __restrict__ counter) {
@@ -484,6 +509,12 @@ extern "C" {
 
 hipError_t cs_ln_finalize_launch(const float* part, int M, int rows_padded, int sp, int C, float eps, float* stat, hipStream_t st) {
   hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows_padded + 255) / 256), dim3(256), 0, st, part, M, rows_padded, sp, 1.0f / (float)C, eps, stat);
+  return hipGetLastError();
+}
+
+hipError_t cs_silu_mul_launch(h16_t* x, int M, int F, int ld, int bf, hipStream_t st) {
+  const long long n8 = (long long)M * (F / 8);
+  hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, x, n8, F / 8, ld, bf);
   return hipGetLastError();
 }
 

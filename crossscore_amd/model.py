@@ -60,7 +60,7 @@ def arch_from_cfg(cfg) -> ArchSpec:
         a = BACKBONES[name]
     elif all(k in bb for k in ("hidden_size", "num_hidden_layers", "num_attention_heads")):
         a = ArchSpec(hidden=int(bb.hidden_size), enc_layers=int(bb.num_hidden_layers), enc_heads=int(bb.num_attention_heads),
-                     pos_grid=int(bb.get("image_size", 518)) // int(m.patch_size), name=str(name))
+                     pos_grid=int(bb.get("image_size", 518)) // int(m.patch_size), name=str(name), swiglu=bool(bb.get("use_swiglu_ffn", False)))
     else:
         raise ValueError(f"unknown backbone '{name}': known {sorted(BACKBONES)} (or give explicit sizes in cfg.model.backbone)")
     return dataclasses.replace(a, patch=int(m.patch_size), pe_h=int(m.pos_enc.multi_view.h), pe_w=int(m.pos_enc.multi_view.w),
@@ -243,7 +243,7 @@ class CrossScoreNet(torch.nn.Module):
                            do_self_attn=int(bool(m.decoder_do_self_attn)), do_short_cut=int(bool(m.decoder_do_short_cut)),
                            act=self._act, pow_p=self._pow, enc_chunk_images=int(self.enc_chunk_images), ln_fold=int(self.ln_fold),
                            lanes=int(self.lanes), pos_interp_legacy=int(self._pos_legacy), enc_fused=int(self.enc_fused),
-                           operand_dtype=self._operand_code(), pe_interp_mode=int(self._pe_mode), skip_finite_check=int(not self.finite_check))
+                           operand_dtype=self._operand_code(), pe_interp_mode=int(self._pe_mode), skip_finite_check=int(not self.finite_check), swiglu=int(bool(a.swiglu)))
         with torch.cuda.device(device):
             h = lib.cs_create(C.byref(cc))
             if not h:

@@ -83,6 +83,10 @@ typedef struct cs_config {
                        * tensor with align_corners=True, so these two are all the reference can run. */
   int skip_finite_check; /* 0 = default: every forward ends with a pass over the score map that counts non-finite values into a device
                        * counter (cs_nonfinite_count; ~3 us); 1 = skip it */
+  int swiglu;         /* encoder MLP: 0 = Dinov2MLP (fc1 -> GELU -> fc2, HF modeling_dinov2.py:286-297); 1 = Dinov2SwiGLUFFN (HF:300-316,
+                       * Dinov2Config.use_swiglu_ffn: facebook/dinov2-giant): weights_in (2F x C) -> silu(x1) * x2 -> weights_out (C x F) with
+                       * F = (int(hidden * mlp_ratio * 2 / 3) + 7) / 8 * 8, which must be a multiple of 64; the layer then runs as separate
+                       * LayerNorm / GEMM launches with one elementwise launch for the gate (no token-panel kernel, no LayerNorm fold) */
 } cs_config;
 
 /* Replaces CrossScoreNet.__init__ (task/core.py:27-56). NULL on failure. */

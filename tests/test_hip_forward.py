@@ -47,6 +47,30 @@ def _compare(score, ref):
     return float(d.mean()), float(d.max())
 
 
+@pytest.mark.parametrize("tag,backbone,dtype", [("g9_swiglu_base_width", "synthetic/dinov2-swiglu-2l", "fp16"),
+                                               ("g9_swiglu_base_width", "synthetic/dinov2-swiglu-2l", "bf16")])
+def test_swiglu_backbone_vs_reference_golden(golden_dir, tag, backbone, dtype):
+    """The SwiGLU MLP of facebook/dinov2-giant (HF Dinov2SwiGLUFFN, Dinov2Config.use_swiglu_ffn; task/core.py:39-40 takes any from_pretrained):
+    weights_in GEMM, the gate as one elementwise launch, weights_out GEMM with the residual epilogue -- against the imported reference's score
+    map and last encoder layer (g9), and the launch census says which kernels ran."""
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    net, arch, sd = _net(backbone, int(g["seed"]))
+    assert arch.swiglu
+    net.operand_dtype = dtype
+    net.debug_capture(True)
+    q, r = synth.make_inputs(int(g["B"]), int(g["N"]), int(g["H"]), int(g["W"]), int(g["seed"]))
+    out = net(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), False, 0, False)
+    torch.cuda.synchronize()
+    mae, mx = _compare(out["score_map_ref_cross"], torch.from_numpy(g["score"]))
+    last = net.debug_read(f"enc_layer_{arch.enc_layers - 1}")[0].float().cpu().numpy()
+    rel = float(np.abs(last - g["enc_last_img0"]).mean() / np.sqrt((g["enc_last_img0"] ** 2).mean()))
+    k = net.forward_stats()["kernels"]
+    print(f"{tag} ({dtype}): score MAE {mae:.2e} max {mx:.2e}; last encoder layer mean |d| / RMS {rel:.2e}; {k}")
+    bound = 8.0 if dtype == "bf16" else 1.0
+    assert mae < MAE_TARGET * bound and mx < MAX_TOL * bound and rel < 1.5e-3 * bound
+    assert k.get("silu_mul", 0) == 2 * arch.enc_layers and "panel" not in k and "ln_stats" not in k  # (two encoder chunks x two layers)
+
+
 def test_tiny_nonsquare_vs_oracle_and_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "g0_tiny_all.npz"))
     net, arch, sd = _net(TINY, int(g["seed"]))
