@@ -223,7 +223,7 @@ int ffn_hidden(const cs_config& c) {
   return c.swiglu ? ((int)((double)f * 2 / 3) + 7) / 8 * 8 : f;
 }
 
-bool supported_dh(int dh) { return dh == 16 || dh == 48 || dh == 64 || dh == 96 || dh == 128; }
+bool supported_dh(int dh) { return dh == 16 || dh == 48 || dh == 64 || dh == 96 || dh == 128 || dh == 192; }
 
 struct Arena {  // carve 256-byte aligned pieces out of the workspace
   char* base; size_t off = 0;
@@ -476,10 +476,10 @@ const char* cs_last_error(void) { return g_err.c_str(); }
 cs_handle cs_create(const cs_config* cfg) {
   if (!cfg) { fail(CS_ERR_BAD_ARG, "cs_create: null config"); return nullptr; }
   const cs_config& c = *cfg;
-  if (c.hidden <= 0 || c.hidden % 64 || c.hidden > 1024) { fail(CS_ERR_UNSUPPORTED, "hidden=%d must be a multiple of 64 and <= 1024", c.hidden); return nullptr; }
+  if (c.hidden <= 0 || c.hidden % 64 || c.hidden > 1536) { fail(CS_ERR_UNSUPPORTED, "hidden=%d must be a multiple of 64 and <= 1536", c.hidden); return nullptr; }
   if (c.enc_layers <= 0 || c.enc_heads <= 0 || c.hidden % c.enc_heads) { fail(CS_ERR_BAD_ARG, "bad encoder layers/heads"); return nullptr; }
-  if (!supported_dh(c.hidden / c.enc_heads)) { fail(CS_ERR_UNSUPPORTED, "encoder head dim %d not in {16,48,64,96,128}", c.hidden / c.enc_heads); return nullptr; }
-  if (c.dec_heads <= 0 || c.hidden % c.dec_heads || !supported_dh(c.hidden / c.dec_heads)) { fail(CS_ERR_UNSUPPORTED, "decoder head dim %d not in {16,48,64,96,128}", c.dec_heads > 0 ? c.hidden / c.dec_heads : 0); return nullptr; }
+  if (!supported_dh(c.hidden / c.enc_heads)) { fail(CS_ERR_UNSUPPORTED, "encoder head dim %d not in {16,48,64,96,128,192}", c.hidden / c.enc_heads); return nullptr; }
+  if (c.dec_heads <= 0 || c.hidden % c.dec_heads || !supported_dh(c.hidden / c.dec_heads)) { fail(CS_ERR_UNSUPPORTED, "decoder head dim %d not in {16,48,64,96,128,192}", c.dec_heads > 0 ? c.hidden / c.dec_heads : 0); return nullptr; }
   if (c.dec_layers <= 0 || c.patch <= 0 || (c.patch * c.patch) % 4 || c.pos_grid <= 0 || c.pe_h <= 0 || c.pe_w <= 0 || c.mlp_ratio <= 0) { fail(CS_ERR_BAD_ARG, "bad config"); return nullptr; }
   if (c.act != 0 && c.act != 1) { fail(CS_ERR_BAD_ARG, "act must be 0 (sigmoid) or 1 (tanh)"); return nullptr; }
   if (c.act == 1 && c.pow_p != 1.0f) { fail(CS_ERR_BAD_ARG, "power factor applies only to the sigmoid range"); return nullptr; }
@@ -1586,7 +1586,7 @@ int cs_op_attention_weights(const uint16_t* Q, const uint16_t* K, int ldq, int l
 
 int cs_op_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float* out_f32,
                     uint16_t* out_f16, cs_stream stream) {
-  if (!x || !gamma || !beta || M <= 0 || C <= 0 || C % 4 || C > 1024) return fail(CS_ERR_BAD_ARG, "layernorm: C must be a multiple of 4 and <= 1024");
+  if (!x || !gamma || !beta || M <= 0 || C <= 0 || C % 4 || C > 2048) return fail(CS_ERR_BAD_ARG, "layernorm: C must be a multiple of 4 and <= 2048");
   HIPCHK(cs_layernorm_launch(x, M, C, gamma, beta, eps, out_f32, out_f16, g_op_bf16, (hipStream_t)stream));
   return 0;
 }

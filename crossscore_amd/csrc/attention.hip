@@ -38,7 +38,7 @@ struct AttnCfg {
   static constexpr int DT = (DH + 31) / 32;          // 32-wide d tiles of O^T
   static constexpr int CH = DH / 8;                  // 16-byte chunks per K/V row
   static constexpr int KROW = DH * 2 + 16;           // bytes; odd multiple of 16 -> ds_read_b128 conflict free
-  static constexpr int VROW = (DH <= 16) ? 64 : (DH <= 96 ? 192 : 320); // bytes; >= DT*64 and == 16 or 48 dwords (mod 64)
+  static constexpr int VROW = (DH <= 16) ? 64 : (DH <= 96 ? 192 : (DH <= 128 ? 320 : 448)); // bytes; >= DT*64 and == 16 or 48 dwords (mod 64)
   static_assert(VROW >= DT * 64 && (VROW / 4) % 32 == 16, "V row pitch");
   static constexpr int KTILE = 64 * KROW;
   static constexpr int VTILE = 64 * VROW;
@@ -47,7 +47,7 @@ struct AttnCfg {
 };
 
 template <int DH, bool BF>
-__global__ __launch_bounds__(256, 2) void cs_attn_kernel(CsAttnParams p) {
+__global__ __launch_bounds__(256, DH > 128 ? 1 : 2) void cs_attn_kernel(CsAttnParams p) {  // (dh = 192: 108 KB of LDS, one workgroup per CU anyway)
   using Cfg = AttnCfg<DH>;
   constexpr int KS = Cfg::KS, DT = Cfg::DT, CH = Cfg::CH, NIT = Cfg::NIT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -339,7 +339,7 @@ extern "C" int cs_attn_debug_read(unsigned long long* dst) { return (int)hipMemc
 #endif
 
 extern "C" const char* cs_attn_check(const CsAttnParams* p, int dh, int batch) {
-  if (dh != 16 && dh != 48 && dh != 64 && dh != 96 && dh != 128) return "attention: head dim must be 16, 48, 64, 96 or 128";
+  if (dh != 16 && dh != 48 && dh != 64 && dh != 96 && dh != 128 && dh != 192) return "attention: head dim must be 16, 48, 64, 96, 128 or 192";
   if (p->Lq <= 0 || p->Lk <= 0 || p->heads <= 0 || batch <= 0) return "attention: empty shape";
   if ((long long)batch * p->heads * ((p->Lq + 127) / 128) > (1ll << 30)) return "attention: grid too large";
   if (p->ldq % 8 || p->ldk % 8 || p->ldv % 8 || p->ldo % 4) return "attention: row strides must keep 16-byte rows";
@@ -356,6 +356,7 @@ extern "C" hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, h
     case 64: return p->bf16 ? launch<64, true>(*p, batch, stream) : launch<64, false>(*p, batch, stream);
     case 96: return p->bf16 ? launch<96, true>(*p, batch, stream) : launch<96, false>(*p, batch, stream);
     case 128: return p->bf16 ? launch<128, true>(*p, batch, stream) : launch<128, false>(*p, batch, stream);
+    case 192: return p->bf16 ? launch<192, true>(*p, batch, stream) : launch<192, false>(*p, batch, stream);  // (dinov2-giant's decoder: 1536 / 8)
   }
   return hipErrorInvalidValue;
 }

@@ -134,20 +134,19 @@ __global__ void patch_wsum_kernel(const float* __restrict__ w, int C, int PP, fl
 // -------------------------------------------------------------------------------------------------------
 // LayerNorm over C (biased variance, two-pass in registers): one wave per row, float4 per lane.
 // -------------------------------------------------------------------------------------------------------
-constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
-
-struct LnRow {
+// LN_MAXV float4 per lane: 4 for C <= 1024 (every BASELINE backbone), 8 for C <= 2048 (dinov2-giant's 1536); the launchers pick
+template <int LN_MAXV> struct LnRow {
   float4 v[LN_MAXV];
 };
 
-__device__ __forceinline__ void ln_load(const float* row, int C4, int lane, LnRow& r) {
+template <int LN_MAXV> __device__ __forceinline__ void ln_load(const float* row, int C4, int lane, LnRow<LN_MAXV>& r) {
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     r.v[i] = c < C4 ? reinterpret_cast<const float4*>(row)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
-__device__ __forceinline__ void ln_normalise(LnRow& r, int C, int C4, int lane, const float* g, const float* b, float eps) {
+template <int LN_MAXV> __device__ __forceinline__ void ln_normalise(LnRow<LN_MAXV>& r, int C, int C4, int lane, const float* g, const float* b, float eps) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
@@ -174,7 +173,7 @@ __device__ __forceinline__ void ln_normalise(LnRow& r, int C, int C4, int lane, 
     }
   }
 }
-__device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float* of32, h16_t* obf, int bf) {
+template <int LN_MAXV> __device__ __forceinline__ void ln_store(const LnRow<LN_MAXV>& r, int C4, int lane, float* of32, h16_t* obf, int bf) {
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
@@ -190,13 +189,14 @@ __device__ __forceinline__ void ln_store(const LnRow& r, int C4, int lane, float
   }
 }
 
+template <int LN_MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int M, int C, const float* __restrict__ g,
                                                          const float* __restrict__ b, float eps, float* of32, h16_t* obf, int bf) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int C4 = C / 4;
-  LnRow r;
+  LnRow<LN_MAXV> r;
   ln_load(x + (size_t)row * C, C4, lane, r);
   ln_normalise(r, C, C4, lane, g, b, eps);
   ln_store(r, C4, lane, of32 ? of32 + (size_t)row * C : nullptr, obf ? obf + (size_t)row * C : nullptr, bf);
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 //   v == 0 : q_f32[b*Np+p], q_f16[b*Np+p]      (decoder residual stream + GEMM operand)
 //   v >= 1 : mem_f16[b*N*Np + (v-1)*Np + p]    (cross-attention memory, GEMM operand only)
 // -------------------------------------------------------------------------------------------------------
+template <int LN_MAXV>
 __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __restrict__ x, int I, int img0, int Np, int C, int N,
                                                               const float* __restrict__ g, const float* __restrict__ b, float eps,
                                                               const float* __restrict__ pe, float* q_f32, h16_t* q_bf,
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void final_ln_split_kernel(const float* __rest
   // N < 0: every image is a reference view (reference-token cache): row goes to mem_bf[(img0+img)*Np + pp]
   const int bb = N < 0 ? 0 : (img0 + img) / (1 + N), v = N < 0 ? 1 + img0 + img : (img0 + img) - bb * (1 + N);
   const int C4 = C / 4;
-  LnRow r;
+  LnRow<LN_MAXV> r;
   ln_load(x + ((size_t)img * (Np + 1) + 1 + pp) * C, C4, lane, r);
   ln_normalise(r, C, C4, lane, g, b, eps);
 #pragma unroll
@@ -561,15 +562,20 @@ hipError_t cs_im2col_launch(const float* xq, const float* xr, int N, int img0, h
 
 hipError_t cs_layernorm_launch(const float* x, int M, int C, const float* g, const float* b, float eps, float* of32,
                                h16_t* obf, int bf, hipStream_t st) {
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, g, b, eps, of32, obf, bf);
+  if (C % 4 || C > 2048) return hipErrorInvalidValue;
+  if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, g, b, eps, of32, obf, bf);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, g, b, eps, of32, obf, bf);
   return hipGetLastError();
 }
 
 hipError_t cs_final_ln_split_launch(const float* x, int I, int img0, int Np, int C, int N, const float* g, const float* b, float eps,
                                     const float* pe, float* q_f32, h16_t* q_bf, h16_t* mem_bf, int bf, hipStream_t st) {
   const long long rows = (long long)I * Np;
-  hipLaunchKernelGGL(final_ln_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, I, img0, Np, C, N, g, b, eps, pe,
-                     q_f32, q_bf, mem_bf, bf);
+  if (C % 4 || C > 2048) return hipErrorInvalidValue;
+  if (C <= 1024)
+    hipLaunchKernelGGL(final_ln_split_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, I, img0, Np, C, N, g, b, eps, pe, q_f32, q_bf, mem_bf, bf);
+  else
+    hipLaunchKernelGGL(final_ln_split_kernel<8>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, I, img0, Np, C, N, g, b, eps, pe, q_f32, q_bf, mem_bf, bf);
   return hipGetLastError();
 }
 
@@ -628,6 +634,7 @@ hipError_t cs_attn_weights_launch(const CsAttnParams* p, int dh, int batch, int 
     case 64: hipLaunchKernelGGL(attn_weights_kernel<64>, grid, dim3(256), 0, st, *p, head, out); break;
     case 96: hipLaunchKernelGGL(attn_weights_kernel<96>, grid, dim3(256), 0, st, *p, head, out); break;
     case 128: hipLaunchKernelGGL(attn_weights_kernel<128>, grid, dim3(256), 0, st, *p, head, out); break;
+    case 192: hipLaunchKernelGGL(attn_weights_kernel<192>, grid, dim3(256), 0, st, *p, head, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

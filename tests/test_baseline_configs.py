@@ -176,6 +176,26 @@ def test_cfg1_predict_plumbing_518(tmp_path):
     assert abs(float(res["rows"][0][-1]) - float(ref.mean())) < 1e-3  # the per-image mean the CSV row carries
 
 
+def test_dinov2_giant_vs_oracle_and_batch_invariance():
+    """facebook/dinov2-giant (C = 1536, 40 layers, 24 heads, SwiGLU MLP with 4096 hidden features; decoder heads of 192 channels) -- the backbone
+    task/core.py:39-40 would load for model.backbone.from_pretrained=facebook/dinov2-giant.  The real depth at 224 x 224 (256 patches; the fp32
+    oracle on the host takes the two images through 40 layers), B=1, N=1 against the oracle, then B=3, N=2: item-wise bitwise invariance."""
+    net, arch, sd = _net("facebook/dinov2-giant", 11)
+    assert arch.swiglu and arch.ffn_hidden == 4096 and arch.hidden // arch.dec_heads == 192
+    q, r = synth.make_inputs_shard(0, 1, 1, 224, 224, 11)
+    score = _run(net, q, r)
+    assert net.nonfinite_count() == 0
+    ref = orc.forward(orc.to_torch(sd), dict(enc_heads=arch.enc_heads), torch.from_numpy(q), torch.from_numpy(r))["score_map_ref_cross"]
+    d = (score.cpu() - ref).abs()
+    print(f"dinov2-giant 224x224 vs oracle: MAE {float(d.mean()):.2e} max {float(d.max()):.2e}")
+    assert float(d.mean()) < MAE_TOL and float(d.max()) < 2 * MAX_TOL, (float(d.mean()), float(d.max()))
+    q3, r3 = synth.make_inputs_shard(0, 3, 2, 224, 224, 12)
+    s3 = _run(net, q3, r3)
+    one = _run(net, q3[1:2].copy(), r3[1:2].copy())
+    assert torch.equal(one[0], s3[1])
+    _properties(net, q3, r3, s3)
+
+
 def test_dinov2_large_518_vs_oracle_and_batch_invariance():
     """Beyond BASELINE's two backbones: facebook/dinov2-large (C = 1024, 24 layers, 16 heads; decoder heads of 128 channels) at 518x518.
     B=1, N=1 against the fp32 oracle on the host (two images through 24 layers: ~20 s), then B=3, N=2: item-wise bitwise invariance."""

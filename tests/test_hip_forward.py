@@ -48,7 +48,8 @@ def _compare(score, ref):
 
 
 @pytest.mark.parametrize("tag,backbone,dtype", [("g9_swiglu_base_width", "synthetic/dinov2-swiglu-2l", "fp16"),
-                                               ("g9_swiglu_base_width", "synthetic/dinov2-swiglu-2l", "bf16")])
+                                               ("g9_swiglu_base_width", "synthetic/dinov2-swiglu-2l", "bf16"),
+                                               ("g9_swiglu_giant_width", "synthetic/dinov2-giant-2l", "fp16")])  # hidden 1536, decoder heads of 192
 def test_swiglu_backbone_vs_reference_golden(golden_dir, tag, backbone, dtype):
     """The SwiGLU MLP of facebook/dinov2-giant (HF Dinov2SwiGLUFFN, Dinov2Config.use_swiglu_ffn; task/core.py:39-40 takes any from_pretrained):
     weights_in GEMM, the gate as one elementwise launch, weights_out GEMM with the residual epilogue -- against the imported reference's score

@@ -601,6 +601,7 @@ def _attn_ref(Q, K, V, heads, dh, prescaled=True):
     (64, 2, 128, 64, 1), (64, 6, 1370, 1370, 2), (64, 2, 31, 31, 3), (64, 1, 129, 65, 1),
     (48, 8, 1369, 1369, 1), (48, 8, 300, 1500, 2), (96, 8, 257, 513, 1), (16, 8, 30, 60, 2), (16, 8, 200, 333, 1),
     (128, 8, 257, 700, 1), (128, 2, 64, 64, 2),  # dinov2-large's decoder heads (C = 1024 / 8)
+    (192, 8, 257, 700, 1), (192, 2, 64, 129, 2),  # dinov2-giant's decoder heads (C = 1536 / 8)
 ])
 def test_attention_matches_fp32(dh, heads, Lq, Lk, B):
     g = _rng(dh * 1000 + Lq + Lk)
