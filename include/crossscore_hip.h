@@ -40,7 +40,7 @@ typedef void* cs_stream; /* hipStream_t */
 enum {
   CS_OK = 0,
   CS_ERR_BAD_ARG = 1,     /* shape / config the reference would also reject (ValueError / assert) */
-  CS_ERR_UNSUPPORTED = 2, /* legal for the reference, not built here (e.g. head dim outside {16,48,64,96,128}) */
+  CS_ERR_UNSUPPORTED = 2, /* legal for the reference, not built here (e.g. head dim outside {16,48,64,96,128,192}) */
   CS_ERR_STATE = 3,       /* wrong call order (forward before finalize, missing weight) */
   CS_ERR_HIP = 4          /* HIP runtime error; message carries hipGetErrorString */
 };
