@@ -32,7 +32,8 @@ const char* cs_gemm_check(const CsGemmParams* p, int epi);
 hipError_t cs_gemm_launch(const CsGemmParams* p, int epi, hipStream_t stream);
 const char* cs_attn_check(const CsAttnParams* p, int dh, int batch);
 hipError_t cs_attn_launch(const CsAttnParams* p, int dh, int batch, hipStream_t stream);
-hipError_t cs_preprocess_tables(int in_h, int in_w, int rs_h, int rs_w, int crop_y, int gh, int P, CsU8Tables* out, int* row_span);
+hipError_t cs_preprocess_tables(int in_h, int in_w, int rs_h, int rs_w, int crop_y, int gh, int P, CsU8Tables* out, int* row_span, unsigned* generation);
+void cs_preprocess_tables_hold(int on);
 hipError_t cs_im2col_launch(const float* q, const float* refs, int N, int img0, h16_t* out, int I, int H, int W, int P, int Kp,
                             float* pmean, int bf, hipStream_t st);
 hipError_t cs_patch_wsum_launch(const float* w, int C, int P, float* wsum, hipStream_t st);
@@ -860,17 +861,28 @@ static int forward_body(cs_handle h, int mode, const float* query, const float* 
       sl.cap = (size_t)n_desc;
     }
     if (!sl.ev) HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-    for (int i = 0; i < n_desc; ++i) {
-      const cs_u8_image& im = i < B ? u8->query[i] : u8->refs[i - B];
-      CsU8Desc d{};
-      if (im.h <= 0 || im.w <= 0 || im.rs_h <= 0 || im.rs_w <= 0 || im.row_bytes < 3 * im.w || im.crop_y < 0 || im.crop_x < 0 ||
-          im.crop_y + H > im.rs_h || im.crop_x + W > im.rs_w)
-        return fail(CS_ERR_BAD_ARG, "uint8 input %d: bad sizes (the %d x %d window must lie inside the resized image %d x %d)", i, H, W, im.rs_h, im.rs_w);
-      int span = 0;
-      HIPCHK(cs_preprocess_tables(im.h, im.w, im.rs_h, im.rs_w, im.crop_y, p.gh, P, &d.t, &span));
-      d.data = im.data; d.row_bytes = im.row_bytes; d.crop_y = im.crop_y; d.crop_x = im.crop_x;
-      u8_span = std::max(u8_span, span);
-      sl.host[i] = d;
+    // (the table cache holds 64 geometries and is dropped as a whole when a 65th arrives: if that happens while this call gathers its tables, the
+    //  pointers gathered before the drop are gone -- gather again; a second drop means the call itself names more than 64 geometries)
+    for (int attempt = 0;; ++attempt) {
+      unsigned gen0 = 0, gen = 0;
+      bool moved = false;
+      u8_span = 0;
+      for (int i = 0; i < n_desc; ++i) {
+        const cs_u8_image& im = i < B ? u8->query[i] : u8->refs[i - B];
+        CsU8Desc d{};
+        if (im.h <= 0 || im.w <= 0 || im.rs_h <= 0 || im.rs_w <= 0 || im.row_bytes < 3 * im.w || im.crop_y < 0 || im.crop_x < 0 ||
+            im.crop_y + H > im.rs_h || im.crop_x + W > im.rs_w)
+          return fail(CS_ERR_BAD_ARG, "uint8 input %d: bad sizes (the %d x %d window must lie inside the resized image %d x %d)", i, H, W, im.rs_h, im.rs_w);
+        int span = 0;
+        HIPCHK(cs_preprocess_tables(im.h, im.w, im.rs_h, im.rs_w, im.crop_y, p.gh, P, &d.t, &span, &gen));
+        if (i == 0) gen0 = gen;
+        moved = moved || gen != gen0;
+        d.data = im.data; d.row_bytes = im.row_bytes; d.crop_y = im.crop_y; d.crop_x = im.crop_x;
+        u8_span = std::max(u8_span, span);
+        sl.host[i] = d;
+      }
+      if (!moved) break;
+      if (attempt) return fail(CS_ERR_UNSUPPORTED, "uint8 input: more than 64 distinct image geometries in one call");
     }
     if (cs_patch_u8_runs(W, u8_span) <= 0)
       return fail(CS_ERR_UNSUPPORTED, "uint8 input: a patch row reaches %d source rows, more than the one-pass form holds; use cs_op_preprocess_u8 + cs_forward", u8_span);
@@ -1328,7 +1340,9 @@ static int forward_impl(cs_handle h, int mode, const float* query, const float* 
   if (h->ev_done && h->last_stream != st) HIPCHK(hipStreamWaitEvent(st, h->ev_done, 0));
   h->census.clear();
   const auto t0 = std::chrono::steady_clock::now();
+  if (u8) cs_preprocess_tables_hold(1);  // (the filter tables its descriptors point at stay put until everything is queued: preprocess.hip)
   const int rc = forward_body(h, mode, query, refs, ref_tokens, tokens_out, B, N, H, W, score_out, attn_out, head_id, mean_out, stream, u8);
+  if (u8) cs_preprocess_tables_hold(0);
   h->host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!h->ev_done) HIPCHK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
   HIPCHK(hipEventRecord(h->ev_done, st));
@@ -1376,7 +1390,7 @@ int cs_u8_input_supported(cs_handle h, const cs_u8_image* im, int H, int W) {
   if (im->h <= 0 || im->w <= 0 || im->rs_h <= 0 || im->rs_w <= 0 || im->crop_y < 0 || im->crop_x < 0 || im->crop_y + H > im->rs_h || im->crop_x + W > im->rs_w) return 0;
   CsU8Tables t{};
   int span = 0;
-  if (cs_preprocess_tables(im->h, im->w, im->rs_h, im->rs_w, im->crop_y, H / c.patch, c.patch, &t, &span) != hipSuccess) return 0;
+  if (cs_preprocess_tables(im->h, im->w, im->rs_h, im->rs_w, im->crop_y, H / c.patch, c.patch, &t, &span, nullptr) != hipSuccess) return 0;
   return cs_patch_u8_runs(W, span) > 0 ? 1 : 0;
 }
 
@@ -1633,7 +1647,7 @@ int cs_op_patch_embed_fused_u8(const uint8_t* imgs, int I, int in_h, int in_w, i
   hipStream_t st = (hipStream_t)stream;
   CsU8Tables t{};
   int span = 0;
-  HIPCHK(cs_preprocess_tables(in_h, in_w, rs_h, rs_w, crop_y, H / P, P, &t, &span));
+  HIPCHK(cs_preprocess_tables(in_h, in_w, rs_h, rs_w, crop_y, H / P, P, &t, &span, nullptr));
   if (cs_patch_u8_runs(W, span) <= 0) return fail(CS_ERR_UNSUPPORTED, "patch_embed_fused_u8: %d source rows per patch row do not fit", span);
   std::vector<CsU8Desc> hd(I);
   for (int i = 0; i < I; ++i) { hd[i].data = imgs + (size_t)i * in_h * row_bytes; hd[i].t = t; hd[i].row_bytes = row_bytes; hd[i].crop_y = crop_y; hd[i].crop_x = crop_x; }

@@ -70,7 +70,8 @@ struct TableEntry {
   std::vector<int> h_ymin, h_yend;  // host copy of the row table (first source row, one past the last) for cs_preprocess_tables' row spans
 };
 std::vector<TableEntry> g_tabs;
-std::mutex g_tabs_mu;  // forwards of several handles may come from several host threads (pipeline.py)
+std::recursive_mutex g_tabs_mu;  // forwards of several handles may come from several host threads (pipeline.py)
+unsigned g_tabs_gen = 0;  // counts the times the cache was dropped: device pointers handed out under an older count are gone
 
 // the entry of (device, in_h, in_w, rs_h, rs_w), built and uploaded on first use; the caller holds g_tabs_mu
 hipError_t table_entry(int in_h, int in_w, int rs_h, int rs_w, const TableEntry** out) {
@@ -83,6 +84,7 @@ hipError_t table_entry(int in_h, int in_w, int rs_h, int rs_w, const TableEntry*
     if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
     for (TableEntry& t : g_tabs) { (void)hipFree(t.d_int); (void)hipFree(t.d_w); }
     g_tabs.clear();
+    ++g_tabs_gen;
   }
   AxisTable tx, ty;
   build_axis(in_w, rs_w, tx);
@@ -221,7 +223,7 @@ extern "C" hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_
                        mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
     return hipGetLastError();
   }
-  std::lock_guard<std::mutex> lock(g_tabs_mu);
+  std::lock_guard<std::recursive_mutex> lock(g_tabs_mu);
   const TableEntry* hit = nullptr;
   hipError_t e = table_entry(in_h, in_w, rs_h, rs_w, &hit);
   if (e != hipSuccess) return e;
@@ -244,8 +246,11 @@ extern "C" hipError_t cs_preprocess_launch(const uint8_t* img, int in_h, int in_
 // The filter tables of one resize geometry for the one-pass input stage (patch.hip, cs_patch_fused_u8_launch): device pointers that stay valid until the
 // cache is dropped (65th geometry, behind a device synchronisation), and the largest number of source rows any row of `gh` P-pixel patches starting
 // at resized row crop_y needs (first tap of its first pixel row .. last tap of its last): what the kernel has to hold in LDS per channel.
-extern "C" hipError_t cs_preprocess_tables(int in_h, int in_w, int rs_h, int rs_w, int crop_y, int gh, int P, CsU8Tables* out, int* row_span) {
-  std::lock_guard<std::mutex> lock(g_tabs_mu);
+// *generation = the cache's drop count when the pointers were handed out: a caller that gathers tables of several geometries compares it across its
+// calls and starts over when it moved (the drop waits for the device, so work already queued is never affected).
+extern "C" hipError_t cs_preprocess_tables(int in_h, int in_w, int rs_h, int rs_w, int crop_y, int gh, int P, CsU8Tables* out, int* row_span,
+                                           unsigned* generation) {
+  std::lock_guard<std::recursive_mutex> lock(g_tabs_mu);
   const TableEntry* hit = nullptr;
   hipError_t e = table_entry(in_h, in_w, rs_h, rs_w, &hit);
   if (e != hipSuccess) return e;
@@ -262,5 +267,14 @@ extern "C" hipError_t cs_preprocess_tables(int in_h, int in_w, int rs_h, int rs_
     span = hi - T.h_ymin[r0] > span ? hi - T.h_ymin[r0] : span;
   }
   *row_span = span;
+  if (generation) *generation = g_tabs_gen;
   return hipSuccess;
+}
+
+// A forward that carries table pointers in its descriptors holds this from its first cs_preprocess_tables call until its last launch is queued: the
+// cache is only ever dropped under the same mutex, behind a device synchronisation, so no other thread's drop can fall between this call's
+// gathering and its launches (its own drop, while gathering, shows in the generation count).
+extern "C" void cs_preprocess_tables_hold(int on) {
+  if (on) g_tabs_mu.lock();
+  else g_tabs_mu.unlock();
 }

@@ -169,6 +169,13 @@ def test_forwards_fed_from_uint8_are_bit_identical(backbone, dtype):
     assert torch.equal(cached["score_map_ref_cross"], want["score_map_ref_cross"]) and torch.equal(cached["score_mean_ref_cross"], want["score_mean_ref_cross"])
     stats = net.forward_stats()
     assert stats["kernels"].get("patch_u8", 0) >= 1 and "patch" not in stats["kernels"], stats["kernels"]
+    # the filter-table cache holds 64 geometries and is dropped as a whole behind a device synchronisation when a 65th arrives: 70 other geometries
+    # later the same call rebuilds what it needs and gives the same bits
+    for k in range(70):
+        net.u8_input_supported(U8Image(None, 200 + k, 260, (70 + 14 * (k % 3), 98), 0, 0), (70, 98), dev)
+    again = net.forward_u8(q_u8, r_u8, True, 3, True)
+    torch.cuda.synchronize()
+    assert torch.equal(again["score_map_ref_cross"], want["score_map_ref_cross"])
     # a 114 x down-scale: 14 pixel rows reach 1 800 source rows, more than the launch holds for even one patch per run (1 170)
     far = U8Image(None, 8000, 9600, (70, 84), 0, 0)
     assert not net.u8_input_supported(far, size, dev)
