@@ -133,23 +133,38 @@ __global__ __launch_bounds__(256, 2) void cs_patch_fused_kernel(PatchParams p) {
     const int R0 = d.t.ymin[ry0];
     int R1 = R0;
     for (int dy = 0; dy < PF_P; ++dy) R1 = max(R1, d.t.ymin[ry0 + dy] + d.t.ysize[ry0 + dy]);
-    const int nout = (R1 - R0) * wpx;
 #pragma unroll 1
     for (int ch = 0; ch < 3; ++ch) {
       __syncthreads();  // the table is there / the previous channel's height pass is done
-      for (int o = tid; o < nout; o += 256) {
-        const int r = o / wpx, rx = X0 + (o - r * wpx);
-        float a = 0.f;
+      // a lane owns strip columns lane, lane + 64, ..: the column's first tap, tap count and weights are fetched once and serve every source row;
+      // the rows go round the four waves.  Same products, same order as u8_resize_w_kernel: a = p0 w0, then fma tap by tap.
+      for (int xc = lane; xc < wpx; xc += 64) {
+        const int rx = X0 + xc;
+        int n = 0;
+        const uint8_t* col = nullptr;
+        const float* w = nullptr;
+        float wr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (d.data) {
-          const int n = d.t.xsize[rx];
-          const uint8_t* src = d.data + (size_t)(R0 + r) * d.row_bytes + (size_t)d.t.xmin[rx] * 3 + ch;
-          const float* w = d.t.wx + (size_t)rx * d.t.taps_x;
-          for (int j = 0; j < n; ++j) {
-            const float px = lut[src[3 * j]];
-            a = j == 0 ? px * w[j] : __builtin_fmaf(px, w[j], a);
-          }
+          n = d.t.xsize[rx];
+          col = d.data + (size_t)d.t.xmin[rx] * 3 + ch;
+          w = d.t.wx + (size_t)rx * d.t.taps_x;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (j < n) wr[j] = w[j];
         }
-        tmp[o] = a;
+        for (int r = wv; r < R1 - R0; r += 4) {
+          float a = 0.f;
+          if (n > 0) {
+            const uint8_t* src = col + (size_t)(R0 + r) * d.row_bytes;
+            a = lut[src[0]] * wr[0];
+            if (n <= 8) {
+#pragma unroll
+              for (int j = 1; j < 8; ++j) if (j < n) a = __builtin_fmaf(lut[src[3 * j]], wr[j], a);
+            } else {
+              for (int j = 1; j < n; ++j) a = __builtin_fmaf(lut[src[3 * j]], w[j], a);
+            }
+          }
+          tmp[r * wpx + xc] = a;
+        }
       }
       __syncthreads();
       const float mu = p.mean[ch], sd = p.stdv[ch];
