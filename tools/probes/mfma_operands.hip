@@ -232,6 +232,39 @@ template <int RANDOM> void run7(unsigned long long* cyc, const char* what) {
   double m = 0; for (int i = 0; i < 256; ++i) m += h[i]; m /= 256;
   printf("%-70s %.1f cycles per 32x32x16-equivalent; %.1f us per launch -> %.2f GHz\n", what, m / (400 * 96.0), ms * 1e3 / 50, m / (ms * 1e3 / 50) / 1e3);
 }
+
+// k8: k6 with the A operand's mantissas cut short (the table's first KiB, which the loop's fragment reads come from, keeps only KEEP mantissa bits
+// per half; the B registers are loaded from beyond it and stay full random): does the power the MFMA draws depend on how many mantissa bits of ONE
+// operand toggle -- i.e. would 16-bit weights rounded to fewer mantissa bits (bf16's 7 of fp16's 10) buy clock at the power cap?
+template <int KEEP>
+__global__ __launch_bounds__(256) void k8(unsigned long long* cyc, int iters) {
+  __shared__ unsigned lds[2048];
+  unsigned long long t0, t1;
+  const unsigned cut = 0xffffu & ~((1u << (10 - KEEP)) - 1u), m2 = cut | (cut << 16);
+  for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = (((i + 1) * 2654435761u) & 0xbbffbbffu) & (i < 260 ? m2 : 0xffffffffu);
+  __syncthreads();
+  asm volatile("v_mov_b32 v202, %0" :: "v"((unsigned)(size_t)lds + (threadIdx.x & 63) * 16) : "v202");
+  asm volatile(LD4(0, 0) LD4(16, 0) LD4(64, 1056) LD4(80, 1072) LD4(96, 1088) LD4(112, 1104) LD4(128, 1120) LD4(144, 1136) "ds_read_b64 v[200:201], v202 offset:128\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile(LD(4, 0) LD(8, 0) LD(12, 0) LD(20, 0) LD(24, 0) LD(28, 0) "s_waitcnt lgkmcnt(0)" ::: "memory");  // every A register from the cut region
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
+  for (int it = 0; it < iters; ++it) {
+    asm volatile(ROW(G3) ROW(G3) ROW(G3) ROW(G3) ROW(G3) ROW(G3) ::: "memory");
+    asm volatile(GRP("a", "v", 0, 64) GRP("a", "v", 12, 80) GRP("a", "v", 0, 96) GRP("a", "v", 12, 112) ::: "memory");
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+  asm volatile("" ::: "v0", "v31", "v64", "v159", "v200", "v201", "v202", "v255", "a0", "a255");
+}
+template <int KEEP> void run8(unsigned long long* cyc, const char* what) {
+  for (int r = 0; r < 30; ++r) k8<KEEP><<<256, 256>>>(cyc, 400);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0); for (int r = 0; r < 50; ++r) k8<KEEP><<<256, 256>>>(cyc, 400); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+  double m = 0; for (int i = 0; i < 256; ++i) m += h[i]; m /= 256;
+  printf("%-70s %.1f cycles per MFMA; %.1f us per launch -> %.2f GHz\n", what, m / (400 * 96.0), ms * 1e3 / 50, m / (ms * 1e3 / 50) / 1e3);
+}
 int main() {
   unsigned long long* cyc; hipMalloc(&cyc, 256 * 8);
   run<0>(cyc, "A cycles 8 quads, B cycles 24 quads (v64..), 2 accumulators");
@@ -260,6 +293,12 @@ int main() {
   run5<1>(cyc, "the same with accumulator reads between the two groups");
   run6<0>(cyc, "fc1 gaps (MFMA + ds_read + 4 VALU) + fc2 group, zero data");
   run6<1>(cyc, "fc1 gaps (MFMA + ds_read + 4 VALU) + fc2 group, random data");
+  run8<10>(cyc, "32x32x16, A operand with 10 mantissa bits (full), B full random");
+  run8<7>(cyc, "32x32x16, A operand with 7 mantissa bits (bf16's), B full random");
+  run8<4>(cyc, "32x32x16, A operand with 4 mantissa bits, B full random");
+  run8<0>(cyc, "32x32x16, A operand powers of two only, B full random");
+  run8<10>(cyc, "32x32x16 again, A full");
+  run8<7>(cyc, "32x32x16 again, A with 7 mantissa bits");
   run7<0>(cyc, "16x16x32: fc1 gaps + fc2 group, zero data");
   run7<1>(cyc, "16x16x32: fc1 gaps + fc2 group, random data");
   run6<1>(cyc, "32x32x16 again: fc1 gaps + fc2 group, random data");
